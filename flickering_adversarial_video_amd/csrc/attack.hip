@@ -1,0 +1,351 @@
+// Perturbation kernels (HBM-bound): apply + clip fused with the stem's space-to-depth staging, the
+// delta-gradient reduction with the clip masks, and regulariser-gradient + Adam.
+//
+// Reference maths: kinetics_i3d_utils.py:100-142 (apply), :172-200 (regularisers/metrics),
+// i3d_adversarial_main_single_video_npy.py:56-59,79-84 (loss, TF Adam); torch dialect model.py:80-101,
+// 198-209, 868.  Closed forms: SURVEY Appendix C.
+#include "flk_internal.h"
+
+template <typename TO> __device__ static inline void store32(char* dst, const float* v);   // 32 channels
+template <> __device__ inline void store32<float>(char* dst, const float* v) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ((float4*)dst)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+template <> __device__ inline void store32<bf16_t>(char* dst, const float* v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[8 * i + e];
+    ((bf16x8*)dst)[i] = o;
+  }
+}
+template <typename TI> __device__ static inline void load24(const char* src, float* v);     // first 24 of 32 channels
+template <> __device__ inline void load24<float>(const char* src, float* v) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { const float4 f = ((const float4*)src)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+}
+template <> __device__ inline void load24<bf16_t>(const char* src, float* v) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const uint4 u = ((const uint4*)src)[i];
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = __uint_as_float(w[k] << 16); v[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+  }
+}
+
+// six consecutive values x[b,t,h,2*w2 .. 2*w2+1, 0..2]
+__device__ static inline void load6(const flk_apply_args& a, size_t off, float* x) {
+  if (a.x_is_u8) {
+    const uint16_t* p = (const uint16_t*)((const uint8_t*)a.x + off);   // off = 6*k: 2-byte aligned
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    const uint32_t by[6] = {w0 & 255, w0 >> 8, w1 & 255, w1 >> 8, w2 & 255, w2 >> 8};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = (float)by[i] * a.x_scale + a.x_bias;
+  } else {
+    const float2* p = (const float2*)((const float*)a.x + off);        // off = 6*k: 8-byte aligned
+    const float2 a0 = p[0], a1 = p[1], a2 = p[2];
+    x[0] = a0.x; x[1] = a0.y; x[2] = a1.x; x[3] = a1.y; x[4] = a2.x; x[5] = a2.y;
+  }
+}
+
+__device__ static inline float clipf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+__device__ static inline int wrap(int t, int T) { t %= T; return t < 0 ? t + T : t; }
+
+// perturbation added at frame t (before adv_flag): p'[t] = p[(t - shift_p) mod T] (tf.roll), p = clip(delta)/std
+__device__ static inline float pert_at(const flk_apply_args& a, int t, int h, int w, int c) {
+  const int ts = wrap(t - a.shift_p, a.T);
+  float d = a.delta_dense ? a.delta[(((size_t)ts * a.H + h) * a.W + w) * 3 + c] : a.delta[ts * 3 + c];
+  if (a.dclip > 0.f) d = clipf(d, -a.dclip, a.dclip);
+  return d * a.inv_std[c];
+}
+
+// ---- apply: one thread = one space-to-depth output position (2x2x2 input cells x 3 channels) ----
+template <typename TO>
+__global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, char* out) {
+  const int T2 = a.T / 2, H2 = a.H / 2, W2 = a.W / 2;
+  const long total = (long)a.B * T2 * H2 * W2;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    long r = gid;
+    const int w2 = r % W2; r /= W2;
+    const int h2 = r % H2; r /= H2;
+    const int t2 = r % T2;
+    const int b = r / T2;
+    float v[32];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int t = 2 * t2 + qt;
+      const int tx = wrap(t - a.shift_x, a.T);      // x'[t] = x[(t - shift_x) mod T]
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) {
+        const int h = 2 * h2 + qh;
+        float x[6];
+        load6(a, ((((size_t)b * a.T + tx) * a.H + h) * a.W + 2 * w2) * 3, x);
+#pragma unroll
+        for (int qw = 0; qw < 2; ++qw)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float pv = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, t, h, 2 * w2 + qw, c) : 0.f;
+            v[(qt * 4 + qh * 2 + qw) * 3 + c] = clipf(x[qw * 3 + c] + pv, a.lo, a.hi);
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 24; i < 32; ++i) v[i] = 0.f;
+    store32<TO>(out + (size_t)gid * 32 * sizeof(TO), v);
+  }
+}
+
+static int check_apply(const flk_apply_args* a) {
+  FLK_REQUIRE(a && a->x && a->delta, "flk_perturb: null argument");
+  FLK_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && a->T % 2 == 0 && a->H % 2 == 0 && a->W % 2 == 0,
+              "flk_perturb: T,H,W must be positive and even (got %d,%d,%d)", a->T, a->H, a->W);
+  FLK_REQUIRE(a->lo <= a->hi, "flk_perturb: lo > hi");
+  return FLK_OK;
+}
+
+extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dtype, void* stream) {
+  int rc = check_apply(a);
+  if (rc) return rc;
+  FLK_REQUIRE(out, "flk_perturb_apply_s2d: null out");
+  const long total = (long)a->B * (a->T / 2) * (a->H / 2) * (a->W / 2);
+  const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  if (dtype == FLK_BF16) hipLaunchKernelGGL(apply_s2d_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (char*)out);
+  else if (dtype == FLK_F32) hipLaunchKernelGGL(apply_s2d_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (char*)out);
+  else { flk_set_error("flk_perturb_apply_s2d: bad dtype"); return FLK_EINVAL; }
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+// ---- delta gradient --------------------------------------------------------------------------
+// stage 1: workgroup (b, t2, chunk of h2 rows) -> partials[wg][qt][c] = sum over its cells of
+//          g * 1[lo <= x' + a p' <= hi]      (both clip gradients are inclusive at the bounds)
+static inline int grad_nchunk(int B, int T, int H) {
+  const int bt = B * (T / 2), H2 = H / 2;
+  int n = (1024 + bt - 1) / bt;
+  if (n > H2) n = H2;
+  if (n < 1) n = 1;
+  return n;
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a, const char* gx, int nchunk, float* partials) {
+  const int T2 = a.T / 2, H2 = a.H / 2, W2 = a.W / 2;
+  int bid = blockIdx.x;
+  const int chunk = bid % nchunk; bid /= nchunk;
+  const int t2 = bid % T2;
+  const int b = bid / T2;
+  const int h_lo = (int)((long)H2 * chunk / nchunk), h_hi = (int)((long)H2 * (chunk + 1) / nchunk);
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int ncell = (h_hi - h_lo) * W2;
+  for (int i = threadIdx.x; i < ncell; i += 256) {
+    const int h2 = h_lo + i / W2, w2 = i % W2;
+    float g[24];
+    load24<TI>(gx + ((((size_t)b * T2 + t2) * H2 + h2) * W2 + w2) * 32 * sizeof(TI), g);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int t = 2 * t2 + qt, tx = wrap(t - a.shift_x, a.T);
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) {
+        const int h = 2 * h2 + qh;
+        float x[6];
+        load6(a, ((((size_t)b * a.T + tx) * a.H + h) * a.W + 2 * w2) * 3, x);
+#pragma unroll
+        for (int qw = 0; qw < 2; ++qw)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float u = x[qw * 3 + c] + a.adv_flag * pert_at(a, t, h, 2 * w2 + qw, c);
+            if (u >= a.lo && u <= a.hi) acc[qt * 3 + c] += g[(qt * 4 + qh * 2 + qw) * 3 + c];
+          }
+      }
+    }
+  }
+  __shared__ float red[4][6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6)
+    partials[(size_t)blockIdx.x * 6 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// stage 2: thread (t,c) sums partials over (b, chunk) in a fixed order; maps frame t back to the delta
+// index it was rolled from; applies adv_flag, 1/std and the delta clip mask.
+__global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const float* partials, float* gdelta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.T * 3) return;
+  const int t = i / 3, c = i % 3, t2 = t >> 1, qt = t & 1, T2 = a.T / 2;
+  float s = 0.f;
+  for (int b = 0; b < a.B; ++b)
+    for (int k = 0; k < nchunk; ++k) s += partials[(((size_t)b * T2 + t2) * nchunk + k) * 6 + qt * 3 + c];
+  const int ts = wrap(t - a.shift_p, a.T);
+  const float d = a.delta[ts * 3 + c];
+  const bool pass = !(a.dclip > 0.f) || (d >= -a.dclip && d <= a.dclip);
+  gdelta[ts * 3 + c] = pass ? s * a.adv_flag * a.inv_std[c] : 0.f;
+}
+
+// dense delta ("L12" baseline, kinetics_i3d_utils.py:308-521): no spatial reduction, sum over the batch.
+template <typename TI>
+__global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a, const char* gx, float* gdelta) {
+  const int T2 = a.T / 2, H2 = a.H / 2, W2 = a.W / 2;
+  const long total = (long)T2 * H2 * W2;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    long r = gid;
+    const int w2 = r % W2; r /= W2;
+    const int h2 = r % H2;
+    const int t2 = r / H2;
+    float acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) acc[k] = 0.f;
+    for (int b = 0; b < a.B; ++b) {
+      float g[24];
+      load24<TI>(gx + ((((size_t)b * T2 + t2) * H2 + h2) * W2 + w2) * 32 * sizeof(TI), g);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int t = 2 * t2 + qt, tx = wrap(t - a.shift_x, a.T);
+#pragma unroll
+        for (int qh = 0; qh < 2; ++qh) {
+          float x[6];
+          load6(a, ((((size_t)b * a.T + tx) * a.H + 2 * h2 + qh) * a.W + 2 * w2) * 3, x);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const float u = x[k] + a.adv_flag * pert_at(a, t, 2 * h2 + qh, 2 * w2 + k / 3, k % 3);
+            if (u >= a.lo && u <= a.hi) acc[(qt * 4 + qh * 2) * 3 + k] += g[(qt * 4 + qh * 2) * 3 + k];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const int t = 2 * t2 + qt, ts = wrap(t - a.shift_p, a.T), c = k % 3;
+          const size_t di = (((size_t)ts * a.H + 2 * h2 + qh) * a.W + 2 * w2 + k / 3) * 3 + c;
+          const float d = a.delta[di];
+          const bool pass = !(a.dclip > 0.f) || (d >= -a.dclip && d <= a.dclip);
+          gdelta[di] = pass ? acc[(qt * 4 + qh * 2) * 3 + k] * a.adv_flag * a.inv_std[c] : 0.f;
+        }
+  }
+}
+
+extern "C" int64_t flk_perturb_grad_scratch_bytes(int B, int T, int H, int W) {
+  (void)W;
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  return (int64_t)B * (T / 2) * grad_nchunk(B, T, H) * 6 * sizeof(float);
+}
+
+extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s2d, int dtype, float* gdelta,
+                                       float* partials, void* stream) {
+  int rc = check_apply(a);
+  if (rc) return rc;
+  FLK_REQUIRE(gx_s2d && gdelta, "flk_perturb_grad_reduce: null argument");
+  FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_perturb_grad_reduce: bad dtype");
+  hipStream_t s = (hipStream_t)stream;
+  if (a->delta_dense) {
+    const long total = (long)(a->T / 2) * (a->H / 2) * (a->W / 2);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (dtype == FLK_BF16) hipLaunchKernelGGL(grad_dense_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
+    else hipLaunchKernelGGL(grad_dense_kernel<float>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
+  } else {
+    FLK_REQUIRE(partials, "flk_perturb_grad_reduce: null scratch");
+    const int nchunk = grad_nchunk(a->B, a->T, a->H);
+    const unsigned grid = (unsigned)(a->B * (a->T / 2) * nchunk);
+    if (dtype == FLK_BF16) hipLaunchKernelGGL(grad_reduce_stage1<bf16_t>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
+    else hipLaunchKernelGGL(grad_reduce_stage1<float>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
+    hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128), dim3(128), 0, s, *a, nchunk, partials, gdelta);
+  }
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+// ---- regulariser gradient + Adam: one workgroup, delta is [T,3] ----------------------------------
+__device__ static inline float block_sum(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ static inline float block_max(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+constexpr int ADAM_PER = 8;  // 256 threads x 8 >= 3*T  (T <= 682)
+
+__global__ __launch_bounds__(256) void reg_adam_kernel(const flk_adam_args a, const float* g_adv, float* delta, float* m, float* v,
+                                                       float* scalars) {
+  __shared__ float sh[4];
+  const int T = a.T, N = 3 * T;
+  const float dyn = a.dyn_max_norm;
+  // value the regulariser sees: raw delta (TF, kinetics_i3d_utils.py:172) or clamp(delta) (torch, model.py:1078)
+  auto rv = [&](int t, int c) -> float {
+    const float d = delta[wrap(t, T) * 3 + c];
+    return a.torch_dialect ? clipf(d, -dyn, dyn) : d;
+  };
+  float nd[ADAM_PER], nm[ADAM_PER], nv[ADAM_PER];
+  float s_norm = 0.f, s_diff = 0.f, s_lap = 0.f, s_abs = 0.f, s_rough = 0.f, s_max = -INFINITY, s_min = INFINITY;
+  const float lr_tf = a.lr * sqrtf(1.f - powf(a.adam_b2, (float)a.step)) / (1.f - powf(a.adam_b1, (float)a.step));
+  const float bc1 = 1.f - powf(a.adam_b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.adam_b2, (float)a.step));
+#pragma unroll
+  for (int k = 0; k < ADAM_PER; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i >= N) continue;
+    const int t = i / 3, c = i % 3;
+    const float x0 = rv(t, c), xm1 = rv(t - 1, c), xp1 = rv(t + 1, c), xm2 = rv(t - 2, c), xp2 = rv(t + 2, c);
+    const float l0 = -2.f * x0 + xm1 + xp1;         // laplacian at t, t-1, t+1
+    const float lm = -2.f * xm1 + xm2 + x0;
+    const float lp = -2.f * xp1 + x0 + xp2;
+    const float df = x0 - xm1;
+    s_norm += x0 * x0; s_diff += df * df; s_lap += l0 * l0;
+    const float raw = delta[i], rawm1 = delta[wrap(t - 1, T) * 3 + c];
+    s_abs += fabsf(raw); s_rough += fabsf(raw - rawm1);
+    s_max = fmaxf(s_max, raw); s_min = fminf(s_min, raw);
+    float greg = a.beta1 * 2.f * x0 / N + a.beta2 * 2.f * (-l0) / N + a.beta3 * 2.f * (-2.f * l0 + lm + lp) / N;
+    if (a.torch_dialect && !(raw >= -dyn && raw <= dyn)) greg = 0.f;   // clamp gradient, inclusive
+    const float g = a.g_scale * g_adv[i] + a.beta0 * greg;
+    const float mi = a.adam_b1 * m[i] + (1.f - a.adam_b1) * g;
+    const float vi = a.adam_b2 * v[i] + (1.f - a.adam_b2) * g * g;
+    nm[k] = mi; nv[k] = vi;
+    if (a.torch_dialect) nd[k] = raw - (a.lr / bc1) * mi / (sqrtf(vi) / bc2s + a.adam_eps);   // torch-1.4 Adam
+    else nd[k] = raw - lr_tf * mi / (sqrtf(vi) + a.adam_eps);                                   // TF-1.15 AdamOptimizer
+  }
+  const float t_norm = block_sum(s_norm, sh), t_diff = block_sum(s_diff, sh), t_lap = block_sum(s_lap, sh);
+  const float t_abs = block_sum(s_abs, sh), t_rough = block_sum(s_rough, sh);
+  const float t_max = block_max(s_max, sh), t_min = -block_max(-s_min, sh);
+  __syncthreads();   // every neighbour read of delta is done
+#pragma unroll
+  for (int k = 0; k < ADAM_PER; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i >= N) continue;
+    delta[i] = nd[k]; m[i] = nm[k]; v[i] = nv[k];
+  }
+  if (threadIdx.x == 0 && scalars) {
+    const float norm = t_norm / N + 1e-12f, diff = t_diff / N + 1e-12f, lap = t_lap / N + 1e-12f;
+    scalars[0] = a.beta1 * norm + a.beta2 * diff + a.beta3 * lap;
+    scalars[1] = norm; scalars[2] = diff; scalars[3] = lap;
+    scalars[4] = t_abs / N; scalars[5] = t_rough / N; scalars[6] = t_max; scalars[7] = t_min;
+  }
+}
+
+extern "C" int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, float* delta, float* m, float* v,
+                                    float* scalars, void* stream) {
+  FLK_REQUIRE(a && g_adv && delta && m && v, "flk_perturb_reg_adam: null argument");
+  FLK_REQUIRE(a->T > 0 && 3 * a->T <= 256 * ADAM_PER, "flk_perturb_reg_adam: T out of range (%d)", a->T);
+  FLK_REQUIRE(a->step >= 1, "flk_perturb_reg_adam: step is 1-based");
+  hipLaunchKernelGGL(reg_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}

@@ -1,0 +1,366 @@
+// 3-D convolution as implicit GEMM on the CDNA4 matrix cores, with LDS-staged T x H x W halo tiles.
+//
+// One kernel serves every convolution of I3D (Unit3D, i3d.py:51-71) and VideoResNet, forward and
+// data-gradient: taps, strides, pads, channel slices and the output-position map are runtime
+// parameters; only the element type and the output-channel tile width are template parameters.
+//
+// Mapping (per 256-thread workgroup = 4 waves):
+//   * tile = up to 256 output positions (a Tt x Ht x Wt box) x BN = 16*NF output channels;
+//   * K loop = input-channel slabs (64 bytes of channels per position) x taps;
+//   * per slab the input HALO box ((Tt-1)*st+kt) x ... is staged ONCE into LDS and every tap reads
+//     it at a constant byte offset (27x less L2 traffic than a per-tap im2col gather);
+//   * LDS halo image = 4 planes [16-byte channel chunk][halo position]: the 16 positions x 4 chunks
+//     one ds_read_b128 wave-instruction touches are bank-conflict-free for consecutive positions
+//     (planes 0/1 and 2/3 aligned mod 256 B, the pairs 32 B apart so the staging writes are 2-way);
+//   * weights arrive pre-packed in MFMA A-fragment order (flk_internal.h), staged per (slab, tap)
+//     through a double-buffered LDS tile with a register prefetch one step ahead;
+//   * MFMA orientation: A = weights (rows = output channels), B = activations (cols = positions),
+//     so an accumulator lane owns ONE position and 4*NF consecutive channels -> 16-byte epilogue
+//     accesses for scale/bias/add/mask and stores.
+//   * bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32, parity mode).
+#include "flk_internal.h"
+
+struct ConvKP {
+  const char* in; const char* w; char* out;
+  const float* scale; const float* bias; const char* add; const char* mask;
+  int in_ld, in_coff, cin;
+  int B, Ti, Hi, Wi;
+  int kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int To, Ho, Wo;
+  int out_ld, out_coff, cout;
+  int OT, OH, OW, ost, osh, osw, oot, ooh, oow;
+  int add_ld, add_coff, mask_ld, mask_coff, relu;
+  int Tt, Ht, Wt, nTt, nTh, nTw, rows;
+  int Th, Hh, Wh, P, plane_b;
+  int nslab, ntaps, cout_frags;
+};
+
+template <typename T> struct Prec;
+template <> struct Prec<bf16_t> {
+  static constexpr int EPL = 8;
+  typedef bf16x8 frag;
+  __device__ static inline void mma(const frag& a, const frag& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  __device__ static inline void to_f32(const uint4& u, float* f) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static inline uint4 from_f32(const float* f) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
+    return __builtin_bit_cast(uint4, v);
+  }
+};
+template <> struct Prec<float> {
+  static constexpr int EPL = 4;
+  typedef f32x4 frag;
+  __device__ static inline void mma(const frag& a, const frag& b, f32x4& c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
+  }
+  __device__ static inline void to_f32(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
+    f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+  }
+  __device__ static inline uint4 from_f32(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+
+__device__ static inline int plane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
+
+constexpr int NPAIR = FLK_MAX_HALO * 4 / 256;  // (position, chunk) pairs staged per thread
+
+template <typename T, int NF>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
+  typedef Prec<T> PR;
+  typedef typename PR::frag frag;
+  constexpr int EPL = PR::EPL;
+  constexpr int SLABC = 4 * EPL;
+  constexpr int WCH = (NF * 64 + 255) / 256;  // 16-byte weight chunks per thread per (slab, tap)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const halo = smem;
+  char* const wbuf = smem + 4 * p.plane_b + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane >> 4, m = lane & 15;
+
+  int bid = blockIdx.x;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int ntile = blockIdx.y;
+  const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * p.Wt;
+  const int it0 = ot0 * p.st - p.pt, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
+
+  // ---- staging plan: pair n of this thread = (halo position (tid>>2) + 64 n, chunk tid&3) ----
+  const int ch = tid & 3;
+  int goff[NPAIR];  // element offset of the chunk in `in`, -1 = zero fill, -2 = beyond the halo
+  {
+    const int HW = p.Hh * p.Wh;
+#pragma unroll
+    for (int n = 0; n < NPAIR; ++n) {
+      const int hp = (tid >> 2) + 64 * n;
+      int g = -2;
+      if (hp < p.P) {
+        const int a = hp / HW, rem = hp - a * HW;
+        const int bq = rem / p.Wh, c = rem - bq * p.Wh;
+        const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
+        g = -1;
+        if ((unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+          g = (((b * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.in_ld + p.in_coff + ch * EPL;
+      }
+      goff[n] = g;
+    }
+  }
+  char* const hdst = halo + plane_off(ch, p.plane_b) + (tid >> 2) * 16;
+
+  // ---- compute plan: this wave owns tile rows [64*wave, 64*wave+64), 4 fragments of 16 positions ----
+  const bool wave_active = wave * 64 < p.rows;
+  int rowpos[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 64 + i * 16 + m;
+    int pos = 0;
+    if (r < p.rows) {
+      const int hw = p.Ht * p.Wt;
+      const int rt = r / hw, rem = r - rt * hw;
+      const int rh = rem / p.Wt, rw = rem - rh * p.Wt;
+      pos = ((rt * p.st) * p.Hh + rh * p.sh) * p.Wh + rw * p.sw;
+    }
+    rowpos[i] = pos * 16 + plane_off(q, p.plane_b);
+  }
+
+  f32x4 acc[NF][4];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // weight stream: (slab, tap) step k lives at w + (k*cout_frags + ntile*NF) KiB
+  const char* wsrc = p.w + (size_t)ntile * NF * 1024 + tid * 16;
+  const size_t wstep = (size_t)p.cout_frags * 1024;
+  uint4 wreg[WCH];
+#pragma unroll
+  for (int k = 0; k < WCH; ++k)
+    if (tid + 256 * k < NF * 64) wreg[k] = *(const uint4*)(wsrc + k * 4096);
+  wsrc += wstep;
+
+  int it_w = 0;
+  const int nsteps = p.nslab * p.ntaps;
+  for (int s = 0; s < p.nslab; ++s) {
+    __syncthreads();  // every wave has finished reading the previous slab's halo
+    {
+      const bool chvalid = s * SLABC + ch * EPL < p.cin;
+      const char* src = p.in + (size_t)s * SLABC * sizeof(T);
+#pragma unroll
+      for (int n0 = 0; n0 < NPAIR; n0 += 6) {
+        uint4 v[6];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+          v[n] = make_uint4(0, 0, 0, 0);
+          if (goff[n0 + n] >= 0 && chvalid) v[n] = *(const uint4*)(src + (size_t)goff[n0 + n] * sizeof(T));
+        }
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+          if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
+      }
+    }
+    int tapoff_t = 0;
+    for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.Hh * p.Wh * 16) {
+      int tapoff_h = tapoff_t;
+      for (int dh = 0; dh < p.kh; ++dh, tapoff_h += p.Wh * 16) {
+        int tapoff = tapoff_h;
+        for (int dw = 0; dw < p.kw; ++dw, tapoff += 16) {
+          char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
+#pragma unroll
+          for (int k = 0; k < WCH; ++k)
+            if (tid + 256 * k < NF * 64) *(uint4*)(wcur + tid * 16 + k * 4096) = wreg[k];
+          ++it_w;
+          if (it_w < nsteps) {
+#pragma unroll
+            for (int k = 0; k < WCH; ++k)
+              if (tid + 256 * k < NF * 64) wreg[k] = *(const uint4*)(wsrc + k * 4096);
+            wsrc += wstep;
+          }
+          __syncthreads();
+          if (wave_active) {
+            frag bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + rowpos[i] + tapoff);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+              const frag af = *(const frag*)(wcur + (f * 64 + lane) * 16);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) PR::mma(af, bf[i], acc[f][i]);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane = position (m of fragment i), channels ntile*16NF + q*4NF + [0, 4NF) ----
+  if (!wave_active) return;
+  const int cbase = ntile * 16 * NF + q * 4 * NF;
+  constexpr int NG = 4 * NF / EPL;   // 16-byte channel groups per lane
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave * 64 + i * 16 + m;
+    if (r >= p.rows) continue;
+    const int hw = p.Ht * p.Wt;
+    const int rt = r / hw, rem = r - rt * hw;
+    const int rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
+    if (ot >= p.To || oh >= p.Ho || ow >= p.Wo) continue;
+    const size_t opos = ((size_t)(b * p.OT + ot * p.ost + p.oot) * p.OH + oh * p.osh + p.ooh) * p.OW + ow * p.osw + p.oow;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int c0 = cbase + g * EPL;
+      if (c0 >= p.cout) continue;
+      float v[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
+      if (p.scale) {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+          const float4 sc = *(const float4*)(p.scale + c0 + e);
+          v[e] *= sc.x; v[e + 1] *= sc.y; v[e + 2] *= sc.z; v[e + 3] *= sc.w;
+        }
+      }
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+          const float4 bi = *(const float4*)(p.bias + c0 + e);
+          v[e] += bi.x; v[e + 1] += bi.y; v[e + 2] += bi.z; v[e + 3] += bi.w;
+        }
+      }
+      if (p.add) {
+        float a[EPL];
+        PR::to_f32(*(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + c0) * sizeof(T)), a);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] += a[e];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.mask) {
+        float a[EPL];
+        PR::to_f32(*(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + c0) * sizeof(T)), a);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
+      }
+      *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c0) * sizeof(T)) = PR::from_f32(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw) {
+  flk_tile best{1, 1, 1};
+  double best_eff = -1.0;
+  long best_halo = 0;
+  for (int Tt = 1; Tt <= To && Tt <= FLK_ROWS; ++Tt)
+    for (int Ht = 1; Ht <= Ho && Tt * Ht <= FLK_ROWS; ++Ht) {
+      const int wmax = FLK_ROWS / (Tt * Ht) < Wo ? FLK_ROWS / (Tt * Ht) : Wo;
+      for (int Wt = 1; Wt <= wmax; ++Wt) {
+        const long halo = (long)((Tt - 1) * st + kt) * ((Ht - 1) * sh + kh) * ((Wt - 1) * sw + kw);
+        if (halo > FLK_MAX_HALO) continue;
+        const long tiles = (long)((To + Tt - 1) / Tt) * ((Ho + Ht - 1) / Ht) * ((Wo + Wt - 1) / Wt);
+        // waves are 64-row granules: idle waves cost nothing, partially filled ones do
+        const int rows = Tt * Ht * Wt;
+        const double eff = (double)To * Ho * Wo / ((double)tiles * ((rows + 63) / 64 * 64));
+        // prefer (1) MFMA row utilisation, (2) fewer workgroups (less halo + weight re-staging),
+        // (3) wide W runs (consecutive positions = conflict-free LDS reads), (4) small halo
+        const double score = eff - 1e-3 * (double)halo / rows;
+        if (score > best_eff + 1e-9 || (score > best_eff - 1e-9 && (Wt > best.Wt || (Wt == best.Wt && halo < best_halo)))) {
+          best_eff = score; best = flk_tile{Tt, Ht, Wt}; best_halo = halo;
+        }
+      }
+    }
+  return best;
+}
+
+template <typename T, int NF>
+static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NF>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<T, NF>), grid, dim3(256), lds, s, kp);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream) {
+  FLK_REQUIRE(a && w && w->dev, "flk_conv3d: null argument");
+  FLK_REQUIRE(dtype == w->dtype, "flk_conv3d: dtype %d != packed weight dtype %d", dtype, w->dtype);
+  FLK_REQUIRE(a->kt == w->kt && a->kh == w->kh && a->kw == w->kw && a->cin == w->cin && a->cout == w->cout,
+              "flk_conv3d: args (%dx%dx%d, %d->%d) do not match weights (%dx%dx%d, %d->%d)", a->kt, a->kh, a->kw,
+              a->cin, a->cout, w->kt, w->kh, w->kw, w->cin, w->cout);
+  FLK_REQUIRE(a->cin % 8 == 0 && a->cout % 8 == 0 && a->in_ld % 8 == 0 && a->in_coff % 8 == 0 &&
+                  a->out_ld % 8 == 0 && a->out_coff % 8 == 0,
+              "flk_conv3d: channel counts / strides / offsets must be multiples of 8");
+  FLK_REQUIRE(!a->add || (a->add_ld % 8 == 0 && a->add_coff % 8 == 0), "flk_conv3d: add ld/coff % 8");
+  FLK_REQUIRE(!a->mask || (a->mask_ld % 8 == 0 && a->mask_coff % 8 == 0), "flk_conv3d: mask ld/coff % 8");
+  FLK_REQUIRE(a->in_coff + a->cin <= a->in_ld && a->out_coff + a->cout <= a->out_ld, "flk_conv3d: slice exceeds ld");
+  FLK_REQUIRE(a->B > 0 && a->To > 0 && a->Ho > 0 && a->Wo > 0 && a->st > 0 && a->sh > 0 && a->sw > 0 &&
+                  a->ost > 0 && a->osh > 0 && a->osw > 0, "flk_conv3d: bad dims");
+  FLK_REQUIRE((a->To - 1) * a->ost + a->oot < a->OT && (a->Ho - 1) * a->osh + a->ooh < a->OH &&
+                  (a->Wo - 1) * a->osw + a->oow < a->OW && a->oot >= 0 && a->ooh >= 0 && a->oow >= 0,
+              "flk_conv3d: logical output grid exceeds the physical output");
+  const size_t esz = flk_esize(dtype);
+  FLK_REQUIRE((size_t)a->B * a->Ti * a->Hi * a->Wi * a->in_ld < (1ull << 31) &&
+                  (size_t)a->B * a->OT * a->OH * a->OW * a->out_ld < (1ull << 31),
+              "flk_conv3d: tensor too large for 32-bit element offsets");
+  (void)esz;
+
+  ConvKP kp{};
+  kp.in = (const char*)a->in; kp.w = (const char*)w->dev; kp.out = (char*)a->out;
+  kp.scale = a->scale; kp.bias = a->bias; kp.add = (const char*)a->add; kp.mask = (const char*)a->mask;
+  kp.in_ld = a->in_ld; kp.in_coff = a->in_coff; kp.cin = a->cin;
+  kp.B = a->B; kp.Ti = a->Ti; kp.Hi = a->Hi; kp.Wi = a->Wi;
+  kp.kt = a->kt; kp.kh = a->kh; kp.kw = a->kw; kp.st = a->st; kp.sh = a->sh; kp.sw = a->sw;
+  kp.pt = a->pt; kp.ph = a->ph; kp.pw = a->pw;
+  kp.To = a->To; kp.Ho = a->Ho; kp.Wo = a->Wo;
+  kp.out_ld = a->out_ld; kp.out_coff = a->out_coff; kp.cout = a->cout;
+  kp.OT = a->OT; kp.OH = a->OH; kp.OW = a->OW;
+  kp.ost = a->ost; kp.osh = a->osh; kp.osw = a->osw; kp.oot = a->oot; kp.ooh = a->ooh; kp.oow = a->oow;
+  kp.add_ld = a->add_ld; kp.add_coff = a->add_coff; kp.mask_ld = a->mask_ld; kp.mask_coff = a->mask_coff;
+  kp.relu = a->relu;
+  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw);
+  kp.Tt = t.Tt; kp.Ht = t.Ht; kp.Wt = t.Wt; kp.rows = t.Tt * t.Ht * t.Wt;
+  kp.nTt = (a->To + t.Tt - 1) / t.Tt; kp.nTh = (a->Ho + t.Ht - 1) / t.Ht; kp.nTw = (a->Wo + t.Wt - 1) / t.Wt;
+  kp.Th = (t.Tt - 1) * a->st + a->kt; kp.Hh = (t.Ht - 1) * a->sh + a->kh; kp.Wh = (t.Wt - 1) * a->sw + a->kw;
+  kp.P = kp.Th * kp.Hh * kp.Wh;
+  FLK_REQUIRE(kp.P <= FLK_MAX_HALO && kp.rows <= FLK_ROWS, "flk_conv3d: no tile fits (halo %d)", kp.P);
+  kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
+  kp.nslab = w->nslab; kp.ntaps = w->ntaps; kp.cout_frags = w->cout_frags;
+  const int nf = w->nf;
+  const size_t lds = 4 * (size_t)kp.plane_b + 64 + 2 * (size_t)nf * 1024;
+  const long gx = (long)a->B * kp.nTt * kp.nTh * kp.nTw;
+  FLK_REQUIRE(gx < (1l << 31), "flk_conv3d: grid too large");
+  dim3 grid((unsigned)gx, (unsigned)(w->cout_frags / nf));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FLK_BF16) {
+    if (nf == 2) return launch<bf16_t, 2>(kp, grid, lds, s);
+    if (nf == 4) return launch<bf16_t, 4>(kp, grid, lds, s);
+    if (nf == 8) return launch<bf16_t, 8>(kp, grid, lds, s);
+  } else if (dtype == FLK_F32) {
+    if (nf == 2) return launch<float, 2>(kp, grid, lds, s);
+    if (nf == 4) return launch<float, 4>(kp, grid, lds, s);
+    if (nf == 8) return launch<float, 8>(kp, grid, lds, s);
+  }
+  flk_set_error("flk_conv3d: unsupported dtype %d / nf %d", dtype, nf);
+  return FLK_EINVAL;
+}

@@ -1,0 +1,60 @@
+// Internal declarations shared by the HIP translation units of libflicker_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/flicker_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing -------------------------------------------------------------------------
+void flk_set_error(const char* fmt, ...);
+#define FLK_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      flk_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return FLK_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+#define FLK_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      flk_set_error(__VA_ARGS__);       \
+      return FLK_EINVAL;                \
+    }                                   \
+  } while (0)
+
+static inline int flk_esize(int dtype) { return dtype == FLK_BF16 ? 2 : 4; }
+
+// ---- packed convolution weights ---------------------------------------------------------------
+// Layout on device: [nslab][ntaps][cout_frags][64 lanes][EPL elems] where EPL = 16 B / elem size,
+// a slab = 4*EPL input channels (one 64-byte run per position) and fragment F = ntile*nf + f of
+// lane l=(q=l>>4, m=l&15) holds, for j < EPL,
+//     W[tap][cin = slab*4*EPL + q*EPL + j][cout = ntile*16*nf + (m>>2)*4*nf + f*4 + (m&3)]
+// (zero outside cin/cout).  With this permutation an MFMA accumulator lane owns 4*nf CONSECUTIVE
+// output channels of one position, so the epilogue issues 16-byte stores.
+struct flk_conv_weights {
+  void* dev = nullptr;
+  int kt = 0, kh = 0, kw = 0, cin = 0, cout = 0;   // of THIS operator (after optional transpose)
+  int dtype = 0, nf = 0, nslab = 0, ntaps = 0, cout_frags = 0;
+  size_t bytes = 0;
+};
+
+int flk_conv_weights_create_impl(const float* w_dhwio, int kt, int kh, int kw, int cin, int cout,
+                                 const float* row_scale, int transpose, int dtype, int nf,
+                                 flk_conv_weights** out);
+
+// choose the (Tt,Ht,Wt) tile for a logical output grid; returns rows used (<=256)
+struct flk_tile {
+  int Tt, Ht, Wt;
+};
+flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw);
+
+constexpr int FLK_MAX_HALO = 768;  // halo positions per tile (LDS: 4 planes x 768 x 16 B = 48 KiB)
+constexpr int FLK_ROWS = 256;      // output positions per workgroup tile

@@ -1,0 +1,238 @@
+// Classifier head and loss head (small fp32 kernels).
+//
+// I3D Logits endpoint (i3d.py:459-474): avg_pool3d 2x7x7 VALID s1 -> dropout(keep 1.0) -> 1x1x1 conv
+// with bias -> squeeze -> reduce_mean over T'.  Every stage is linear, so
+//     logits[b,n] = bias[n] + sum_c W[c,n] * feat[b,c],   feat[b,c] = sum_{t,h,w} wt[t] * y[b,t,h,w,c]
+// with wt[t] = (#pool windows covering frame t) / (2*7*7*T').  VideoResNet (AdaptiveAvgPool3d(1) +
+// Linear, torchvision 0.5.0) is the same form with wt = 1/(T*H*W).  Backward:
+//     gy[b,t,h,w,c] = wt[t] * sum_n dlogits[b,n] W[c,n], masked by y > 0 (ReluGrad of the producer).
+//
+// Loss head (kinetics_i3d_utils.py:152-169,253-307; model.py:177-250): one workgroup per clip computes
+// softmax, label / max-non-label statistics, the adversarial loss and d(loss)/d(logits) in closed form.
+#include "flk_internal.h"
+
+template <typename T> __device__ static inline float ldf(const char* p, size_t i);
+template <> __device__ inline float ldf<float>(const char* p, size_t i) { return ((const float*)p)[i]; }
+template <> __device__ inline float ldf<bf16_t>(const char* p, size_t i) {
+  return __uint_as_float((uint32_t)((const uint16_t*)p)[i] << 16);
+}
+template <typename T> __device__ static inline void stf(char* p, size_t i, float v);
+template <> __device__ inline void stf<float>(char* p, size_t i, float v) { ((float*)p)[i] = v; }
+template <> __device__ inline void stf<bf16_t>(char* p, size_t i, float v) { ((bf16_t*)p)[i] = (bf16_t)v; }
+
+// feat[b,c] = sum_pos wt[t(pos)] * y[b,pos,c]      grid (C/256, B)
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool_kernel(const char* y, int ld, int coff, int C, int Tn, int HW,
+                                                        const float* wt, float* feat) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int t = 0; t < Tn; ++t) {
+    float s = 0.f;
+    const size_t base = ((size_t)(b * Tn + t) * HW) * ld + coff + c;
+    for (int i = 0; i < HW; ++i) s += ldf<T>(y, base + (size_t)i * ld);
+    acc += wt[t] * s;
+  }
+  feat[(size_t)b * C + c] = acc;
+}
+
+// logits[b,n] = bias[n] + sum_c feat[b,c] * W[c,n]     grid (ceil(N/256), B)
+__global__ __launch_bounds__(256) void head_fc_kernel(const float* feat, const float* W, const float* bias, int C, int N,
+                                                      float* logits) {
+  const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  __shared__ float sf[2048];
+  for (int c = threadIdx.x; c < C; c += 256) sf[c] = feat[(size_t)b * C + c];
+  __syncthreads();
+  if (n >= N) return;
+  float acc = bias ? bias[n] : 0.f;
+  for (int c = 0; c < C; ++c) acc += sf[c] * W[(size_t)c * N + n];
+  logits[(size_t)b * N + n] = acc;
+}
+
+// dfeat[b,c] = sum_n dlogits[b,n] * W[c,n]      grid (ceil(C/256), B)
+__global__ __launch_bounds__(256) void head_fc_bwd_kernel(const float* dlogits, const float* W, int C, int N, float* dfeat) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  __shared__ float sd[1024];
+  for (int n = threadIdx.x; n < N; n += 256) sd[n] = dlogits[(size_t)b * N + n];
+  __syncthreads();
+  if (c >= C) return;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc += sd[n] * W[(size_t)c * N + n];
+  dfeat[(size_t)b * C + c] = acc;
+}
+
+// gy[b,pos,c] = wt[t] * dfeat[b,c] * (y > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool_bwd_kernel(const char* y, int ld, int coff, char* gy, int gld, int gcoff,
+                                                            int C, int Tn, int HW, int B, const float* wt, const float* dfeat, int use_mask) {
+  const long total = (long)B * Tn * HW * C;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int c = gid % C;
+    const long pos = gid / C;
+    const int t = (pos / HW) % Tn;
+    const int b = pos / ((long)HW * Tn);
+    float g = wt[t] * dfeat[(size_t)b * C + c];
+    if (use_mask && !(ldf<T>(y, (size_t)pos * ld + coff + c) > 0.f)) g = 0.f;
+    stf<T>(gy, (size_t)pos * gld + gcoff + c, g);
+  }
+}
+
+int flk_head_forward(const void* y, int ld, int coff, int C, int B, int Tn, int HW, const float* wt, const float* W,
+                     const float* bias, int N, float* feat, float* logits, int dtype, hipStream_t s) {
+  FLK_REQUIRE(C <= 2048 && N <= 1024, "head: C<=2048, N<=1024 supported");
+  dim3 g1((C + 255) / 256, B);
+  if (dtype == FLK_BF16) hipLaunchKernelGGL(head_pool_kernel<bf16_t>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
+  else hipLaunchKernelGGL(head_pool_kernel<float>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
+  hipLaunchKernelGGL(head_fc_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, feat, W, bias, C, N, logits);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+int flk_head_backward(const void* y, int ld, int coff, void* gy, int gld, int gcoff, int C, int B, int Tn, int HW,
+                      const float* wt, const float* W, int N, const float* dlogits, float* dfeat, int use_mask, int dtype,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(head_fc_bwd_kernel, dim3((C + 255) / 256, B), dim3(256), 0, s, dlogits, W, C, N, dfeat);
+  const long total = (long)B * Tn * HW * C;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (dtype == FLK_BF16)
+    hipLaunchKernelGGL(head_pool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const char*)y, ld, coff, (char*)gy, gld, gcoff, C, Tn, HW, B, wt, dfeat, use_mask);
+  else
+    hipLaunchKernelGGL(head_pool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const char*)y, ld, coff, (char*)gy, gld, gcoff, C, Tn, HW, B, wt, dfeat, use_mask);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// softmax + adversarial loss + dlogits.  One 256-thread workgroup per clip.
+// d(loss_b)/dz_j = alpha [j==y] + beta [j==mz] + gy * p_y ([j==y] - p_j) + gP * p_mp ([j==mp] - p_j)
+// with (alpha, beta, gy, gP) derived per variant below.
+__device__ static inline void block_argmax(float v, int i, float* sv, int* si, float& ov, int& oi) {
+  // first-index-wins argmax over the block (ties -> smallest index, like np.argmax / tf.reduce_max's value)
+  const int tid = threadIdx.x;
+  sv[tid] = v; si[tid] = i;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const float a = sv[tid], b2 = sv[tid + s];
+      const int ia = si[tid], ib = si[tid + s];
+      if (b2 > a || (b2 == a && ib < ia)) { sv[tid] = b2; si[tid] = ib; }
+    }
+    __syncthreads();
+  }
+  ov = sv[0]; oi = si[0];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void softmax_adv_loss_kernel(const flk_loss_args a, const float* logits, const int64_t* labels,
+                                                               float* softmax, float* dlogits, float* per_clip) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  __shared__ float coef[8];
+  const int b = blockIdx.x, tid = threadIdx.x, C = a.C;
+  const float* z = logits + (size_t)b * C;
+  const int y = (int)labels[b];
+  constexpr int PER = 4;  // C <= 1024
+  float zl[PER], pl[PER];
+  float mx = -INFINITY; int mxi = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int j = tid + 256 * k;
+    zl[k] = j < C ? z[j] : -INFINITY;
+    if (zl[k] > mx) { mx = zl[k]; mxi = j; }
+  }
+  float zmax; int amax;
+  block_argmax(mx, mxi, sv, si, zmax, amax);
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { pl[k] = tid + 256 * k < C ? __expf(zl[k] - zmax) : 0.f; se += pl[k]; }
+  sv[tid] = se;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (tid < s) sv[tid] += sv[tid + s]; __syncthreads(); }
+  const float inv = 1.f / sv[0];
+  __syncthreads();
+  // max non-label prob / logit.  TF dialect: max_k(v_k - onehot_k) (label NOT excluded);
+  // torch dialect: true exclusion (model.py:218-219,235).
+  float bp = -INFINITY, bz = -INFINITY; int bpi = 0x7fffffff, bzi = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int j = tid + 256 * k;
+    pl[k] *= inv;
+    if (j >= C) continue;
+    float vp = pl[k], vz = zl[k];
+    if (j == y) {
+      if (a.torch_dialect) { vp = -INFINITY; vz = -INFINITY; } else { vp -= 1.f; vz -= 1.f; }
+    }
+    if (vp > bp) { bp = vp; bpi = j; }
+    if (vz > bz) { bz = vz; bzi = j; }
+  }
+  float P, Z; int mp, mz;
+  block_argmax(bp, bpi, sv, si, P, mp);
+  block_argmax(bz, bzi, sv, si, Z, mz);
+  if (tid == 0) {
+    const float zy = z[y], py = __expf(zy - zmax) * inv;
+    const float Pm = __expf(z[mp] - zmax) * inv;   // p at the arg of the max (P may carry the TF "-1")
+    float alpha = 0.f, beta = 0.f, gy = 0.f, gP = 0.f, loss = 0.f;
+    const float mg = a.margin;
+    if (a.improve_loss) {
+      float u, M, dM_dpy = 0.f, dM_dP = 0.f, su_y = 0.f, su_m = 0.f, sp_y = 0.f, sp_P = 0.f;
+      // u = to_min - to_max + M ; record d(u)/d(z_y), d(u)/d(z_mz), d(u)/d(p_y), d(u)/d(P) excluding M
+      if (!a.use_logits) {
+        M = mg;
+        if (!a.targeted) { u = py - P + M; sp_y = 1.f; sp_P = -1.f; }
+        else { u = P - py + M; sp_y = -1.f; sp_P = 1.f; }
+      } else if (!a.targeted) {
+        const float q = a.torch_dialect ? py : P;          // model.py:236 uses the LABEL prob
+        M = logf(1.f + mg / (1e-5f + q));
+        const float dM = -mg / ((1e-5f + q) * (1e-5f + q + mg));
+        if (a.torch_dialect) dM_dpy = dM; else dM_dP = dM;
+        u = zy - Z + M; su_y = 1.f; su_m = -1.f;
+      } else {                                             // TF targeted, logits (kinetics_i3d_utils.py:256-259)
+        M = logf(1.f + mg / py);
+        dM_dpy = -mg / (py * (py + mg));
+        u = Z - zy + M; su_y = -1.f; su_m = 1.f;
+      }
+      float dl_du = 0.f, dl_dM = 0.f;
+      if (u > 0.f) {
+        if (u * u / M <= u) { loss = u * u / M; dl_du = 2.f * u / M; dl_dM = -u * u / (M * M); }
+        else { loss = u; dl_du = 1.f; }
+      }
+      const float cM = dl_du + dl_dM;                      // total derivative through M
+      alpha = dl_du * su_y; beta = dl_du * su_m;
+      gy = dl_du * sp_y + cM * dM_dpy;
+      gP = dl_du * sp_P + cM * dM_dP;
+    } else {
+      const float ms = a.mean_scale;
+      if (!a.targeted) { loss = -logf(1.f - py + 1e-6f) * ms; gy = ms / (1.f - py + 1e-6f); }
+      else if (a.torch_dialect) { loss = -logf(py + 1e-6f) * ms; gy = -ms / (py + 1e-6f); }
+      else { loss = -(zy - zmax - logf(1.f / inv)) * ms; gy = -ms / py; }
+    }
+    coef[0] = alpha; coef[1] = beta; coef[2] = gy * py; coef[3] = gP * Pm;
+    per_clip[b * 4 + 0] = loss; per_clip[b * 4 + 1] = py; per_clip[b * 4 + 2] = Pm; per_clip[b * 4 + 3] = (float)amax;
+  }
+  __syncthreads();
+  const float alpha = coef[0], beta = coef[1], cy = coef[2], cP = coef[3];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int j = tid + 256 * k;
+    if (j >= C) continue;
+    float d = -(cy + cP) * pl[k];
+    if (j == y) d += alpha + cy;
+    if (j == mz) d += beta;
+    if (j == mp) d += cP;
+    if (softmax) softmax[(size_t)b * C + j] = pl[k];
+    dlogits[(size_t)b * C + j] = d;
+  }
+}
+
+extern "C" int flk_softmax_adv_loss(const flk_loss_args* a, const float* logits, const int64_t* labels, float* softmax,
+                                    float* dlogits, float* per_clip, void* stream) {
+  FLK_REQUIRE(a && logits && labels && dlogits && per_clip, "flk_softmax_adv_loss: null argument");
+  FLK_REQUIRE(a->B > 0 && a->C > 1 && a->C <= 1024, "flk_softmax_adv_loss: need 1 < C <= 1024");
+  FLK_REQUIRE(!(a->torch_dialect && a->improve_loss && a->targeted),
+              "flk_softmax_adv_loss: the reference's targeted improve-loss is non-functional in the torch dialect "
+              "(model.py:223-225 references undefined names); refusing to guess");
+  FLK_REQUIRE(a->margin > 0.f || !a->improve_loss, "flk_softmax_adv_loss: margin must be > 0");
+  hipLaunchKernelGGL(softmax_adv_loss_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a, logits, labels, softmax, dlogits, per_clip);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}

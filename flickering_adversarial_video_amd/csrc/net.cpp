@@ -1,0 +1,576 @@
+// Whole-network plan: victim classifier forward + backward-to-input as a flat list of kernel launches
+// over pre-planned, resident buffers (static shapes; nothing is allocated or synchronised per step).
+//
+// I3D topology follows reference i3d.py:144-479; every Unit3D (i3d.py:51-71) is one flk_conv3d launch
+// with BN(inference, no gamma, eps 1e-3) folded into an fp32 scale/bias epilogue + ReLU, writing its
+// channel slice of the Inception concat buffer.  Backward is data-gradient only (only the perturbation
+// is trainable: i3d_adversarial_main_single_video_npy.py:82): gradient buffers mirror the activation
+// buffers and hold d(loss)/d(pre-ReLU output) ("G"), the ReLU mask being applied by the PRODUCING
+// kernel's epilogue and the BN scale folded into the transposed weights.
+#include <math.h>
+#include <string.h>
+#include <functional>
+#include <map>
+#include <memory>
+#include "flk_internal.h"
+
+int flk_head_forward(const void* y, int ld, int coff, int C, int B, int Tn, int HW, const float* wt, const float* W,
+                     const float* bias, int N, float* feat, float* logits, int dtype, hipStream_t s);
+int flk_head_backward(const void* y, int ld, int coff, void* gy, int gld, int gcoff, int C, int B, int Tn, int HW,
+                      const float* wt, const float* W, int N, const float* dlogits, float* dfeat, int use_mask, int dtype,
+                      hipStream_t s);
+
+namespace {
+
+enum OpKind { K_CONV = 0, K_POOL = 1, K_HEAD = 2, K_OTHER = 3 };
+const char* kKindName[] = {"conv", "pool", "head", "other"};
+
+struct Op {
+  std::string name;
+  int kind;
+  double flops;   // algorithmic flops (2*MAC) for conv ops, 0 otherwise
+  double bytes;   // algorithmic HBM bytes (compulsory traffic) for memory-bound ops
+  std::function<int(hipStream_t)> run;
+};
+
+struct Act {      // channels-last activation tensor [B,T,H,W,ld]
+  void* p = nullptr;
+  int T = 0, H = 0, W = 0, ld = 0;
+  size_t numel(int B) const { return (size_t)B * T * H * W * ld; }
+};
+
+struct ConvLayer {
+  std::string name;
+  int kt, kh, kw, cin, cout;
+  std::vector<float> w;        // canonical [kt][kh][kw][cin][cout]
+  std::vector<float> scale, bias;
+  flk_conv_weights* wf = nullptr;
+  flk_conv_weights* wb = nullptr;
+  float* d_scale = nullptr;
+  float* d_bias = nullptr;
+};
+
+inline void same_pad(int n, int k, int s, int& out, int& before) {
+  out = (n + s - 1) / s;
+  int tot = (out - 1) * s + k - n;
+  if (tot < 0) tot = 0;
+  before = tot / 2;
+}
+
+int choose_nf(int cout, int taps) {
+  int best = 8;
+  double best_cost = 1e30;
+  const int cand[3] = {8, 4, 2};
+  for (int nf : cand) {
+    const int padded = (cout + 16 * nf - 1) / (16 * nf) * (16 * nf);
+    const int ntiles = padded / (16 * nf);
+    // MFMA work ~ padded*taps (narrow tiles re-read the activation fragments more often per MFMA);
+    // every extra N tile re-stages the halo
+    const double cost = (double)padded * taps * (nf == 2 ? 1.35 : nf == 4 ? 1.1 : 1.0) + 64.0 * ntiles;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = nf; }
+  }
+  return best;
+}
+
+}  // namespace
+
+struct flk_net {
+  int arch = 0, dtype = 0, B = 0, T = 0, H = 0, W = 0, device = 0;
+  int num_classes = 400;
+  bool finalized = false, fwd_done = false;
+  std::map<std::string, std::vector<float>> weights;
+  std::vector<std::unique_ptr<ConvLayer>> convs;
+  std::vector<void*> allocs;
+  size_t alloc_bytes = 0;
+  std::vector<Op> fwd, bwd;
+  std::map<std::string, std::pair<Act, int>> named;   // endpoint name -> (tensor, channels)
+  // bound per call
+  const void* x_in = nullptr;
+  void* gx_in = nullptr;
+  float* logits_out = nullptr;
+  const float* dlogits_in = nullptr;
+  // head
+  float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
+  // profiling
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fwd, ev_bwd;
+  bool ev_fwd_valid = false, ev_bwd_valid = false;
+
+  int esz() const { return flk_esize(dtype); }
+
+  int dmalloc(void** p, size_t bytes, bool zero = false) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { flk_set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return FLK_ENOMEM; }
+    allocs.push_back(*p);
+    alloc_bytes += bytes;
+    if (zero) FLK_CHECK_HIP(hipMemset(*p, 0, bytes));
+    return FLK_OK;
+  }
+  int new_act(Act& a, int T_, int H_, int W_, int ld, bool zero = false) {
+    a.T = T_; a.H = H_; a.W = W_; a.ld = ld;
+    return dmalloc(&a.p, a.numel(B) * esz(), zero);
+  }
+  int upload(float** d, const std::vector<float>& h) {
+    int rc = dmalloc((void**)d, h.size() * sizeof(float));
+    if (rc) return rc;
+    FLK_CHECK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return FLK_OK;
+  }
+  const std::vector<float>* find(const std::string& name, size_t numel) {
+    auto it = weights.find(name);
+    if (it == weights.end()) { flk_set_error("flk_net_finalize: missing weight '%s'", name.c_str()); return nullptr; }
+    if (it->second.size() != numel) {
+      flk_set_error("flk_net_finalize: weight '%s' has %zu elements, expected %zu", name.c_str(), it->second.size(), numel);
+      return nullptr;
+    }
+    return &it->second;
+  }
+
+  // ---- conv layer construction -----------------------------------------------------------------
+  // Unit3D parameters from the checkpoint names (kinetics_i3d_utils.py:41-62)
+  int make_unit3d(const std::string& unit, int kt, int kh, int kw, int cin, int cout, ConvLayer** out) {
+    const std::string pre = "RGB/inception_i3d/" + unit;
+    auto* w = find(pre + "/conv_3d/w", (size_t)kt * kh * kw * cin * cout);
+    auto* beta = find(pre + "/batch_norm/beta", cout);
+    auto* mean = find(pre + "/batch_norm/moving_mean", cout);
+    auto* var = find(pre + "/batch_norm/moving_variance", cout);
+    if (!w || !beta || !mean || !var) return FLK_EINVAL;
+    auto L = std::make_unique<ConvLayer>();
+    L->name = unit; L->kt = kt; L->kh = kh; L->kw = kw; L->cin = cin; L->cout = cout;
+    L->w = *w;
+    L->scale.resize(cout); L->bias.resize(cout);
+    for (int c = 0; c < cout; ++c) {
+      const float a = 1.0f / sqrtf((*var)[c] + 1e-3f);      // snt.BatchNorm(eps=1e-3, scale=False)
+      L->scale[c] = a;
+      L->bias[c] = (*beta)[c] - (*mean)[c] * a;
+    }
+    *out = L.get();
+    convs.push_back(std::move(L));
+    return FLK_OK;
+  }
+  // pack forward + data-gradient operators and upload the epilogue vectors
+  int pack(ConvLayer* L) {
+    const int taps = L->kt * L->kh * L->kw;
+    int rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, nullptr, 0, dtype,
+                                          choose_nf(L->cout, taps), &L->wf);
+    if (rc) return rc;
+    rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, L->scale.data(), 1, dtype,
+                                      choose_nf(L->cin, taps), &L->wb);
+    if (rc) return rc;
+    if ((rc = upload(&L->d_scale, L->scale))) return rc;
+    if ((rc = upload(&L->d_bias, L->bias))) return rc;
+    return FLK_OK;
+  }
+
+  // ---- op emitters -------------------------------------------------------------------------------
+  // forward Unit3D: out[:, coff:coff+cout] = relu(conv(in[:, in_coff:in_coff+cin]) * scale + bias), stride 1 SAME
+  void emit_conv_fwd(ConvLayer* L, const Act& in, int in_coff, const Act& out, int out_coff, const void* const* in_ptr = nullptr) {
+    flk_conv_args a{};
+    a.in = in.p; a.in_ld = in.ld; a.in_coff = in_coff; a.cin = L->cin;
+    a.B = B; a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
+    a.kt = L->kt; a.kh = L->kh; a.kw = L->kw; a.st = a.sh = a.sw = 1;
+    a.pt = (L->kt - 1) / 2; a.ph = (L->kh - 1) / 2; a.pw = (L->kw - 1) / 2;
+    a.To = out.T; a.Ho = out.H; a.Wo = out.W;
+    a.out = out.p; a.out_ld = out.ld; a.out_coff = out_coff; a.cout = L->cout;
+    a.OT = out.T; a.OH = out.H; a.OW = out.W; a.ost = a.osh = a.osw = 1;
+    a.scale = L->d_scale; a.bias = L->d_bias; a.relu = 1;
+    const double macs = (double)B * out.T * out.H * out.W * L->kt * L->kh * L->kw * L->cin * L->cout;
+    flk_conv_weights* wf = L->wf;
+    const int dt = dtype;
+    fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt, in_ptr](hipStream_t s) mutable {
+                       if (in_ptr) a.in = *in_ptr;
+                       return flk_conv3d(&a, wf, dt, s);
+                     }});
+  }
+  // data gradient of a stride-1 SAME Unit3D: gin[:, gin_coff..] = (conv_T(G[:, g_coff..]) + add) masked
+  void emit_conv_bwd(ConvLayer* L, const Act& G, int g_coff, const Act& gin, int gin_coff, const void* add, int add_ld,
+                     int add_coff, const Act* mask, int mask_coff, void* const* out_ptr = nullptr) {
+    flk_conv_args a{};
+    a.in = G.p; a.in_ld = G.ld; a.in_coff = g_coff; a.cin = L->cout;
+    a.B = B; a.Ti = G.T; a.Hi = G.H; a.Wi = G.W;
+    a.kt = L->kt; a.kh = L->kh; a.kw = L->kw; a.st = a.sh = a.sw = 1;
+    a.pt = L->kt - 1 - (L->kt - 1) / 2; a.ph = L->kh - 1 - (L->kh - 1) / 2; a.pw = L->kw - 1 - (L->kw - 1) / 2;
+    a.To = gin.T; a.Ho = gin.H; a.Wo = gin.W;
+    a.out = gin.p; a.out_ld = gin.ld; a.out_coff = gin_coff; a.cout = L->cin;
+    a.OT = gin.T; a.OH = gin.H; a.OW = gin.W; a.ost = a.osh = a.osw = 1;
+    a.add = add; a.add_ld = add_ld; a.add_coff = add_coff;
+    if (mask) { a.mask = mask->p; a.mask_ld = mask->ld; a.mask_coff = mask_coff; }
+    const double macs = (double)B * gin.T * gin.H * gin.W * L->kt * L->kh * L->kw * L->cin * L->cout;
+    flk_conv_weights* wb = L->wb;
+    const int dt = dtype;
+    bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt, out_ptr](hipStream_t s) mutable {
+                       if (out_ptr) a.out = *out_ptr;
+                       return flk_conv3d(&a, wb, dt, s);
+                     }});
+  }
+  struct PoolRec { flk_pool_args a; };
+  int emit_pool_fwd(const std::string& name, const Act& in, int C, int kt, int kh, int kw, int st, int sh, int sw, Act& out,
+                    PoolRec& rec) {
+    flk_pool_args a{};
+    a.in = in.p; a.in_ld = in.ld; a.in_coff = 0; a.C = C;
+    a.B = B; a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
+    a.kt = kt; a.kh = kh; a.kw = kw; a.st = st; a.sh = sh; a.sw = sw;
+    same_pad(in.T, kt, st, a.To, a.pt); same_pad(in.H, kh, sh, a.Ho, a.ph); same_pad(in.W, kw, sw, a.Wo, a.pw);
+    int rc = new_act(out, a.To, a.Ho, a.Wo, C);
+    if (rc) return rc;
+    void* idx = nullptr;
+    if ((rc = dmalloc(&idx, (size_t)B * a.To * a.Ho * a.Wo * C))) return rc;
+    a.out = out.p; a.out_ld = C; a.out_coff = 0; a.idx = (uint8_t*)idx;
+    rec.a = a;
+    const int dt = dtype;
+    const double bytes = ((double)in.numel(B) + out.numel(B)) * esz() + (double)B * a.To * a.Ho * a.Wo * C;
+    fwd.push_back(Op{name, K_POOL, 0.0, bytes, [a, dt](hipStream_t s) { return flk_maxpool3d_fwd(&a, dt, s); }});
+    return FLK_OK;
+  }
+  void emit_pool_bwd(const std::string& name, const PoolRec& rec, const Act& gout, const Act& gin, const Act* mask) {
+    const flk_pool_args a = rec.a;
+    const int dt = dtype;
+    const void* mp = mask ? mask->p : nullptr;
+    const int mld = mask ? mask->ld : 0;
+    const double bytes = ((double)gout.numel(B) + gin.numel(B) + (mask ? gin.numel(B) : 0)) * esz() + (double)B * a.To * a.Ho * a.Wo * a.C;
+    bwd.push_back(Op{name + "/grad", K_POOL, 0.0, bytes, [a, dt, gout, gin, mp, mld](hipStream_t s) {
+                       return flk_maxpool3d_bwd(&a, gout.p, gout.ld, 0, gin.p, gin.ld, 0, mp, mld, 0, dt, s);
+                     }});
+  }
+
+  int build_i3d();
+};
+
+// ---------------------------------------------------------------------------------------------------
+// I3D (i3d.py:144-479).
+int flk_net::build_i3d() {
+  FLK_REQUIRE(T % 2 == 0 && T >= 16, "I3D: T must be even and >= 16 (got %d)", T);
+  FLK_REQUIRE(H == 224 && W == 224, "I3D: the Logits endpoint's 2x7x7 VALID avg-pool + squeeze (i3d.py:461-471) "
+              "requires 224x224 input (got %dx%d)", H, W);
+  int rc;
+  std::vector<std::function<void()>> bwd_emit;   // backward emitters, run in reverse at the end
+
+  // ---- stem: Conv3d_1a_7x7 (7x7x7 / 2, 3->64) as a 4x4x4 / 1 convolution over the space-to-depth clip ----
+  ConvLayer* stem7 = nullptr;
+  if ((rc = make_unit3d("Conv3d_1a_7x7", 7, 7, 7, 3, 64, &stem7))) return rc;
+  ConvLayer* stem = nullptr;
+  {
+    auto L = std::make_unique<ConvLayer>();
+    L->name = "Conv3d_1a_7x7"; L->kt = L->kh = L->kw = 4; L->cin = 32; L->cout = 64;
+    L->w.assign((size_t)64 * 32 * 64, 0.f);
+    for (int kt = 0; kt < 7; ++kt) for (int kh = 0; kh < 7; ++kh) for (int kw = 0; kw < 7; ++kw)
+      for (int c = 0; c < 3; ++c) {
+        const int jt = kt >> 1, qt = kt & 1, jh = kh >> 1, qh = kh & 1, jw = kw >> 1, qw = kw & 1;
+        const int ch = (qt * 4 + qh * 2 + qw) * 3 + c;
+        const float* src = &stem7->w[((((size_t)kt * 7 + kh) * 7 + kw) * 3 + c) * 64];
+        float* dst = &L->w[((((size_t)jt * 4 + jh) * 4 + jw) * 32 + ch) * 64];
+        for (int co = 0; co < 64; ++co) dst[co] = src[co];
+      }
+    L->scale = stem7->scale; L->bias = stem7->bias;
+    stem = L.get();
+    convs.push_back(std::move(L));
+  }
+  if ((rc = pack(stem))) return rc;
+  const int T1 = T / 2, H1 = H / 2, W1 = W / 2;
+  Act xin; xin.T = T1; xin.H = H1; xin.W = W1; xin.ld = 32;       // bound per call
+  Act a1, G1;
+  if ((rc = new_act(a1, T1, H1, W1, 64)) || (rc = new_act(G1, T1, H1, W1, 64))) return rc;
+  named["Conv3d_1a_7x7"] = {a1, 64};
+  {
+    // SAME padding of the 7/2 conv on an even size is (2,3) -> in s2d space taps j=0..3 read o-1+j: pad-before 1
+    flk_conv_args a{};
+    a.in_ld = 32; a.in_coff = 0; a.cin = 32; a.B = B; a.Ti = T1; a.Hi = H1; a.Wi = W1;
+    a.kt = a.kh = a.kw = 4; a.st = a.sh = a.sw = 1; a.pt = a.ph = a.pw = 1;
+    a.To = T1; a.Ho = H1; a.Wo = W1; a.out = a1.p; a.out_ld = 64; a.cout = 64;
+    a.OT = T1; a.OH = H1; a.OW = W1; a.ost = a.osh = a.osw = 1;
+    a.scale = stem->d_scale; a.bias = stem->d_bias; a.relu = 1;
+    const double macs = (double)B * T1 * H1 * W1 * 343.0 * 3 * 64;   // algorithmic (7x7x7x3), not the padded 4x4x4x32
+    flk_conv_weights* wf = stem->wf;
+    const int dt = dtype;
+    fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * macs, 0.0, [this, a, wf, dt](hipStream_t s) mutable {
+                       a.in = x_in;
+                       return flk_conv3d(&a, wf, dt, s);
+                     }});
+    flk_conv_args g{};
+    g.in = G1.p; g.in_ld = 64; g.cin = 64; g.B = B; g.Ti = T1; g.Hi = H1; g.Wi = W1;
+    g.kt = g.kh = g.kw = 4; g.st = g.sh = g.sw = 1; g.pt = g.ph = g.pw = 2;   // k-1-pad
+    g.To = T1; g.Ho = H1; g.Wo = W1; g.out_ld = 32; g.cout = 32;
+    g.OT = T1; g.OH = H1; g.OW = W1; g.ost = g.osh = g.osw = 1;
+    flk_conv_weights* wb = stem->wb;
+    bwd_emit.push_back([this, g, wb, dt, macs]() {
+      bwd.push_back(Op{"Conv3d_1a_7x7/dgrad", K_CONV, 2.0 * macs, 0.0, [this, g, wb, dt](hipStream_t s) mutable {
+                         g.out = gx_in;
+                         return flk_conv3d(&g, wb, dt, s);
+                       }});
+    });
+  }
+
+  // ---- MaxPool3d_2a_3x3 ----
+  Act p2a, Gp2a; PoolRec r2a;
+  if ((rc = emit_pool_fwd("MaxPool3d_2a_3x3", a1, 64, 1, 3, 3, 1, 2, 2, p2a, r2a))) return rc;
+  if ((rc = new_act(Gp2a, p2a.T, p2a.H, p2a.W, 64))) return rc;
+  named["MaxPool3d_2a_3x3"] = {p2a, 64};
+  bwd_emit.push_back([this, r2a, Gp2a, G1, a1]() { emit_pool_bwd("MaxPool3d_2a_3x3", r2a, Gp2a, G1, &a1); });
+
+  // ---- Conv3d_2b_1x1, Conv3d_2c_3x3 ----
+  ConvLayer *c2b = nullptr, *c2c = nullptr;
+  if ((rc = make_unit3d("Conv3d_2b_1x1", 1, 1, 1, 64, 64, &c2b)) || (rc = pack(c2b))) return rc;
+  if ((rc = make_unit3d("Conv3d_2c_3x3", 3, 3, 3, 64, 192, &c2c)) || (rc = pack(c2c))) return rc;
+  Act a2b, G2b, a2c, G2c;
+  if ((rc = new_act(a2b, p2a.T, p2a.H, p2a.W, 64)) || (rc = new_act(G2b, p2a.T, p2a.H, p2a.W, 64))) return rc;
+  if ((rc = new_act(a2c, p2a.T, p2a.H, p2a.W, 192)) || (rc = new_act(G2c, p2a.T, p2a.H, p2a.W, 192))) return rc;
+  emit_conv_fwd(c2b, p2a, 0, a2b, 0);
+  emit_conv_fwd(c2c, a2b, 0, a2c, 0);
+  named["Conv3d_2b_1x1"] = {a2b, 64};
+  named["Conv3d_2c_3x3"] = {a2c, 192};
+  bwd_emit.push_back([this, c2b, G2b, Gp2a]() { emit_conv_bwd(c2b, G2b, 0, Gp2a, 0, nullptr, 0, 0, nullptr, 0); });
+  bwd_emit.push_back([this, c2c, G2c, G2b, a2b]() { emit_conv_bwd(c2c, G2c, 0, G2b, 0, nullptr, 0, 0, &a2b, 0); });
+
+  // ---- MaxPool3d_3a_3x3 ----
+  Act p3a, Gp3a; PoolRec r3a;
+  if ((rc = emit_pool_fwd("MaxPool3d_3a_3x3", a2c, 192, 1, 3, 3, 1, 2, 2, p3a, r3a))) return rc;
+  if ((rc = new_act(Gp3a, p3a.T, p3a.H, p3a.W, 192))) return rc;
+  named["MaxPool3d_3a_3x3"] = {p3a, 192};
+  bwd_emit.push_back([this, r3a, Gp3a, G2c, a2c]() { emit_pool_bwd("MaxPool3d_3a_3x3", r3a, Gp3a, G2c, &a2c); });
+
+  // ---- Inception blocks ----
+  struct Blk { const char* name; int c[6]; int pool_before; int pk[3]; int ps[3]; const char* pool_name; };
+  const Blk blocks[] = {
+      {"Mixed_3b", {64, 96, 128, 16, 32, 32}, 0, {0, 0, 0}, {0, 0, 0}, ""},
+      {"Mixed_3c", {128, 128, 192, 32, 96, 64}, 0, {0, 0, 0}, {0, 0, 0}, ""},
+      {"Mixed_4b", {192, 96, 208, 16, 48, 64}, 1, {3, 3, 3}, {2, 2, 2}, "MaxPool3d_4a_3x3"},
+      {"Mixed_4c", {160, 112, 224, 24, 64, 64}, 0, {0, 0, 0}, {0, 0, 0}, ""},
+      {"Mixed_4d", {128, 128, 256, 24, 64, 64}, 0, {0, 0, 0}, {0, 0, 0}, ""},
+      {"Mixed_4e", {112, 144, 288, 32, 64, 64}, 0, {0, 0, 0}, {0, 0, 0}, ""},
+      {"Mixed_4f", {256, 160, 320, 32, 128, 128}, 0, {0, 0, 0}, {0, 0, 0}, ""},
+      {"Mixed_5b", {256, 160, 320, 32, 128, 128}, 1, {2, 2, 2}, {2, 2, 2}, "MaxPool3d_5a_2x2"},
+      {"Mixed_5c", {384, 192, 384, 48, 128, 128}, 0, {0, 0, 0}, {0, 0, 0}, ""},
+  };
+  Act cur = p3a, Gcur = Gp3a;   // block input and its gradient buffer
+  int cur_c = 192;
+  bool cur_is_relu = false;     // is `cur` a ReLU output (so its gradient needs the producer's mask)?
+  for (const Blk& bk : blocks) {
+    const std::string bn = bk.name;
+    if (bk.pool_before) {
+      Act po, Gpo; PoolRec pr;
+      if ((rc = emit_pool_fwd(bk.pool_name, cur, cur_c, bk.pk[0], bk.pk[1], bk.pk[2], bk.ps[0], bk.ps[1], bk.ps[2], po, pr))) return rc;
+      if ((rc = new_act(Gpo, po.T, po.H, po.W, cur_c))) return rc;
+      named[bk.pool_name] = {po, cur_c};
+      const Act prev = cur, Gprev = Gcur;
+      const std::string pn = bk.pool_name;
+      bwd_emit.push_back([this, pn, pr, Gpo, Gprev, prev]() { emit_pool_bwd(pn, pr, Gpo, Gprev, &prev); });
+      cur = po; Gcur = Gpo; cur_is_relu = false;
+    }
+    const int c0 = bk.c[0], c1a = bk.c[1], c1b = bk.c[2], c2a = bk.c[3], c2b_ = bk.c[4], c3 = bk.c[5];
+    const int cout_total = c0 + c1b + c2b_ + c3;
+    ConvLayer *L0, *L1a, *L1b, *L2a, *L2b, *L3;
+    const std::string b2name = bn == "Mixed_5b" ? "Conv3d_0a_3x3" : "Conv3d_0b_3x3";   // i3d.py:418
+    if ((rc = make_unit3d(bn + "/Branch_0/Conv3d_0a_1x1", 1, 1, 1, cur_c, c0, &L0)) || (rc = pack(L0))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0a_1x1", 1, 1, 1, cur_c, c1a, &L1a)) || (rc = pack(L1a))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0b_3x3", 3, 3, 3, c1a, c1b, &L1b)) || (rc = pack(L1b))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_2/Conv3d_0a_1x1", 1, 1, 1, cur_c, c2a, &L2a)) || (rc = pack(L2a))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_2/" + b2name, 3, 3, 3, c2a, c2b_, &L2b)) || (rc = pack(L2b))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_3/Conv3d_0b_1x1", 1, 1, 1, cur_c, c3, &L3)) || (rc = pack(L3))) return rc;
+    Act out, Gout, mid, Gmid, pl, Gpl, gxa;
+    if ((rc = new_act(out, cur.T, cur.H, cur.W, cout_total)) || (rc = new_act(Gout, cur.T, cur.H, cur.W, cout_total))) return rc;
+    if ((rc = new_act(mid, cur.T, cur.H, cur.W, c1a + c2a)) || (rc = new_act(Gmid, cur.T, cur.H, cur.W, c1a + c2a))) return rc;
+    if ((rc = new_act(Gpl, cur.T, cur.H, cur.W, cur_c)) || (rc = new_act(gxa, cur.T, cur.H, cur.W, cur_c))) return rc;
+    PoolRec pr3;
+    // forward: [b0 | b1 | b2 | b3] slices of `out` (tf.concat axis 4, i3d.py:219)
+    emit_conv_fwd(L0, cur, 0, out, 0);
+    emit_conv_fwd(L1a, cur, 0, mid, 0);
+    emit_conv_fwd(L1b, mid, 0, out, c0);
+    emit_conv_fwd(L2a, cur, 0, mid, c1a);
+    emit_conv_fwd(L2b, mid, c1a, out, c0 + c1b);
+    if ((rc = emit_pool_fwd(bn + "/Branch_3/MaxPool3d_0a_3x3", cur, cur_c, 3, 3, 3, 1, 1, 1, pl, pr3))) return rc;
+    emit_conv_fwd(L3, pl, 0, out, c0 + c1b + c2b_);
+    named[bn] = {out, cout_total};
+    // backward (emitted in reverse program order below): branch 3 first so the 1x1 dgrads can accumulate on it
+    const Act in_act = cur, Gin = Gcur;
+    const bool in_relu = cur_is_relu;
+    const std::string pname = bn + "/Branch_3/MaxPool3d_0a_3x3";
+    bwd_emit.push_back([=]() {
+      emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
+      emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
+      emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a);
+      emit_conv_bwd(L1b, Gout, c0, Gmid, 0, nullptr, 0, 0, &mid, 0);
+      emit_conv_bwd(L0, Gout, 0, Gin, 0, gxa.p, gxa.ld, 0, nullptr, 0);
+      emit_conv_bwd(L1a, Gmid, 0, Gin, 0, Gin.p, Gin.ld, 0, nullptr, 0);
+      emit_conv_bwd(L2a, Gmid, c1a, Gin, 0, Gin.p, Gin.ld, 0, in_relu ? &in_act : nullptr, 0);
+    });
+    cur = out; Gcur = Gout; cur_c = cout_total; cur_is_relu = true;
+  }
+
+  // ---- Logits head (i3d.py:459-474) ----
+  FLK_REQUIRE(cur.H == 7 && cur.W == 7 && cur.T >= 2, "I3D head: expected 7x7 spatial, T>=2 (got %dx%dx%d)", cur.T, cur.H, cur.W);
+  {
+    auto* fw = find("RGB/inception_i3d/Logits/Conv3d_0c_1x1/conv_3d/w", (size_t)cur_c * num_classes);
+    auto* fb = find("RGB/inception_i3d/Logits/Conv3d_0c_1x1/conv_3d/b", num_classes);
+    if (!fw || !fb) return FLK_EINVAL;
+    if ((rc = upload(&d_fcw, *fw)) || (rc = upload(&d_fcb, *fb))) return rc;
+    const int Tn = cur.T, Tp = Tn - 1;       // avg-pool 2x7x7 VALID s1 -> T' = Tn-1 frames, then mean over T'
+    std::vector<float> wt(Tn);
+    for (int t = 0; t < Tn; ++t) {
+      const int cover = (t >= 1 ? 1 : 0) + (t <= Tn - 2 ? 1 : 0);
+      wt[t] = (float)cover / (2.0f * 49.0f * (float)Tp);
+    }
+    if ((rc = upload(&d_wt, wt))) return rc;
+    if ((rc = dmalloc((void**)&d_feat, (size_t)B * cur_c * 4)) || (rc = dmalloc((void**)&d_dfeat, (size_t)B * cur_c * 4))) return rc;
+    const Act y = cur, Gy = Gcur;
+    const int C = cur_c, N = num_classes, dt = dtype;
+    fwd.push_back(Op{"Logits", K_HEAD, 0.0, (double)y.numel(B) * esz(), [this, y, C, N, Tn, dt](hipStream_t s) {
+                       return flk_head_forward(y.p, y.ld, 0, C, B, Tn, y.H * y.W, d_wt, d_fcw, d_fcb, N, d_feat, logits_out, dt, s);
+                     }});
+    bwd_emit.push_back([this, y, Gy, C, N, Tn, dt]() {
+      bwd.push_back(Op{"Logits/grad", K_HEAD, 0.0, 2.0 * (double)y.numel(B) * esz(), [this, y, Gy, C, N, Tn, dt](hipStream_t s) {
+                         return flk_head_backward(y.p, y.ld, 0, Gy.p, Gy.ld, 0, C, B, Tn, y.H * y.W, d_wt, d_fcw, N, dlogits_in,
+                                                  d_dfeat, 1, dt, s);
+                       }});
+    });
+  }
+  for (auto it = bwd_emit.rbegin(); it != bwd_emit.rend(); ++it) (*it)();
+  (void)xin;
+  return FLK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int flk_net_create(int arch, int dtype, int B, int T, int H, int W, int device, flk_net** out) {
+  FLK_REQUIRE(out, "flk_net_create: null out");
+  FLK_REQUIRE(arch == FLK_NET_I3D, "flk_net_create: arch %d not built yet (I3D only)", arch);
+  FLK_REQUIRE(dtype == FLK_F32 || dtype == FLK_BF16, "flk_net_create: bad dtype %d", dtype);
+  FLK_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0, "flk_net_create: bad dims");
+  flk_net* n = new (std::nothrow) flk_net();
+  if (!n) { flk_set_error("out of host memory"); return FLK_ENOMEM; }
+  n->arch = arch; n->dtype = dtype; n->B = B; n->T = T; n->H = H; n->W = W; n->device = device;
+  *out = n;
+  return FLK_OK;
+}
+
+extern "C" int flk_net_destroy(flk_net* n) {
+  if (!n) return FLK_OK;
+  (void)hipSetDevice(n->device);
+  for (void* p : n->allocs) (void)hipFree(p);
+  for (auto& L : n->convs) { flk_conv_weights_destroy(L->wf); flk_conv_weights_destroy(L->wb); }
+  for (auto& e : n->ev_fwd) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (auto& e : n->ev_bwd) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete n;
+  return FLK_OK;
+}
+
+extern "C" int flk_net_set_weight(flk_net* n, const char* name, const float* data, int64_t numel) {
+  FLK_REQUIRE(n && name && data && numel > 0, "flk_net_set_weight: bad argument");
+  FLK_REQUIRE(!n->finalized, "flk_net_set_weight: net already finalized");
+  n->weights[name].assign(data, data + numel);
+  return FLK_OK;
+}
+
+extern "C" int flk_net_finalize(flk_net* n) {
+  FLK_REQUIRE(n && !n->finalized, "flk_net_finalize: bad state");
+  FLK_CHECK_HIP(hipSetDevice(n->device));
+  int rc = n->build_i3d();
+  if (rc) return rc;
+  n->weights.clear();
+  for (auto& L : n->convs) { std::vector<float>().swap(L->w); }
+  FLK_CHECK_HIP(hipDeviceSynchronize());
+  n->finalized = true;
+  return FLK_OK;
+}
+
+extern "C" int64_t flk_net_workspace_bytes(const flk_net* n) { return n ? (int64_t)n->alloc_bytes : 0; }
+extern "C" int64_t flk_net_input_numel(const flk_net* n) {
+  return n ? (int64_t)n->B * (n->T / 2) * (n->H / 2) * (n->W / 2) * 32 : 0;
+}
+extern "C" int flk_net_num_classes(const flk_net* n) { return n ? n->num_classes : 0; }
+
+static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool& ev_valid, hipStream_t s) {
+  if (n->profile && ev.size() != ops.size()) {
+    for (size_t i = ev.size(); i < ops.size(); ++i) {
+      hipEvent_t a, b;
+      FLK_CHECK_HIP(hipEventCreate(&a));
+      FLK_CHECK_HIP(hipEventCreate(&b));
+      ev.push_back({a, b});
+    }
+  }
+  for (size_t i = 0; i < ops.size(); ++i) {
+    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].first, s));
+    int rc = ops[i].run(s);
+    if (rc) return rc;
+    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].second, s));
+  }
+  ev_valid = n->profile;
+  return FLK_OK;
+}
+
+extern "C" int flk_net_forward(flk_net* n, const void* x_in, float* logits, int save_for_backward, void* stream) {
+  FLK_REQUIRE(n && n->finalized && x_in && logits, "flk_net_forward: bad argument / not finalized");
+  (void)save_for_backward;   // every activation lives in its own resident buffer
+  n->x_in = x_in; n->logits_out = logits;
+  int rc = run_ops(n, n->fwd, n->ev_fwd, n->ev_fwd_valid, (hipStream_t)stream);
+  if (rc) return rc;
+  n->fwd_done = true;
+  return FLK_OK;
+}
+
+extern "C" int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream) {
+  FLK_REQUIRE(n && n->finalized && dlogits && gx_in, "flk_net_backward: bad argument / not finalized");
+  if (!n->fwd_done) { flk_set_error("flk_net_backward: no forward pass to differentiate"); return FLK_ESTATE; }
+  n->dlogits_in = dlogits; n->gx_in = gx_in;
+  return run_ops(n, n->bwd, n->ev_bwd, n->ev_bwd_valid, (hipStream_t)stream);
+}
+
+extern "C" int flk_net_profile(flk_net* n, int enable) {
+  FLK_REQUIRE(n, "flk_net_profile: null net");
+  n->profile = enable != 0;
+  if (!enable) { n->ev_fwd_valid = n->ev_bwd_valid = false; }
+  return FLK_OK;
+}
+
+extern "C" int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap) {
+  FLK_REQUIRE(n && json_out && cap > 2, "flk_net_profile_read: bad argument");
+  std::string js = "[";
+  auto dump = [&](std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool valid, const char* pass) -> int {
+    if (!valid) return FLK_OK;
+    for (size_t i = 0; i < ops.size(); ++i) {
+      FLK_CHECK_HIP(hipEventSynchronize(ev[i].second));
+      float ms = 0.f;
+      FLK_CHECK_HIP(hipEventElapsedTime(&ms, ev[i].first, ev[i].second));
+      char buf[512];
+      snprintf(buf, sizeof(buf), "%s{\"name\":\"%s\",\"pass\":\"%s\",\"kind\":\"%s\",\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
+               js.size() > 1 ? "," : "", ops[i].name.c_str(), pass, kKindName[ops[i].kind], ms, ops[i].flops, ops[i].bytes);
+      js += buf;
+    }
+    return FLK_OK;
+  };
+  int rc = dump(n->fwd, n->ev_fwd, n->ev_fwd_valid, "fwd");
+  if (rc) return rc;
+  rc = dump(n->bwd, n->ev_bwd, n->ev_bwd_valid, "bwd");
+  if (rc) return rc;
+  js += "]";
+  FLK_REQUIRE((int64_t)js.size() + 1 <= cap, "flk_net_profile_read: buffer too small (%zu needed)", js.size() + 1);
+  memcpy(json_out, js.c_str(), js.size() + 1);
+  return FLK_OK;
+}
+
+extern "C" int flk_net_get_activation(flk_net* n, const char* name, float* host_out, int64_t cap_numel, int64_t* dims5) {
+  FLK_REQUIRE(n && n->finalized && name && dims5, "flk_net_get_activation: bad argument");
+  auto it = n->named.find(name);
+  FLK_REQUIRE(it != n->named.end(), "flk_net_get_activation: unknown endpoint '%s'", name);
+  const Act& a = it->second.first;
+  const int C = it->second.second;
+  dims5[0] = n->B; dims5[1] = a.T; dims5[2] = a.H; dims5[3] = a.W; dims5[4] = C;
+  const size_t npos = (size_t)n->B * a.T * a.H * a.W;
+  if (!host_out) return FLK_OK;
+  FLK_REQUIRE((int64_t)(npos * C) <= cap_numel, "flk_net_get_activation: buffer too small");
+  FLK_CHECK_HIP(hipDeviceSynchronize());
+  const size_t esz = n->esz();
+  std::vector<char> tmp(npos * a.ld * esz);
+  FLK_CHECK_HIP(hipMemcpy(tmp.data(), a.p, tmp.size(), hipMemcpyDeviceToHost));
+  for (size_t p = 0; p < npos; ++p)
+    for (int c = 0; c < C; ++c) {
+      float v;
+      if (n->dtype == FLK_BF16) {
+        const uint32_t u = (uint32_t)((const uint16_t*)tmp.data())[p * a.ld + c] << 16;
+        memcpy(&v, &u, 4);
+      } else {
+        v = ((const float*)tmp.data())[p * a.ld + c];
+      }
+      host_out[p * C + c] = v;
+    }
+  return FLK_OK;
+}

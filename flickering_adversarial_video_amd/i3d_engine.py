@@ -1,0 +1,173 @@
+"""I3D flickering-attack engine: the host-side mirror of the reference's ``kinetics_i3d`` object
+(utils/kinetics_i3d_utils.py:76-307) on top of libflicker_hip.so.
+
+The reference drives a TF-1 graph with 3-4 ``sess.run`` calls per iteration (3 forwards + 1 backward,
+each re-feeding the 54 MB clip: i3d_adversarial_main_single_video_npy.py:213-217,305-308).  Here ONE
+device pass per iteration does  apply(delta) -> I3D forward -> loss -> backward-to-delta -> Adam  and
+returns every scalar the scripts fetch; nothing syncs with the host unless a value is read.
+
+Data-parallel (class-generalisation / universal attacks): every rank holds the frozen packed weights and
+an identical replica of (delta, Adam m, v, t); the only exchange is ONE sum all-reduce of the (T x 3)
+adversarial gradient plus the loss scalars; the regulariser gradient is added once, after it.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import FLK_NET_I3D
+
+NUM_CLASSES = 400          # kinetics_i3d_utils.py:19
+SAMPLE_VIDEO_FRAMES = 90   # kinetics_i3d_utils.py:12 (reference default; the benchmark shape is 64)
+IMAGE_SIZE = 224           # kinetics_i3d_utils.py:9
+
+
+class StepResult(dict):
+    """Scalars of one attack iteration as device tensors; ``.host()`` fetches them (one sync)."""
+
+    def host(self):
+        return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in self.items()}
+
+
+class FlickerI3D:
+    """Attack engine for InceptionI3d.
+
+    ctor kwargs follow kinetics_i3d.__init__ (kinetics_i3d_utils.py:79-80) where they still mean something:
+    ``batch_size``, ``cyclic_flag_default_c``, ``cyclic_pert_flag_default_c``, ``default_adv_flag_c``;
+    ``weights`` replaces ``ckpt_path`` (a {checkpoint variable name: ndarray} dict, see i3d_spec.py) and
+    ``frames`` / ``dtype`` are new optional knobs (defaults reproduce the reference: 90 frames).
+    """
+
+    def __init__(self, weights, batch_size=1, frames=SAMPLE_VIDEO_FRAMES, dtype="bf16", device=0, dense_delta=False,
+                 cyclic_flag_default_c=0.0, cyclic_pert_flag_default_c=0.0, default_adv_flag_c=1.0, process_group=None,
+                 seed=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FlickerI3D needs an MI355X (HIP) device; there is no CPU fallback")
+        torch.cuda.set_device(device)
+        self.B, self.T, self.H, self.W = batch_size, frames, IMAGE_SIZE, IMAGE_SIZE
+        self.dtype = dtype
+        self.dense = dense_delta
+        self.cyclic_flag, self.cyclic_pert_flag, self.adv_flag = cyclic_flag_default_c, cyclic_pert_flag_default_c, default_adv_flag_c
+        self.pg = process_group
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world = torch.distributed.get_world_size(process_group) if dist_on else 1
+        self.net = ops.Net(FLK_NET_I3D, dtype, self.B, self.T, self.H, self.W, weights, device)
+        dev = torch.device("cuda", device)
+        dshape = (self.T, self.H, self.W, 3) if dense_delta else (self.T, 3)
+        # eps_rgb: zeros [T,1,1,3] (kinetics_i3d_utils.py:100); dense L12 variant: 1e-8 (:333)
+        self.eps_rgb = torch.full(dshape, 1e-8 if dense_delta else 0.0, dtype=torch.float32, device=dev)
+        self.adam_m, self.adam_v = torch.zeros_like(self.eps_rgb), torch.zeros_like(self.eps_rgb)
+        self.adam_t = 0
+        self._xs2d = torch.empty((self.B, self.T // 2, self.H // 2, self.W // 2, 32), dtype=self.net_torch_dtype, device=dev)
+        self._gx = torch.empty_like(self._xs2d)
+        self._logits = torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev)
+        # [g_adv (T*3) | adv loss sum | sum to_min_prob | sum to_max_prob]: ONE all-reduce payload
+        self._red = torch.zeros(self.T * 3 + 3, dtype=torch.float32, device=dev)
+        self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4),
+                                    dtype=torch.float32, device=dev)
+        self._scalars = torch.empty(8, dtype=torch.float32, device=dev)
+        self._rng = np.random.default_rng(seed)
+
+    @property
+    def net_torch_dtype(self):
+        return torch.bfloat16 if self.dtype in ("bf16", torch.bfloat16) else torch.float32
+
+    # ---- state -------------------------------------------------------------------------------------
+    def reset_perturbation(self, delta=None):
+        """sess.run(eps_rgb.initializer) + Adam slot re-init (i3d_adversarial_main_single_video_npy.py:205-206)"""
+        if delta is None:
+            self.eps_rgb.fill_(1e-8 if self.dense else 0.0)
+        else:
+            self.eps_rgb.copy_(torch.as_tensor(delta, dtype=torch.float32).reshape(self.eps_rgb.shape))
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        self.adam_t = 0
+
+    @property
+    def perturbation(self):
+        """[T,1,1,3] like the reference variable"""
+        return self.eps_rgb if self.dense else self.eps_rgb.view(self.T, 1, 1, 3)
+
+    def _apply_args(self, x, adv_flag, cyclic, cyclic_pert):
+        sx = int(self._rng.integers(0, self.T)) if cyclic else 0          # one shift per step for the whole batch
+        sp = int(self._rng.integers(0, self.T)) if cyclic_pert else 0     # (kinetics_i3d_utils.py:115,130)
+        return ops.make_apply_args(x, self.eps_rgb, dialect="tf", dclip=0.0 if self.dense else 0.4, adv_flag=adv_flag,
+                                   shift_x=sx, shift_p=sp)
+
+    def _check_x(self, x):
+        if tuple(x.shape) != (self.B, self.T, self.H, self.W, 3) or x.dtype not in (torch.uint8, torch.float32) or not x.is_cuda:
+            raise ValueError(f"clip must be a CUDA uint8/float32 tensor of shape {(self.B, self.T, self.H, self.W, 3)}, "
+                             f"got {tuple(x.shape)} {x.dtype} {x.device}")
+        return x.contiguous()
+
+    # ---- inference ---------------------------------------------------------------------------------
+    def logits(self, x, adv_flag=None, cyclic=None):
+        x = self._check_x(x)
+        a = self._apply_args(x, self.adv_flag if adv_flag is None else adv_flag, self.cyclic_flag if cyclic is None else cyclic, 0)
+        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
+        return self.net.forward(self._xs2d, self._logits)
+
+    def __call__(self, inputs, adv_flag=0):
+        """softmax of the (clean by default) clip: kinetics_i3d.__call__ (kinetics_i3d_utils.py:210-212)"""
+        return torch.softmax(self.logits(inputs, adv_flag), -1)
+
+    # ---- one attack iteration ----------------------------------------------------------------------
+    def step(self, x, labels, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05, targeted=False,
+             use_logits=False, improve_loss=True, cyclic=None, cyclic_pert=None, update=True):
+        """apply -> forward -> loss -> backward-to-delta -> (all-reduce) -> Adam, in one device pass.
+
+        loss = adv + beta0*(beta1*norm + beta2*diff + beta3*lap)  (i3d_adversarial_main_single_video_npy.py:56-59);
+        labels = true labels (untargeted) or the target class per clip (targeted).  Returned scalars are the
+        PRE-update values, as the reference fetches them together with train_op."""
+        if self.dense:
+            raise NotImplementedError("dense-delta (L12) Adam is not built yet; use the flicker attack")
+        x = self._check_x(x)
+        cyclic = self.cyclic_flag if cyclic is None else cyclic
+        cyclic_pert = self.cyclic_pert_flag if cyclic_pert is None else cyclic_pert
+        a = self._apply_args(x, 1.0, cyclic, cyclic_pert)
+        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
+        self.net.forward(self._xs2d, self._logits)
+        gbatch = self.B * self.world
+        sm, dl, pc = ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
+                                          targeted=targeted, margin=margin, mean_scale=1.0 / gbatch)
+        self.net.backward(dl, self._gx)
+        n = self.T * 3
+        ops.perturb_grad_reduce(a, self._gx, self._red[:n].view(self.T, 3), self._scratch)
+        self._red[n:] = pc[:, :3].sum(0)
+        if self.world > 1:
+            torch.distributed.all_reduce(self._red, group=self.pg)      # RCCL over xGMI: (T*3+3) floats
+        res = StepResult(adv_loss=self._red[n].clone(), prob_to_min=self._red[n + 1] / gbatch, prob_to_max=self._red[n + 2] / gbatch,
+                         softmax=sm, label_prob=pc[:, 1], argmax=pc[:, 3].to(torch.int64))
+        res["is_adversarial"] = (res["argmax"] == labels).all() if targeted else (res["argmax"] != labels).all()
+        if update:
+            self.adam_t += 1
+            ops.perturb_reg_adam(self._red[:n], self.eps_rgb, self.adam_m, self.adam_v, self.adam_t, dialect="tf", beta0=beta0,
+                                 beta1=beta1, beta2=beta2, beta3=beta3, lr=lr, scalars=self._scalars)
+            sc = self._scalars.clone()
+            res.update(reg_loss=sc[0], norm_reg=sc[1], diff_norm_reg=sc[2], laplacian_norm_reg=sc[3], thickness=sc[4],
+                       roughness=sc[5], pert_max=sc[6], pert_min=sc[7], total_loss=res["adv_loss"] + beta0 * sc[0],
+                       thickness_relative=sc[4] / 2 * 100, roughness_relative=sc[5] / 2 * 100)
+        return res
+
+    def delta_gradient(self):
+        """last all-reduced adversarial gradient d(adv)/d(delta), [T,3]"""
+        return self._red[:self.T * 3].view(self.T, 3)
+
+    # ---- fooling rate --------------------------------------------------------------------------------
+    def evaluate(self, batches, targeted_attack=False, target_class_id=None, cyclic=0, exclude_misclassify=True):
+        """kinetics_i3d.evaluate (kinetics_i3d_utils.py:217-250) over an iterable of (clip, labels) batches.
+        Returns (miss_rate, total_valid) aggregated over all ranks."""
+        cnt = torch.zeros(2, dtype=torch.float64, device=self.eps_rgb.device)
+        for x, y in batches:
+            adv = self.logits(x, 1.0, cyclic).argmax(-1)
+            miss = (adv == target_class_id) if targeted_attack else (adv != y)
+            if exclude_misclassify:
+                valid = self.logits(x, 0.0, 0).argmax(-1) == y
+                cnt[0] += (miss & valid).sum()
+                cnt[1] += valid.sum()
+            else:
+                cnt[0] += miss.sum()
+                cnt[1] += miss.numel()
+        if self.world > 1:
+            torch.distributed.all_reduce(cnt, group=self.pg)
+        miss, total = cnt.tolist()
+        return (miss / total if total else float("nan")), int(total)

@@ -1,0 +1,231 @@
+"""Thin host-side wrappers over the C ABI (include/flicker_hip.h): torch tensors are used for device
+memory and streams only; every computation happens in libflicker_hip.so."""
+import ctypes as C
+import json
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (FLK_BF16, FLK_F32, AdamArgs, ApplyArgs, ConvArgs, LossArgs, PoolArgs, check, dtype_code, load, ptr,
+                   stream_ptr, torch_dtype)
+
+
+def same_pad(n, k, s):
+    """TF SAME: (out, pad_before); the extra pad goes after."""
+    out = -(-n // s)
+    tot = max((out - 1) * s + k - n, 0)
+    return out, tot // 2
+
+
+class ConvWeights:
+    """Packed weights of one convolution operator (flk_conv_weights)."""
+
+    def __init__(self, w_dhwio, dtype, nf, row_scale=None, transpose=False):
+        w = np.ascontiguousarray(w_dhwio, dtype=np.float32)
+        assert w.ndim == 5
+        self.kt, self.kh, self.kw, cin, cout = w.shape
+        self.cin, self.cout = (cout, cin) if transpose else (cin, cout)
+        self.dtype, self.nf = dtype_code(dtype), nf
+        rs = None if row_scale is None else np.ascontiguousarray(row_scale, dtype=np.float32)
+        h = C.c_void_p()
+        check(load().flk_conv_weights_create(ptr(w), self.kt, self.kh, self.kw, cin, cout, ptr(rs), int(transpose),
+                                             self.dtype, nf, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            load().flk_conv_weights_destroy(self.handle)
+            self.handle = None
+
+
+def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
+           out_stride=(1, 1, 1), out_offset=(0, 0, 0), scale=None, bias=None, add=None, add_coff=0, mask=None,
+           mask_coff=0, relu=False):
+    """x: [B,T,H,W,ld] channels-last; returns / fills out [B,OT,OH,OW,ld_out].  pad = pad-before per dim
+    (default: TF SAME).  out_grid = logical output grid (default: SAME output size)."""
+    B, Ti, Hi, Wi, in_ld = x.shape
+    cin = w.cin if cin is None else cin
+    k = (w.kt, w.kh, w.kw)
+    if pad is None:
+        pad = tuple(same_pad(n, kk, s)[1] for n, kk, s in zip((Ti, Hi, Wi), k, stride))
+    if out_grid is None:
+        out_grid = tuple(same_pad(n, kk, s)[0] for n, kk, s in zip((Ti, Hi, Wi), k, stride))
+    if out is None:
+        phys = tuple((g - 1) * os_ + oo + 1 for g, os_, oo in zip(out_grid, out_stride, out_offset))
+        out = torch.zeros((B, *phys, w.cout + out_coff), dtype=x.dtype, device=x.device)
+    a = ConvArgs()
+    a.in_, a.in_ld, a.in_coff, a.cin = ptr(x), in_ld, in_coff, cin
+    a.B, a.Ti, a.Hi, a.Wi = B, Ti, Hi, Wi
+    a.kt, a.kh, a.kw = k
+    a.st, a.sh, a.sw = stride
+    a.pt, a.ph, a.pw = pad
+    a.To, a.Ho, a.Wo = out_grid
+    a.out, a.out_ld, a.out_coff, a.cout = ptr(out), out.shape[4], out_coff, w.cout
+    a.OT, a.OH, a.OW = out.shape[1:4]
+    a.ost, a.osh, a.osw = out_stride
+    a.oot, a.ooh, a.oow = out_offset
+    a.scale, a.bias = ptr(scale), ptr(bias)
+    if add is not None:
+        a.add, a.add_ld, a.add_coff = ptr(add), add.shape[4], add_coff
+    if mask is not None:
+        a.mask, a.mask_ld, a.mask_coff = ptr(mask), mask.shape[4], mask_coff
+    a.relu = int(relu)
+    check(load().flk_conv3d(C.byref(a), w.handle, dtype_code(x.dtype), stream_ptr()))
+    return out
+
+
+def _pool_args(x, C_, k, s, pad, out, idx, in_coff=0, out_coff=0):
+    B, Ti, Hi, Wi, ld = x.shape
+    a = PoolArgs()
+    a.in_, a.in_ld, a.in_coff, a.C = ptr(x), ld, in_coff, C_
+    a.B, a.Ti, a.Hi, a.Wi = B, Ti, Hi, Wi
+    a.kt, a.kh, a.kw = k
+    a.st, a.sh, a.sw = s
+    a.pt, a.ph, a.pw = pad
+    a.To, a.Ho, a.Wo = out.shape[1:4]
+    a.out, a.out_ld, a.out_coff = ptr(out), out.shape[4], out_coff
+    a.idx = ptr(idx)
+    return a
+
+
+def maxpool3d(x, k, s, C_=None):
+    """tf.nn.max_pool3d SAME.  Returns (out, idx uint8, ctx) with ctx for maxpool3d_bwd."""
+    B, Ti, Hi, Wi, ld = x.shape
+    C_ = ld if C_ is None else C_
+    og, pad = zip(*(same_pad(n, kk, ss) for n, kk, ss in zip((Ti, Hi, Wi), k, s)))
+    out = torch.empty((B, *og, C_), dtype=x.dtype, device=x.device)
+    idx = torch.empty((B, *og, C_), dtype=torch.uint8, device=x.device)
+    a = _pool_args(x, C_, k, s, pad, out, idx)
+    check(load().flk_maxpool3d_fwd(C.byref(a), dtype_code(x.dtype), stream_ptr()))
+    return out, idx, (x, C_, k, s, pad, out, idx)
+
+
+def maxpool3d_bwd(ctx, gout, mask=None):
+    x, C_, k, s, pad, out, idx = ctx
+    gin = torch.empty((*x.shape[:4], C_), dtype=x.dtype, device=x.device)
+    a = _pool_args(x, C_, k, s, pad, out, idx)
+    check(load().flk_maxpool3d_bwd(C.byref(a), ptr(gout), gout.shape[4], 0, ptr(gin), C_, 0, ptr(mask),
+                                   0 if mask is None else mask.shape[4], 0, dtype_code(x.dtype), stream_ptr()))
+    return gin
+
+
+def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=0, shift_p=0, inv_std=(1.0, 1.0, 1.0),
+                    lo=-1.0, hi=1.0):
+    """x: uint8 or fp32 [B,T,H,W,3] on the GPU; delta fp32 [T,3] or [T,H,W,3]."""
+    B, T, H, W, c3 = x.shape
+    assert c3 == 3 and x.is_contiguous() and delta.is_contiguous() and delta.dtype == torch.float32
+    a = ApplyArgs()
+    a.x = ptr(x)
+    a.x_is_u8 = int(x.dtype == torch.uint8)
+    assert x.dtype in (torch.uint8, torch.float32)
+    # TFRecord path: x = u8/128 - 1 (pre_process_rgb_flow.py:226-234)
+    a.x_scale, a.x_bias = (1.0 / 128.0, -1.0) if dialect == "tf" else (1.0, 0.0)
+    a.delta = ptr(delta)
+    a.delta_dense = int(delta.dim() == 4)
+    assert tuple(delta.shape) in ((T, 3), (T, H, W, 3)), delta.shape
+    a.dclip = float(dclip)
+    a.inv_std = (C.c_float * 3)(*inv_std)
+    a.lo, a.hi, a.adv_flag = float(lo), float(hi), float(adv_flag)
+    a.shift_x, a.shift_p = int(shift_x), int(shift_p)
+    a.B, a.T, a.H, a.W = B, T, H, W
+    return a
+
+
+def perturb_apply_s2d(args, dtype, out=None):
+    if out is None:
+        out = torch.empty((args.B, args.T // 2, args.H // 2, args.W // 2, 32), dtype=torch_dtype(dtype_code(dtype)), device="cuda")
+    check(load().flk_perturb_apply_s2d(C.byref(args), ptr(out), dtype_code(dtype), stream_ptr()))
+    return out
+
+
+def perturb_grad_reduce(args, gx_s2d, gdelta=None, scratch=None):
+    if gdelta is None:
+        shape = (args.T, args.H, args.W, 3) if args.delta_dense else (args.T, 3)
+        gdelta = torch.empty(shape, dtype=torch.float32, device="cuda")
+    if scratch is None and not args.delta_dense:
+        n = load().flk_perturb_grad_scratch_bytes(args.B, args.T, args.H, args.W)
+        scratch = torch.empty(n // 4, dtype=torch.float32, device="cuda")
+    check(load().flk_perturb_grad_reduce(C.byref(args), ptr(gx_s2d), dtype_code(gx_s2d.dtype), ptr(gdelta), ptr(scratch), stream_ptr()))
+    return gdelta
+
+
+def perturb_reg_adam(g_adv, delta, m, v, step, *, dialect="tf", beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5,
+                     dyn_max_norm=0.0, g_scale=1.0, lr=1e-3, adam=(0.9, 0.999, 1e-8), scalars=None):
+    a = AdamArgs()
+    a.T = delta.shape[0]
+    a.torch_dialect = int(dialect == "torch")
+    a.beta0, a.beta1, a.beta2, a.beta3 = beta0, beta1, beta2, beta3
+    a.dyn_max_norm, a.g_scale, a.lr = dyn_max_norm, g_scale, lr
+    a.adam_b1, a.adam_b2, a.adam_eps = adam
+    a.step = int(step)
+    if scalars is None:
+        scalars = torch.empty(8, dtype=torch.float32, device="cuda")
+    check(load().flk_perturb_reg_adam(C.byref(a), ptr(g_adv), ptr(delta), ptr(m), ptr(v), ptr(scalars), stream_ptr()))
+    return scalars
+
+
+def softmax_adv_loss(logits, labels, *, dialect="tf", improve_loss=True, use_logits=False, targeted=False, margin=0.05,
+                     mean_scale=1.0):
+    B, Cn = logits.shape
+    a = LossArgs()
+    a.B, a.C = B, Cn
+    a.torch_dialect, a.improve_loss, a.use_logits, a.targeted = int(dialect == "torch"), int(improve_loss), int(use_logits), int(targeted)
+    a.margin, a.mean_scale = margin, mean_scale
+    sm = torch.empty_like(logits)
+    dl = torch.empty_like(logits)
+    pc = torch.empty((B, 4), dtype=torch.float32, device=logits.device)
+    assert logits.dtype == torch.float32 and labels.dtype == torch.int64 and logits.is_contiguous()
+    check(load().flk_softmax_adv_loss(C.byref(a), ptr(logits), ptr(labels), ptr(sm), ptr(dl), ptr(pc), stream_ptr()))
+    return sm, dl, pc
+
+
+class Net:
+    """flk_net: whole-network forward + backward-to-input plan with resident packed weights."""
+
+    def __init__(self, arch, dtype, B, T, H, W, weights, device=0):
+        self.dtype = dtype_code(dtype)
+        self.B, self.T, self.H, self.W = B, T, H, W
+        h = C.c_void_p()
+        check(load().flk_net_create(arch, self.dtype, B, T, H, W, device, C.byref(h)))
+        self.handle = h
+        for name, arr in weights.items():
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            check(load().flk_net_set_weight(h, name.encode(), ptr(arr), arr.size))
+        check(load().flk_net_finalize(h))
+        self.num_classes = load().flk_net_num_classes(h)
+        self.input_numel = load().flk_net_input_numel(h)
+        self.workspace_bytes = load().flk_net_workspace_bytes(h)
+
+    def forward(self, x_in, logits=None):
+        if logits is None:
+            logits = torch.empty((self.B, self.num_classes), dtype=torch.float32, device="cuda")
+        assert x_in.numel() == self.input_numel and x_in.is_contiguous()
+        check(load().flk_net_forward(self.handle, ptr(x_in), ptr(logits), 1, stream_ptr()))
+        return logits
+
+    def backward(self, dlogits, gx=None):
+        if gx is None:
+            gx = torch.empty(self.input_numel, dtype=torch_dtype(self.dtype), device="cuda")
+        check(load().flk_net_backward(self.handle, ptr(dlogits), ptr(gx), stream_ptr()))
+        return gx
+
+    def profile(self, enable):
+        check(load().flk_net_profile(self.handle, int(enable)))
+
+    def profile_read(self):
+        buf = C.create_string_buffer(1 << 20)
+        check(load().flk_net_profile_read(self.handle, buf, len(buf)))
+        return json.loads(buf.value.decode())
+
+    def activation(self, name):
+        dims = (C.c_int64 * 5)()
+        check(load().flk_net_get_activation(self.handle, name.encode(), None, 0, dims))
+        out = np.empty(tuple(dims), dtype=np.float32)
+        check(load().flk_net_get_activation(self.handle, name.encode(), ptr(out), out.size, dims))
+        return out
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            load().flk_net_destroy(self.handle)
+            self.handle = None

@@ -1,0 +1,192 @@
+/* flicker_hip.h -- C ABI of libflicker_hip.so (MI355X / gfx950 flickering-attack hot path).
+ *
+ * The reference (roiponytch/Flickering_Adversarial_Video) has no FFI / operator layer: its hot path is
+ * framework ops (TF-1.15 Conv3D / MaxPool3D / ... and torch-1.4 aten::conv3d / ...) reached from
+ * Python objects.  This header is the boundary a maintainer binds instead; every
+ * entry point cites the reference code it replaces.  See INTEGRATION.md for the ctypes binding.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns 0 (FLK_OK) or a negative
+ *     FLK_E* code; flk_last_error() returns a thread-local message for the last failure.
+ *   - the CALLER owns every tensor: functions take raw device pointers, PODs and a hipStream_t
+ *     (passed as void*); everything is asynchronous on that stream, there are no hidden syncs.
+ *   - tensors are channels-last ("NDHWC") as the I3D maths is specified (i3d.py); `ld` is the
+ *     channel stride between consecutive positions (>= C), `coff` a channel offset into the buffer
+ *     (so Inception branches write slices of one concat buffer -- tf.concat, i3d.py:219, is elided).
+ *   - dtype: FLK_F32 = fp32 storage + exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): the parity mode;
+ *            FLK_BF16 = bf16 storage + bf16 MFMA with fp32 accumulation: the performance mode.
+ *     BN scale/bias, losses, delta, Adam state and all reductions are fp32 in both modes.
+ *   - a flk_net is bound to one device and is not thread-safe; distinct nets are independent.
+ */
+#ifndef FLICKER_HIP_H
+#define FLICKER_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLK_OK 0
+#define FLK_EINVAL (-1)   /* bad argument / unsupported shape */
+#define FLK_EHIP (-2)     /* a HIP runtime call failed */
+#define FLK_ENOMEM (-3)
+#define FLK_ESTATE (-4)   /* call order violated (e.g. backward before forward) */
+
+#define FLK_F32 0
+#define FLK_BF16 1
+
+int flk_version(void);
+const char* flk_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-op entry points (kernel-level parity tests call these).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Packed weights for one convolution: built once on the host, resident on the device.
+ * w_dhwio: fp32 host array [kt][kh][kw][cin][cout] (TF checkpoint layout, i3d.py:61-65).
+ * row_scale (optional, len cout for transpose=1): folded into the weights (BN scale for dgrad).
+ * transpose=1 builds the data-gradient operator (taps flipped, cin<->cout swapped), i.e. what
+ * Conv3DBackpropInputV2 / aten::conv3d backward-input applies.  nf = output-channel fragments per
+ * workgroup tile (2, 4 or 8 -> 32/64/128 channels). */
+typedef struct flk_conv_weights flk_conv_weights;
+int flk_conv_weights_create(const float* w_dhwio, int kt, int kh, int kw, int cin, int cout,
+                            const float* row_scale, int transpose, int dtype, int nf,
+                            flk_conv_weights** out);
+int flk_conv_weights_destroy(flk_conv_weights* w);
+
+/* Generic 3-D convolution as implicit GEMM on MFMA, LDS-staged T x H x W halo tiles.
+ * Replaces snt.Conv3D + snt.BatchNorm(inference) + relu (Unit3D, i3d.py:51-71) and, with a
+ * transposed weight set, Conv3DBackpropInputV2 + ReluGrad; also aten::conv3d(+BatchNorm3d+ReLU
+ * +residual) of torchvision VideoResNet (model.py:421).
+ *   out[pos, coff_out + n] = epilogue( sum_{tap,c} in[pos*stride - pad + tap, coff_in + c] * W )
+ *   epilogue: v = acc*scale[n] + bias[n];  v += add[pos,n];  relu;  v = mask[pos,n] > 0 ? v : 0
+ * (each stage optional).  Logical output grid (To,Ho,Wo) maps to physical output positions
+ * o*ostride + ooffset inside (OT,OH,OW): stride-1 everywhere except the parity-decomposed
+ * data-gradient of strided convolutions. */
+typedef struct {
+  const void* in; int in_ld, in_coff, cin;
+  int B, Ti, Hi, Wi;
+  int kt, kh, kw;          /* tap box */
+  int st, sh, sw;          /* input step per logical output step */
+  int pt, ph, pw;          /* padding BEFORE (TF SAME puts the extra pad after, i3d.py:64) */
+  int To, Ho, Wo;          /* logical output grid */
+  void* out; int out_ld, out_coff, cout;
+  int OT, OH, OW;          /* physical output dims */
+  int ost, osh, osw, oot, ooh, oow;
+  const float* scale; const float* bias;       /* per output channel or NULL */
+  const void* add; int add_ld, add_coff;       /* NULL or tensor with the physical output geometry */
+  const void* mask; int mask_ld, mask_coff;    /* NULL or tensor with the physical output geometry */
+  int relu;
+} flk_conv_args;
+int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream);
+
+/* tf.nn.max_pool3d SAME (i3d.py:174,189,212,252,398): padded cells never win; argmax = FIRST
+ * maximum in (t,h,w) scan order, stored as a uint8 window index for the backward pass.
+ * MaxPool3DGrad: gather form (deterministic), optional add and relu-mask like flk_conv3d. */
+typedef struct {
+  const void* in; int in_ld, in_coff; int C;
+  int B, Ti, Hi, Wi;
+  int kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int To, Ho, Wo;
+  void* out; int out_ld, out_coff;
+  uint8_t* idx;            /* [B,To,Ho,Wo,C] */
+} flk_pool_args;
+int flk_maxpool3d_fwd(const flk_pool_args* a, int dtype, void* stream);
+/* gin[pos,c] = (add?add:0) + sum_{windows containing pos with argmax == pos} gout[window,c];
+ * then masked by mask[pos,c] > 0 if mask != NULL.  a->in/out describe the FORWARD tensors'
+ * geometry: gout has the `out` geometry (ld/coff given here), gin the `in` geometry. */
+int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int gout_ld, int gout_coff,
+                      void* gin, int gin_ld, int gin_coff,
+                      const void* mask, int mask_ld, int mask_coff, int dtype, void* stream);
+
+/* Perturbation apply fused with the stem's space-to-depth staging.
+ * kinetics_i3d_utils.py:100-142:  x_adv = clip(x + a * clip(delta[t,c], +-dclip), lo, hi)
+ * model.py:80-101 (torch dialect): same with delta/std[c] and scalar clamp bounds.
+ * x: uint8 (x = u8*x_scale + x_bias, the TFRecord path pre_process_rgb_flow.py:226-234) or fp32,
+ *    [B,T,H,W,3]; delta: fp32 [T,3] (flicker) or [T,H,W,3] (dense, "L12" baseline).
+ * out: [B,T/2,H/2,W/2,32] of dtype: channel (qt*4+qh*2+qw)*3+c, channels 24..31 zero -- the
+ * 7x7x7/2 stem (i3d.py:169) then runs as a 4x4x4/1 convolution on MFMA.  T,H,W must be even. */
+typedef struct {
+  const void* x; int x_is_u8; float x_scale, x_bias;
+  const float* delta; int delta_dense;
+  float dclip;               /* 0.4 (TF) or dynamic_max_norm (torch); <=0 disables */
+  float inv_std[3];          /* 1 (TF) or 1/DEFAULT_STD (torch) */
+  float lo, hi;              /* -1,1 (TF) or -1.73488, 2.49020 (torch) */
+  float adv_flag;            /* 0 -> clean input */
+  int shift_x, shift_p;      /* cyclic temporal rolls (kinetics_i3d_utils.py:115-137), 0 = off */
+  int B, T, H, W;
+} flk_apply_args;
+int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dtype, void* stream);
+
+/* d(loss)/d(delta): reduce the stem's input gradient (space-to-depth layout, from flk_conv3d) over
+ * (B,H,W) with the clip masks of flk_perturb_apply_s2d.  gdelta: fp32 [T,3]
+ * (flicker; deterministic two-stage reduction) or [T,H,W,3] (dense).  `partials` is caller scratch
+ * of flk_perturb_grad_scratch_bytes(). */
+int64_t flk_perturb_grad_scratch_bytes(int B, int T, int H, int W);
+int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s2d, int dtype,
+                            float* gdelta, float* partials, void* stream);
+
+/* Regulariser gradient + Adam on delta (flicker, [T,3] time-major; the torch dialect's [3,T] is
+ * transposed by the host wrapper).  TF dialect: kinetics_i3d_utils.py:177-186 +
+ * i3d_adversarial_main_single_video_npy.py:56-59,79-84 (regulariser on the RAW delta, TF Adam).
+ * torch dialect: model.py:198-209 (regulariser on the CLAMPED delta, torch Adam, model.py:868).
+ * g_adv is the (all-reduced) adversarial-loss gradient.  Writes scalars[8] =
+ * {reg_total, norm, diff, lap, thickness, roughness, max, min} of the PRE-update delta. */
+typedef struct {
+  int T;
+  int torch_dialect;
+  float beta0;               /* TF: LAMBDA; torch: lambda_ */
+  float beta1, beta2, beta3; /* TF: b1*norm + b2*diff + b3*lap; torch: b1*norm + (1-b1)(diff+lap) */
+  float dyn_max_norm;        /* torch clamp bound for the regulariser */
+  float g_scale;             /* multiplies g_adv (1/(global batch) for mean losses) */
+  float lr, adam_b1, adam_b2, adam_eps;
+  int step;                  /* 1-based Adam step of THIS update */
+} flk_adam_args;
+int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, float* delta, float* m, float* v,
+                         float* scalars, void* stream);
+
+/* Loss head: softmax + adversarial loss + d(loss)/d(logits) (kinetics_i3d_utils.py:152-169,253-307;
+ * model.py:177-250).  per_clip[b*4..] = {loss_b, label_prob, max_non_label_prob, argmax}. */
+typedef struct {
+  int B, C;
+  int torch_dialect, improve_loss, use_logits, targeted;
+  float margin;
+  float mean_scale;          /* CE variants are means: 1/(global batch) */
+} flk_loss_args;
+int flk_softmax_adv_loss(const flk_loss_args* a, const float* logits, const int64_t* labels,
+                         float* softmax, float* dlogits, float* per_clip, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-network plan: the victim classifier forward + backward-to-input as one call
+ * (replaces sess.run([train_op, ...]) of i3d_adversarial_main_single_video_npy.py:213-217 and
+ * model([x,True]) + loss.backward() of model.py:1073-1101).  Weights are handed over once,
+ * packed on the host and kept resident (never re-broadcast, cf. nn.DataParallel model.py:576).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct flk_net flk_net;
+#define FLK_NET_I3D 0
+#define FLK_NET_R2PLUS1D_18 1
+#define FLK_NET_R3D_18 2
+#define FLK_NET_MC3_18 3
+
+int flk_net_create(int arch, int dtype, int B, int T, int H, int W, int device, flk_net** out);
+int flk_net_destroy(flk_net* n);
+/* name = checkpoint variable name (kinetics_i3d_utils.py:41-62 for I3D; torchvision state_dict keys
+ * for VideoResNet); data = fp32 host array in the checkpoint's own layout. */
+int flk_net_set_weight(flk_net* n, const char* name, const float* data, int64_t numel);
+int flk_net_finalize(flk_net* n);                 /* pack + upload; plan buffers */
+int64_t flk_net_workspace_bytes(const flk_net* n);
+/* x_s2d: output of flk_perturb_apply_s2d (I3D) ; logits: fp32 [B,num_classes] */
+int flk_net_forward(flk_net* n, const void* x_in, float* logits, int save_for_backward, void* stream);
+/* dlogits fp32 [B,C] -> gradient w.r.t. the network input (same layout/dtype as x_in) */
+int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream);
+/* per-layer HIP-event timing of the next forward/backward (bench.py roofline leg) */
+int flk_net_profile(flk_net* n, int enable);
+int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap);
+int64_t flk_net_input_numel(const flk_net* n);
+int flk_net_num_classes(const flk_net* n);
+/* debugging / parity: copy a named activation (fp32, NDHWC) to the host */
+int flk_net_get_activation(flk_net* n, const char* name, float* host_out, int64_t cap_numel, int64_t* dims5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
