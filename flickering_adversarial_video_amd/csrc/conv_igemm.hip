@@ -275,12 +275,12 @@ flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st,
         const long halo = (long)((Tt - 1) * st + kt) * ((Ht - 1) * sh + kh) * ((Wt - 1) * sw + kw);
         if (halo > FLK_MAX_HALO) continue;
         const long tiles = (long)((To + Tt - 1) / Tt) * ((Ho + Ht - 1) / Ht) * ((Wo + Wt - 1) / Wt);
-        // waves are 64-row granules: idle waves cost nothing, partially filled ones do
+        // a workgroup occupies a CU slot whatever its row count: utilisation = useful rows / (tiles * 256);
+        // staging cost grows with the halo (per slab) while MFMA work grows with rows * taps
         const int rows = Tt * Ht * Wt;
-        const double eff = (double)To * Ho * Wo / ((double)tiles * ((rows + 63) / 64 * 64));
-        // prefer (1) MFMA row utilisation, (2) fewer workgroups (less halo + weight re-staging),
-        // (3) wide W runs (consecutive positions = conflict-free LDS reads), (4) small halo
-        const double score = eff - 1e-3 * (double)halo / rows;
+        const double eff = (double)To * Ho * Wo / ((double)tiles * FLK_ROWS);
+        const double score = eff / (1.0 + 2.0 * (double)halo / ((double)FLK_ROWS * kt * kh * kw));
+        (void)rows;
         if (score > best_eff + 1e-9 || (score > best_eff - 1e-9 && (Wt > best.Wt || (Wt == best.Wt && halo < best_halo)))) {
           best_eff = score; best = flk_tile{Tt, Ht, Wt}; best_halo = halo;
         }

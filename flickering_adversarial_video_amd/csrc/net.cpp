@@ -272,6 +272,7 @@ int flk_net::build_i3d() {
   Act a1, G1;
   if ((rc = new_act(a1, T1, H1, W1, 64)) || (rc = new_act(G1, T1, H1, W1, 64))) return rc;
   named["Conv3d_1a_7x7"] = {a1, 64};
+  named["grad:Conv3d_1a_7x7"] = {G1, 64};
   {
     // SAME padding of the 7/2 conv on an even size is (2,3) -> in s2d space taps j=0..3 read o-1+j: pad-before 1
     flk_conv_args a{};
@@ -306,6 +307,7 @@ int flk_net::build_i3d() {
   if ((rc = emit_pool_fwd("MaxPool3d_2a_3x3", a1, 64, 1, 3, 3, 1, 2, 2, p2a, r2a))) return rc;
   if ((rc = new_act(Gp2a, p2a.T, p2a.H, p2a.W, 64))) return rc;
   named["MaxPool3d_2a_3x3"] = {p2a, 64};
+  named["grad:MaxPool3d_2a_3x3"] = {Gp2a, 64};
   bwd_emit.push_back([this, r2a, Gp2a, G1, a1]() { emit_pool_bwd("MaxPool3d_2a_3x3", r2a, Gp2a, G1, &a1); });
 
   // ---- Conv3d_2b_1x1, Conv3d_2c_3x3 ----
@@ -319,6 +321,8 @@ int flk_net::build_i3d() {
   emit_conv_fwd(c2c, a2b, 0, a2c, 0);
   named["Conv3d_2b_1x1"] = {a2b, 64};
   named["Conv3d_2c_3x3"] = {a2c, 192};
+  named["grad:Conv3d_2b_1x1"] = {G2b, 64};
+  named["grad:Conv3d_2c_3x3"] = {G2c, 192};
   bwd_emit.push_back([this, c2b, G2b, Gp2a]() { emit_conv_bwd(c2b, G2b, 0, Gp2a, 0, nullptr, 0, 0, nullptr, 0); });
   bwd_emit.push_back([this, c2c, G2c, G2b, a2b]() { emit_conv_bwd(c2c, G2c, 0, G2b, 0, nullptr, 0, 0, &a2b, 0); });
 
@@ -327,6 +331,7 @@ int flk_net::build_i3d() {
   if ((rc = emit_pool_fwd("MaxPool3d_3a_3x3", a2c, 192, 1, 3, 3, 1, 2, 2, p3a, r3a))) return rc;
   if ((rc = new_act(Gp3a, p3a.T, p3a.H, p3a.W, 192))) return rc;
   named["MaxPool3d_3a_3x3"] = {p3a, 192};
+  named["grad:MaxPool3d_3a_3x3"] = {Gp3a, 192};
   bwd_emit.push_back([this, r3a, Gp3a, G2c, a2c]() { emit_pool_bwd("MaxPool3d_3a_3x3", r3a, Gp3a, G2c, &a2c); });
 
   // ---- Inception blocks ----
@@ -352,6 +357,7 @@ int flk_net::build_i3d() {
       if ((rc = emit_pool_fwd(bk.pool_name, cur, cur_c, bk.pk[0], bk.pk[1], bk.pk[2], bk.ps[0], bk.ps[1], bk.ps[2], po, pr))) return rc;
       if ((rc = new_act(Gpo, po.T, po.H, po.W, cur_c))) return rc;
       named[bk.pool_name] = {po, cur_c};
+      named[std::string("grad:") + bk.pool_name] = {Gpo, cur_c};
       const Act prev = cur, Gprev = Gcur;
       const std::string pn = bk.pool_name;
       bwd_emit.push_back([this, pn, pr, Gpo, Gprev, prev]() { emit_pool_bwd(pn, pr, Gpo, Gprev, &prev); });
@@ -381,6 +387,9 @@ int flk_net::build_i3d() {
     if ((rc = emit_pool_fwd(bn + "/Branch_3/MaxPool3d_0a_3x3", cur, cur_c, 3, 3, 3, 1, 1, 1, pl, pr3))) return rc;
     emit_conv_fwd(L3, pl, 0, out, c0 + c1b + c2b_);
     named[bn] = {out, cout_total};
+    named["grad:" + bn] = {Gout, cout_total};
+    named["mid:" + bn] = {mid, c1a + c2a};
+    named["gradmid:" + bn] = {Gmid, c1a + c2a};
     // backward (emitted in reverse program order below): branch 3 first so the 1x1 dgrads can accumulate on it
     const Act in_act = cur, Gin = Gcur;
     const bool in_relu = cur_is_relu;

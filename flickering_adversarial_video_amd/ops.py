@@ -34,9 +34,12 @@ class ConvWeights:
         self.handle = h
 
     def __del__(self):
-        if getattr(self, "handle", None):
-            load().flk_conv_weights_destroy(self.handle)
-            self.handle = None
+        try:
+            if getattr(self, "handle", None):
+                load().flk_conv_weights_destroy(self.handle)
+                self.handle = None
+        except Exception:      # interpreter shutdown
+            pass
 
 
 def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
@@ -129,6 +132,7 @@ def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=
     a.lo, a.hi, a.adv_flag = float(lo), float(hi), float(adv_flag)
     a.shift_x, a.shift_p = int(shift_x), int(shift_p)
     a.B, a.T, a.H, a.W = B, T, H, W
+    a._keepalive = (x, delta)   # the struct holds raw pointers only
     return a
 
 
@@ -226,6 +230,9 @@ class Net:
         return out
 
     def __del__(self):
-        if getattr(self, "handle", None):
-            load().flk_net_destroy(self.handle)
-            self.handle = None
+        try:
+            if getattr(self, "handle", None):
+                load().flk_net_destroy(self.handle)
+                self.handle = None
+        except Exception:      # interpreter shutdown
+            pass

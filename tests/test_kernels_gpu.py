@@ -158,3 +158,93 @@ def test_maxpool_fwd_bwd(ops, dtype, k, s, dims):
     torch.testing.assert_close(masked, torch.where(pos, gref, torch.zeros_like(gref)), rtol=r, atol=a)
     # first-max-in-scan-order is torch-CPU's rule too: without ties broken differently the full tensors agree
     torch.testing.assert_close(gin.float().cpu(), gref, rtol=r, atol=a)
+
+
+BLOCKS = {"small": (1, 2, 7, 7, 64, (32, 24, 48, 16, 32, 16)),
+          "Mixed_5c": (1, 2, 7, 7, 832, (384, 192, 384, 48, 128, 128)),
+          "Mixed_3b": (1, 4, 28, 28, 192, (64, 96, 128, 16, 32, 32)),
+          "Mixed_4c": (2, 4, 14, 14, 512, (160, 112, 224, 24, 64, 64))}
+
+
+def pick_nf(c, taps):
+    return 8 if c > 64 else (4 if c > 32 else 2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("blk", list(BLOCKS))
+def test_inception_block_forward_backward(ops, dtype, blk):
+    """One Mixed block (i3d.py:194-219) composed from the per-op C ABI exactly as csrc/net.cpp wires it
+    (slice writes into the concat buffer; backward = branch-3 dgrad -> pool grad -> 3x3x3 dgrads with ReLU
+    masks -> three accumulating 1x1 dgrads), against torch-CPU autograd."""
+    B, T, H, W, cin, (c0, c1a, c1b, c2a, c2b, c3) = BLOCKS[blk]
+    ctot = c0 + c1b + c2b + c3
+    rng = np.random.default_rng(0)
+
+    def mk(k, ci, co, seed):
+        w = q(rnd((*k, ci, co), seed, (2.0 / (ci * k[0] * k[1] * k[2])) ** 0.5), dtype)
+        return w, rnd((co,), seed + 100).abs() * 0.5 + 0.75, rnd((co,), seed + 200) * 0.1
+
+    one, three = (1, 1, 1), (3, 3, 3)
+    P = {"0": mk(one, cin, c0, 1), "1a": mk(one, cin, c1a, 2), "1b": mk(three, c1a, c1b, 3), "2a": mk(one, cin, c2a, 4),
+         "2b": mk(three, c2a, c2b, 5), "3": mk(one, cin, c3, 6)}
+    xin = torch.relu(q(rnd((B, T, H, W, cin), 7), dtype))     # block input = a ReLU output
+    gout = q(rnd((B, T, H, W, ctot), 8), dtype)
+
+    # ---- oracle ----
+    xr = xin.clone().requires_grad_(True)
+
+    def unit(x, key, k):
+        w, a, b = P[key]
+        return torch.relu(ref_conv(x, w, (1, 1, 1), tuple((kk - 1) // 2 for kk in k), (T, H, W)) * a + b)
+
+    b0 = unit(xr, "0", one)
+    y1a = unit(xr, "1a", one); b1 = unit(y1a, "1b", three)
+    y2a = unit(xr, "2a", one); b2 = unit(y2a, "2b", three)
+    pl = cl(F.max_pool3d(F.pad(cf(xr), (1, 1, 1, 1, 1, 1), value=float("-inf")), 3, 1))
+    b3 = unit(pl, "3", one)
+    out_ref = torch.cat([b0, b1, b2, b3], -1)
+    G_ref = torch.where(out_ref > 0, gout, torch.zeros_like(gout))      # masked gradient the G buffer holds
+    gx_ref, gpl_ref, g1a_ref, g2a_ref = torch.autograd.grad(out_ref, [xr, pl, y1a, y2a], gout)
+    g1a_ref = torch.where(y1a > 0, g1a_ref, torch.zeros_like(g1a_ref))
+    g2a_ref = torch.where(y2a > 0, g2a_ref, torch.zeros_like(g2a_ref))
+    gx_ref = torch.where(xin > 0, gx_ref, torch.zeros_like(gx_ref))
+
+    # ---- HIP, wired like net.cpp ----
+    dev = lambda t: t.to(dtype).cuda()
+    x = dev(xin)
+    out = torch.zeros((B, T, H, W, ctot), dtype=dtype).cuda()
+    mid = torch.zeros((B, T, H, W, c1a + c2a), dtype=dtype).cuda()
+    Wf = {k: ops.ConvWeights(v[0].numpy(), dtype, pick_nf(v[0].shape[4], 0)) for k, v in P.items()}
+    Wb = {k: ops.ConvWeights(v[0].numpy(), dtype, pick_nf(v[0].shape[3], 0), row_scale=v[1].numpy(), transpose=True)
+          for k, v in P.items()}
+    sc = {k: (v[1].cuda(), v[2].cuda()) for k, v in P.items()}
+    ops.conv3d(x, Wf["0"], out=out, out_coff=0, scale=sc["0"][0], bias=sc["0"][1], relu=True)
+    ops.conv3d(x, Wf["1a"], out=mid, out_coff=0, scale=sc["1a"][0], bias=sc["1a"][1], relu=True)
+    ops.conv3d(mid, Wf["1b"], in_coff=0, cin=c1a, out=out, out_coff=c0, scale=sc["1b"][0], bias=sc["1b"][1], relu=True)
+    ops.conv3d(x, Wf["2a"], out=mid, out_coff=c1a, scale=sc["2a"][0], bias=sc["2a"][1], relu=True)
+    ops.conv3d(mid, Wf["2b"], in_coff=c1a, cin=c2a, out=out, out_coff=c0 + c1b, scale=sc["2b"][0], bias=sc["2b"][1], relu=True)
+    pool, idx, pctx = ops.maxpool3d(x, three, one)
+    ops.conv3d(pool, Wf["3"], out=out, out_coff=c0 + c1b + c2b, scale=sc["3"][0], bias=sc["3"][1], relu=True)
+    r, a = tol(dtype, out_ref)
+    torch.testing.assert_close(out.float().cpu(), out_ref.detach(), rtol=r * 2, atol=a * 2)
+
+    G = dev(torch.where(out.float().cpu() > 0, gout, torch.zeros_like(gout)))
+    Gpl = ops.conv3d(G, Wb["3"], in_coff=c0 + c1b + c2b, cin=c3)
+    gxa = ops.maxpool3d_bwd(pctx, Gpl)
+    Gmid = torch.zeros_like(mid)
+    ops.conv3d(G, Wb["2b"], in_coff=c0 + c1b, cin=c2b, out=Gmid, out_coff=c1a, mask=mid, mask_coff=c1a)
+    ops.conv3d(G, Wb["1b"], in_coff=c0, cin=c1b, out=Gmid, out_coff=0, mask=mid, mask_coff=0)
+    if dtype == torch.float32:
+        for nm, got, want in (("branch-3 1x1 dgrad", Gpl, gpl_ref), ("1b dgrad", Gmid[..., :c1a], g1a_ref), ("2b dgrad", Gmid[..., c1a:], g2a_ref)):
+            r, a = tol(dtype, want)
+            frac = ((got.float().cpu() - want).abs() > a * 4 + r * 4 * want.abs()).float().mean().item()
+            assert frac < 0.01, (nm, frac)
+    Gin = torch.zeros_like(x)
+    ops.conv3d(G, Wb["0"], in_coff=0, cin=c0, out=Gin, add=gxa)
+    ops.conv3d(Gmid, Wb["1a"], in_coff=0, cin=c1a, out=Gin, add=Gin)
+    ops.conv3d(Gmid, Wb["2a"], in_coff=c1a, cin=c2a, out=Gin, add=Gin, mask=x)
+    r, a = tol(dtype, gx_ref)
+    # a ReLU mask can flip where an activation is within rounding of 0 (fp32 too: different summation order)
+    # -> isolated O(1) differences on that unit's receptive field; everything else must agree tightly
+    bad = ((Gin.float().cpu() - gx_ref).abs() > a * 4 + r * 4 * gx_ref.abs()).float().mean().item()
+    assert bad < (0.01 if dtype == torch.float32 else 0.03), bad
