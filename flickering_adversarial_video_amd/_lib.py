@@ -106,6 +106,9 @@ def load():
         raise FlickerHipError(
             f"{LIB_PATH} is missing: build it with `python -m flickering_adversarial_video_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7; load it FIRST so that this library's NEEDED libamdhip64.so.7
+    # resolves to the SAME runtime instance (one HIP runtime per process: shared streams / device pointers).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
