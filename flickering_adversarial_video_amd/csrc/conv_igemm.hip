@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   typedef typename PR::frag frag;
   constexpr int EPL = PR::EPL;
   constexpr int SLABC = 4 * EPL;
-  constexpr int WCH = (NF * 64 + 255) / 256;  // 16-byte weight chunks per thread per (slab, tap)
+  constexpr int WCH = NF >= 4 ? NF / 4 : 1;   // 16-byte weight chunks per thread per (slab, tap)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo = smem;
   char* const wbuf = smem + 4 * p.plane_b + 64;
@@ -144,32 +144,36 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // weight stream: (slab, tap) step k lives at w + (k*cout_frags + ntile*NF) KiB
-  const char* wsrc = p.w + (size_t)ntile * NF * 1024 + tid * 16;
+  // weight stream: (slab, tap) step k lives at w + (k*cout_frags + ntile*NF) KiB.  Every thread moves WCH 16-byte
+  // chunks per step, unconditionally (NF=2: threads t and t+128 move the same chunk) so the prefetch stays in VGPRs.
+  const int wchunk = NF >= 4 ? tid : (tid & 127);
+  const char* wsrc = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
   const size_t wstep = (size_t)p.cout_frags * 1024;
-  uint4 wreg[WCH];
-#pragma unroll
-  for (int k = 0; k < WCH; ++k)
-    if (tid + 256 * k < NF * 64) wreg[k] = *(const uint4*)(wsrc + k * 4096);
+  uint4 wreg0 = *(const uint4*)wsrc, wreg1 = make_uint4(0, 0, 0, 0);   // named scalars: an array here is demoted to scratch
+  if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
   wsrc += wstep;
 
   int it_w = 0;
   const int nsteps = p.nslab * p.ntaps;
+  auto ldhalo = [&](const char* src, int g, bool chvalid) -> uint4 {
+    const bool ok = g >= 0 && chvalid;
+    uint4 v = *(const uint4*)(src + (size_t)(ok ? g : 0) * sizeof(T));   // offset 0 is always readable
+    if (!ok) v = make_uint4(0, 0, 0, 0);
+    return v;
+  };
   for (int s = 0; s < p.nslab; ++s) {
     __syncthreads();  // every wave has finished reading the previous slab's halo
     {
       const bool chvalid = s * SLABC + ch * EPL < p.cin;
       const char* src = p.in + (size_t)s * SLABC * sizeof(T);
 #pragma unroll
-      for (int n0 = 0; n0 < NPAIR; n0 += 6) {
-        uint4 v[6];
+      for (int n0 = 0; n0 < NPAIR; n0 += 4) {
+        if (n0 * 64 >= p.P) break;
+        uint4 v[4];
 #pragma unroll
-        for (int n = 0; n < 6; ++n) {
-          v[n] = make_uint4(0, 0, 0, 0);
-          if (goff[n0 + n] >= 0 && chvalid) v[n] = *(const uint4*)(src + (size_t)goff[n0 + n] * sizeof(T));
-        }
+        for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, goff[n0 + n], chvalid);
 #pragma unroll
-        for (int n = 0; n < 6; ++n)
+        for (int n = 0; n < 4; ++n)
           if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
       }
     }
@@ -180,27 +184,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         int tapoff = tapoff_h;
         for (int dw = 0; dw < p.kw; ++dw, tapoff += 16) {
           char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
-#pragma unroll
-          for (int k = 0; k < WCH; ++k)
-            if (tid + 256 * k < NF * 64) *(uint4*)(wcur + tid * 16 + k * 4096) = wreg[k];
+          *(uint4*)(wcur + wchunk * 16) = wreg0;
+          if (WCH == 2) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
           ++it_w;
           if (it_w < nsteps) {
-#pragma unroll
-            for (int k = 0; k < WCH; ++k)
-              if (tid + 256 * k < NF * 64) wreg[k] = *(const uint4*)(wsrc + k * 4096);
+            wreg0 = *(const uint4*)wsrc;
+            if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
             wsrc += wstep;
           }
           __syncthreads();
           if (wave_active) {
-            frag bf[4];
+            frag bf[4], af[NF];
 #pragma unroll
             for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + rowpos[i] + tapoff);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
-              const frag af = *(const frag*)(wcur + (f * 64 + lane) * 16);
+            for (int f = 0; f < NF; ++f) af[f] = *(const frag*)(wcur + (f * 64 + lane) * 16);
+            __builtin_amdgcn_sched_barrier(0);   // keep every fragment read ahead of the MFMA chain (counted lgkmcnt waits)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) PR::mma(af, bf[i], acc[f][i]);
-            }
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
           }
         }
       }

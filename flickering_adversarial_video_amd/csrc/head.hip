@@ -20,20 +20,22 @@ template <typename T> __device__ static inline void stf(char* p, size_t i, float
 template <> __device__ inline void stf<float>(char* p, size_t i, float v) { ((float*)p)[i] = v; }
 template <> __device__ inline void stf<bf16_t>(char* p, size_t i, float v) { ((bf16_t*)p)[i] = (bf16_t)v; }
 
-// feat[b,c] = sum_pos wt[t(pos)] * y[b,pos,c]      grid (C/256, B)
+// feat[b,c] = sum_pos wt[t(pos)] * y[b,pos,c]      grid (C/64, B); 4 position groups x 64 channels per workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void head_pool_kernel(const char* y, int ld, int coff, int C, int Tn, int HW,
                                                         const float* wt, float* feat) {
-  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (c >= C) return;
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
   float acc = 0.f;
-  for (int t = 0; t < Tn; ++t) {
-    float s = 0.f;
-    const size_t base = ((size_t)(b * Tn + t) * HW) * ld + coff + c;
-    for (int i = 0; i < HW; ++i) s += ldf<T>(y, base + (size_t)i * ld);
-    acc += wt[t] * s;
+  if (c < C) {
+    const int npos = Tn * HW;
+    for (int i = grp; i < npos; i += 4)
+      acc += wt[i / HW] * ldf<T>(y, ((size_t)b * npos + i) * ld + coff + c);
   }
-  feat[(size_t)b * C + c] = acc;
+  part[grp][cl] = acc;
+  __syncthreads();
+  if (grp == 0 && c < C) feat[(size_t)b * C + c] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
 }
 
 // logits[b,n] = bias[n] + sum_c feat[b,c] * W[c,n]     grid (ceil(N/256), B)
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void head_pool_bwd_kernel(const char* y, int l
 int flk_head_forward(const void* y, int ld, int coff, int C, int B, int Tn, int HW, const float* wt, const float* W,
                      const float* bias, int N, float* feat, float* logits, int dtype, hipStream_t s) {
   FLK_REQUIRE(C <= 2048 && N <= 1024, "head: C<=2048, N<=1024 supported");
-  dim3 g1((C + 255) / 256, B);
+  dim3 g1((C + 63) / 64, B);
   if (dtype == FLK_BF16) hipLaunchKernelGGL(head_pool_kernel<bf16_t>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
   else hipLaunchKernelGGL(head_pool_kernel<float>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
   hipLaunchKernelGGL(head_fc_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, feat, W, bias, C, N, logits);

@@ -114,16 +114,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) g[e] = 0.f;
     if (p.add) PV<T>::ld(p.add + (ipos * p.gin_ld + p.gin_coff + cg * EPL) * sizeof(T), g);
-    int tap = 0;
-    for (int dt = 0; dt < p.kt; ++dt) {
-      const int nt = it + p.pt - dt;
-      for (int dh = 0; dh < p.kh; ++dh) {
-        const int nh = ih + p.ph - dh;
-        for (int dw = 0; dw < p.kw; ++dw, ++tap) {
-          const int nw = iw + p.pw - dw;
-          if (nt < 0 || nh < 0 || nw < 0 || nt % p.st || nh % p.sh || nw % p.sw) continue;
-          const int ot = nt / p.st, oh = nh / p.sh, ow = nw / p.sw;
-          if (ot >= p.To || oh >= p.Ho || ow >= p.Wo) continue;
+    // windows containing this cell: o in [ceil((i+p-k+1)/s), floor((i+p)/s)] per dim; its tap index d = i+p-o*s
+    const int ot_lo = max(0, (it + p.pt - p.kt + p.st) / p.st), ot_hi = min(p.To - 1, (it + p.pt) / p.st);
+    const int oh_lo = max(0, (ih + p.ph - p.kh + p.sh) / p.sh), oh_hi = min(p.Ho - 1, (ih + p.ph) / p.sh);
+    const int ow_lo = max(0, (iw + p.pw - p.kw + p.sw) / p.sw), ow_hi = min(p.Wo - 1, (iw + p.pw) / p.sw);
+    for (int ot = ot_lo; ot <= ot_hi; ++ot)
+      for (int oh = oh_lo; oh <= oh_hi; ++oh)
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+          const int tap = ((it + p.pt - ot * p.st) * p.kh + (ih + p.ph - oh * p.sh)) * p.kw + (iw + p.pw - ow * p.sw);
           const size_t opos = (((size_t)(b * p.To + ot) * p.Ho + oh) * p.Wo + ow);
           int id[EPL];
           PV<T>::ldidx(p.idx + opos * p.C + cg * EPL, id);
@@ -137,8 +135,6 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
           for (int e = 0; e < EPL; ++e)
             if (id[e] == tap) g[e] += go[e];
         }
-      }
-    }
     if (p.mask) {
       float mk[EPL];
       PV<T>::ld(p.mask + (ipos * p.mask_ld + p.mask_coff + cg * EPL) * sizeof(T), mk);
