@@ -13,7 +13,7 @@ adversarial gradient plus the loss scalars; the regulariser gradie
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, parallel
 from ._lib import FLK_NET_I3D
 
 NUM_CLASSES = 400          # kinetics_i3d_utils.py:19
@@ -48,8 +48,7 @@ class FlickerI3D:
         self.dense = dense_delta
         self.cyclic_flag, self.cyclic_pert_flag, self.adv_flag = cyclic_flag_default_c, cyclic_pert_flag_default_c, default_adv_flag_c
         self.pg = process_group
-        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
-        self.world = torch.distributed.get_world_size(process_group) if dist_on else 1
+        self.world = parallel.world_size(process_group)
         self.net = ops.Net(FLK_NET_I3D, dtype, self.B, self.T, self.H, self.W, weights, device)
         dev = torch.device("cuda", device)
         dshape = (self.T, self.H, self.W, 3) if dense_delta else (self.T, 3)
@@ -61,7 +60,7 @@ class FlickerI3D:
         self._gx = torch.empty_like(self._xs2d)
         self._logits = torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev)
         # [g_adv (T*3) | adv loss sum | sum to_min_prob | sum to_max_prob]: ONE all-reduce payload
-        self._red = torch.zeros(self.T * 3 + 3, dtype=torch.float32, device=dev)
+        self._red = torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev)
         self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4),
                                     dtype=torch.float32, device=dev)
         self._scalars = torch.empty(8, dtype=torch.float32, device=dev)
@@ -132,10 +131,11 @@ class FlickerI3D:
         self.net.backward(dl, self._gx)
         n = self.T * 3
         ops.perturb_grad_reduce(a, self._gx, self._red[:n].view(self.T, 3), self._scratch)
-        self._red[n:] = pc[:, :3].sum(0)
-        if self.world > 1:
-            torch.distributed.all_reduce(self._red, group=self.pg)      # RCCL over xGMI: (T*3+3) floats
-        res = StepResult(adv_loss=self._red[n].clone(), prob_to_min=self._red[n + 1] / gbatch, prob_to_max=self._red[n + 2] / gbatch,
+        parallel.pack_scalars(self._red, self.T, pc)
+        parallel.allreduce_sum_(self._red, self.pg)                    # RCCL over xGMI: (T*3+3) floats
+        _, adv_sum, p_lab, p_non = parallel.unpack(self._red, self.T, gbatch)
+        # to_min / to_max probabilities swap roles for targeted attacks (kinetics_i3d_utils.py:265-278)
+        res = StepResult(adv_loss=adv_sum.clone(), prob_to_min=p_non if targeted else p_lab, prob_to_max=p_lab if targeted else p_non,
                          softmax=sm, label_prob=pc[:, 1], argmax=pc[:, 3].to(torch.int64))
         res["is_adversarial"] = (res["argmax"] == labels).all() if targeted else (res["argmax"] != labels).all()
         if update:
@@ -156,18 +156,9 @@ class FlickerI3D:
     def evaluate(self, batches, targeted_attack=False, target_class_id=None, cyclic=0, exclude_misclassify=True):
         """kinetics_i3d.evaluate (kinetics_i3d_utils.py:217-250) over an iterable of (clip, labels) batches.
         Returns (miss_rate, total_valid) aggregated over all ranks."""
-        cnt = torch.zeros(2, dtype=torch.float64, device=self.eps_rgb.device)
+        cnt = parallel.FoolingCounter(self.eps_rgb.device)
         for x, y in batches:
             adv = self.logits(x, 1.0, cyclic).argmax(-1)
-            miss = (adv == target_class_id) if targeted_attack else (adv != y)
-            if exclude_misclassify:
-                valid = self.logits(x, 0.0, 0).argmax(-1) == y
-                cnt[0] += (miss & valid).sum()
-                cnt[1] += valid.sum()
-            else:
-                cnt[0] += miss.sum()
-                cnt[1] += miss.numel()
-        if self.world > 1:
-            torch.distributed.all_reduce(cnt, group=self.pg)
-        miss, total = cnt.tolist()
-        return (miss / total if total else float("nan")), int(total)
+            clean = self.logits(x, 0.0, 0).argmax(-1) if exclude_misclassify else None
+            cnt.update(adv, clean, y, targeted_attack, target_class_id, exclude_misclassify)
+        return cnt.result(self.pg)
