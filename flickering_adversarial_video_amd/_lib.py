@@ -28,7 +28,9 @@ class ConvArgs(C.Structure):
                 ("scale", C.c_void_p), ("bias", C.c_void_p),
                 ("add", C.c_void_p), ("add_ld", C.c_int), ("add_coff", C.c_int),
                 ("mask", C.c_void_p), ("mask_ld", C.c_int), ("mask_coff", C.c_int),
-                ("relu", C.c_int)]
+                ("relu", C.c_int),
+                ("in2", C.c_void_p), ("in2_ld", C.c_int), ("in2_coff", C.c_int), ("cin1", C.c_int),
+                ("out2", C.c_void_p), ("out2_ld", C.c_int), ("out2_coff", C.c_int), ("cout1", C.c_int)]
 
 
 class PoolArgs(C.Structure):
@@ -69,6 +71,8 @@ _SIGS = {
     "flk_last_error": (C.c_char_p, []),
     "flk_conv_weights_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "flk_conv_weights_create_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "flk_conv_weights_destroy": (C.c_int, [C.c_void_p]),
     "flk_conv3d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "flk_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolArgs), C.c_int, C.c_void_p]),

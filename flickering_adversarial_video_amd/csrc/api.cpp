@@ -24,7 +24,7 @@ static inline uint16_t f32_to_bf16_rne(float f) {
 }
 
 int flk_conv_weights_create_impl(const float* w, int kt, int kh, int kw, int cin, int cout,
-                                 const float* row_scale, int transpose, int dtype, int nf,
+                                 const float* row_scale, int transpose, int dtype, int nf, int cin_split,
                                  flk_conv_weights** out) {
   FLK_REQUIRE(w && out, "flk_conv_weights_create: null argument");
   FLK_REQUIRE(dtype == FLK_F32 || dtype == FLK_BF16, "flk_conv_weights_create: bad dtype %d", dtype);
@@ -34,7 +34,10 @@ int flk_conv_weights_create_impl(const float* w, int kt, int kh, int kw, int cin
   const int ocout = transpose ? cin : cout;   // operator output channels
   const int epl = dtype == FLK_BF16 ? 8 : 4, slabc = 4 * epl;
   const int ntaps = kt * kh * kw;
-  const int nslab = (ocin + slabc - 1) / slabc;
+  FLK_REQUIRE(cin_split >= 0 && cin_split < ocin && cin_split % 8 == 0 && !(cin_split && transpose),
+              "flk_conv_weights_create: bad cin_split %d", cin_split);
+  const int nslab1 = cin_split ? (cin_split + slabc - 1) / slabc : 0;
+  const int nslab = cin_split ? nslab1 + (ocin - cin_split + slabc - 1) / slabc : (ocin + slabc - 1) / slabc;
   const int cout_frags = (ocout + 16 * nf - 1) / (16 * nf) * nf;
   const size_t nelem = (size_t)nslab * ntaps * cout_frags * 64 * epl;
   const size_t bytes = nelem * (dtype == FLK_BF16 ? 2 : 4);
@@ -51,9 +54,14 @@ int flk_conv_weights_create_impl(const float* w, int kt, int kh, int kw, int cin
           const int q = lane >> 4, m = lane & 15;
           const int co = ntile * 16 * nf + (m >> 2) * 4 * nf + f * 4 + (m & 3);
           for (int j = 0; j < epl; ++j, ++o) {
-            const int ci = s * slabc + q * epl + j;
+            int ci = s * slabc + q * epl + j;          // position in the (segment-padded) K order -> channel
+            bool civalid = ci < ocin;
+            if (cin_split) {
+              if (s < nslab1) civalid = ci < cin_split;
+              else { ci = cin_split + (s - nslab1) * slabc + q * epl + j; civalid = ci < ocin; }
+            }
             float v = 0.f;
-            if (co < ocout && ci < ocin) {
+            if (co < ocout && civalid) {
               // original array is [tap][cin][cout]
               v = transpose ? w[((size_t)src_tap * cin + co) * cout + ci] : w[((size_t)src_tap * cin + ci) * cout + co];
               if (row_scale) v *= row_scale[ci];
@@ -67,7 +75,7 @@ int flk_conv_weights_create_impl(const float* w, int kt, int kh, int kw, int cin
   if (!cw) { flk_set_error("flk_conv_weights_create: out of host memory"); return FLK_ENOMEM; }
   cw->kt = kt; cw->kh = kh; cw->kw = kw; cw->cin = ocin; cw->cout = ocout;
   cw->dtype = dtype; cw->nf = nf; cw->nslab = nslab; cw->ntaps = ntaps; cw->cout_frags = cout_frags;
-  cw->bytes = bytes;
+  cw->bytes = bytes; cw->cin_split = cin_split; cw->nslab1 = cin_split ? nslab1 : nslab;
   hipError_t e = hipMalloc(&cw->dev, bytes);
   if (e != hipSuccess) { delete cw; flk_set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return FLK_ENOMEM; }
   e = hipMemcpy(cw->dev, host.data(), bytes, hipMemcpyHostToDevice);
@@ -79,7 +87,13 @@ int flk_conv_weights_create_impl(const float* w, int kt, int kh, int kw, int cin
 extern "C" int flk_conv_weights_create(const float* w, int kt, int kh, int kw, int cin, int cout,
                                        const float* row_scale, int transpose, int dtype, int nf,
                                        flk_conv_weights** out) {
-  return flk_conv_weights_create_impl(w, kt, kh, kw, cin, cout, row_scale, transpose, dtype, nf, out);
+  return flk_conv_weights_create_impl(w, kt, kh, kw, cin, cout, row_scale, transpose, dtype, nf, 0, out);
+}
+
+extern "C" int flk_conv_weights_create_split(const float* w, int kt, int kh, int kw, int cin, int cout,
+                                             const float* row_scale, int cin_split, int dtype, int nf,
+                                             flk_conv_weights** out) {
+  return flk_conv_weights_create_impl(w, kt, kh, kw, cin, cout, row_scale, 0, dtype, nf, cin_split, out);
 }
 
 extern "C" int flk_conv_weights_destroy(flk_conv_weights* w) {

@@ -21,7 +21,7 @@
 #include "flk_internal.h"
 
 struct ConvKP {
-  const char* in; const char* w; char* out;
+  const char* in; const char* in2; const char* w; char* out; char* out2;
   const float* scale; const float* bias; const char* add; const char* mask;
   int in_ld, in_coff, cin;
   int B, Ti, Hi, Wi;
@@ -33,6 +33,7 @@ struct ConvKP {
   int Tt, Ht, Wt, nTt, nTh, nTw, rows;
   int Th, Hh, Wh, P, plane_b;
   int nslab, ntaps, cout_frags;
+  int in2_ld, in2_coff, cin1, nslab1, out2_ld, out2_coff, cout1;
 };
 
 template <typename T> struct Prec;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 
   // ---- staging plan: pair n of this thread = (halo position (tid>>2) + 64 n, chunk tid&3) ----
   const int ch = tid & 3;
-  int goff[NPAIR];  // element offset of the chunk in `in`, -1 = zero fill, -2 = beyond the halo
+  int goff[NPAIR];  // linear input position of the pair, -1 = zero fill (padding), -2 = beyond the halo
   {
     const int HW = p.Hh * p.Wh;
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
         g = -1;
         if ((unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-          g = (((b * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.in_ld + p.in_coff + ch * EPL;
+          g = ((b * p.Ti + it) * p.Hi + ih) * p.Wi + iw;
       }
       goff[n] = g;
     }
@@ -155,23 +156,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 
   int it_w = 0;
   const int nsteps = p.nslab * p.ntaps;
-  auto ldhalo = [&](const char* src, int g, bool chvalid) -> uint4 {
+  // src = segment base + (coff + slab*SLABC + ch*EPL) elements; ld = that segment's channel stride
+  auto ldhalo = [&](const char* src, int ld, int g, bool chvalid) -> uint4 {
     const bool ok = g >= 0 && chvalid;
-    uint4 v = *(const uint4*)(src + (size_t)(ok ? g : 0) * sizeof(T));   // offset 0 is always readable
+    uint4 v = *(const uint4*)(src + (size_t)(ok ? g : 0) * ld * sizeof(T));   // position 0 is always readable
     if (!ok) v = make_uint4(0, 0, 0, 0);
     return v;
   };
+  // slab s -> (segment base pointer incl. channel offset, ld, chunk validity)
+  auto slab_src = [&](int s, const char*& src, int& ld) -> bool {
+    if (s < p.nslab1) {
+      src = p.in + (size_t)(p.in_coff + s * SLABC + ch * EPL) * sizeof(T); ld = p.in_ld;
+      return s * SLABC + ch * EPL < p.cin1;
+    }
+    const int s2 = s - p.nslab1;
+    src = p.in2 + (size_t)(p.in2_coff + s2 * SLABC + ch * EPL) * sizeof(T); ld = p.in2_ld;
+    return s2 * SLABC + ch * EPL < p.cin - p.cin1;
+  };
+  // Small halos (every 1x1x1 convolution, small tiles: P <= 256 -> 4 pairs per thread) are software-pipelined:
+  // slab s+1 is fetched into named registers while slab s computes, so the K loop does not expose one global-load
+  // latency per slab.  Larger halos are staged after the barrier (amortised over kt*kh*kw taps; the second resident
+  // workgroup covers the stall).
+  const bool small_halo = p.P <= 256;
+  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+  auto prefetch = [&](int s) {
+    const char* src; int ld;
+    const bool chvalid = slab_src(s, src, ld);
+    pre0 = ldhalo(src, ld, goff[0], chvalid); pre1 = ldhalo(src, ld, goff[1], chvalid);
+    pre2 = ldhalo(src, ld, goff[2], chvalid); pre3 = ldhalo(src, ld, goff[3], chvalid);
+  };
+  if (small_halo) prefetch(0);
   for (int s = 0; s < p.nslab; ++s) {
     __syncthreads();  // every wave has finished reading the previous slab's halo
-    {
-      const bool chvalid = s * SLABC + ch * EPL < p.cin;
-      const char* src = p.in + (size_t)s * SLABC * sizeof(T);
+    if (small_halo) {
+      if (goff[0] != -2) *(uint4*)(hdst) = pre0;
+      if (goff[1] != -2) *(uint4*)(hdst + 1024) = pre1;
+      if (goff[2] != -2) *(uint4*)(hdst + 2048) = pre2;
+      if (goff[3] != -2) *(uint4*)(hdst + 3072) = pre3;
+      if (s + 1 < p.nslab) prefetch(s + 1);
+    } else {
+      const char* src; int ld;
+      const bool chvalid = slab_src(s, src, ld);
 #pragma unroll
       for (int n0 = 0; n0 < NPAIR; n0 += 4) {
         if (n0 * 64 >= p.P) break;
         uint4 v[4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, goff[n0 + n], chvalid);
+        for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
           if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
@@ -261,7 +292,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
       }
-      *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c0) * sizeof(T)) = PR::from_f32(v);
+      if (c0 < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c0) * sizeof(T)) = PR::from_f32(v);
+      else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c0 - p.cout1)) * sizeof(T)) = PR::from_f32(v);
     }
   }
 }
@@ -316,7 +348,7 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
               "flk_conv3d: channel counts / strides / offsets must be multiples of 8");
   FLK_REQUIRE(!a->add || (a->add_ld % 8 == 0 && a->add_coff % 8 == 0), "flk_conv3d: add ld/coff % 8");
   FLK_REQUIRE(!a->mask || (a->mask_ld % 8 == 0 && a->mask_coff % 8 == 0), "flk_conv3d: mask ld/coff % 8");
-  FLK_REQUIRE(a->in_coff + a->cin <= a->in_ld && a->out_coff + a->cout <= a->out_ld, "flk_conv3d: slice exceeds ld");
+  FLK_REQUIRE((a->in2 || a->in_coff + a->cin <= a->in_ld) && (a->out2 || a->out_coff + a->cout <= a->out_ld), "flk_conv3d: slice exceeds ld");
   FLK_REQUIRE(a->B > 0 && a->To > 0 && a->Ho > 0 && a->Wo > 0 && a->st > 0 && a->sh > 0 && a->sw > 0 &&
                   a->ost > 0 && a->osh > 0 && a->osw > 0, "flk_conv3d: bad dims");
   FLK_REQUIRE((a->To - 1) * a->ost + a->oot < a->OT && (a->Ho - 1) * a->osh + a->ooh < a->OH &&
@@ -349,6 +381,25 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   FLK_REQUIRE(kp.P <= FLK_MAX_HALO && kp.rows <= FLK_ROWS, "flk_conv3d: no tile fits (halo %d)", kp.P);
   kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
   kp.nslab = w->nslab; kp.ntaps = w->ntaps; kp.cout_frags = w->cout_frags;
+  if (a->in2) {
+    FLK_REQUIRE(w->cin_split == a->cin1 && a->cin1 > 0 && a->cin1 < a->cin, "flk_conv3d: in2 given but weights were packed with "
+                "cin_split %d (args cin1 %d)", w->cin_split, a->cin1);
+    FLK_REQUIRE(a->in2_ld % 8 == 0 && a->in2_coff % 8 == 0 && a->in2_coff + a->cin - a->cin1 <= a->in2_ld &&
+                    a->in_coff + a->cin1 <= a->in_ld, "flk_conv3d: bad in2 slice");
+    kp.in2 = (const char*)a->in2; kp.in2_ld = a->in2_ld; kp.in2_coff = a->in2_coff; kp.cin1 = a->cin1; kp.nslab1 = w->nslab1;
+  } else {
+    FLK_REQUIRE(w->cin_split == 0, "flk_conv3d: weights packed for two input segments but in2 is NULL");
+    kp.in2 = kp.in; kp.in2_ld = a->in_ld; kp.in2_coff = a->in_coff; kp.cin1 = a->cin; kp.nslab1 = w->nslab;
+  }
+  if (a->out2) {
+    FLK_REQUIRE(a->cout1 > 0 && a->cout1 < a->cout && a->cout1 % 8 == 0 && a->out2_ld % 8 == 0 && a->out2_coff % 8 == 0 &&
+                    a->out2_coff + a->cout - a->cout1 <= a->out2_ld && a->out_coff + a->cout1 <= a->out_ld,
+                "flk_conv3d: bad out2 slice");
+    FLK_REQUIRE(!a->add && !a->mask, "flk_conv3d: out2 cannot be combined with add / mask");
+    kp.out2 = (char*)a->out2; kp.out2_ld = a->out2_ld; kp.out2_coff = a->out2_coff; kp.cout1 = a->cout1;
+  } else {
+    kp.out2 = kp.out; kp.cout1 = a->cout;
+  }
   const int nf = w->nf;
   const size_t lds = 4 * (size_t)kp.plane_b + 64 + 2 * (size_t)nf * 1024;
   const long gx = (long)a->B * kp.nTt * kp.nTh * kp.nTw;

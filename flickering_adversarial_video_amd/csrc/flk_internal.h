@@ -43,11 +43,12 @@ struct flk_conv_weights {
   void* dev = nullptr;
   int kt = 0, kh = 0, kw = 0, cin = 0, cout = 0;   // of THIS operator (after optional transpose)
   int dtype = 0, nf = 0, nslab = 0, ntaps = 0, cout_frags = 0;
+  int cin_split = 0, nslab1 = 0;   // two-segment K order: slabs [0,nslab1) = channels [0,cin_split)
   size_t bytes = 0;
 };
 
 int flk_conv_weights_create_impl(const float* w_dhwio, int kt, int kh, int kw, int cin, int cout,
-                                 const float* row_scale, int transpose, int dtype, int nf,
+                                 const float* row_scale, int transpose, int dtype, int nf, int cin_split,
                                  flk_conv_weights** out);
 
 // choose the (Tt,Ht,Wt) tile for a logical output grid; returns rows used (<=256)

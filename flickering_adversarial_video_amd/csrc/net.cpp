@@ -153,10 +153,10 @@ struct flk_net {
   int pack(ConvLayer* L) {
     const int taps = L->kt * L->kh * L->kw;
     int rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, nullptr, 0, dtype,
-                                          choose_nf(L->cout, taps), &L->wf);
+                                          choose_nf(L->cout, taps), 0, &L->wf);
     if (rc) return rc;
     rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, L->scale.data(), 1, dtype,
-                                      choose_nf(L->cin, taps), &L->wb);
+                                      choose_nf(L->cin, taps), 0, &L->wb);
     if (rc) return rc;
     if ((rc = upload(&L->d_scale, L->scale))) return rc;
     if ((rc = upload(&L->d_bias, L->bias))) return rc;
@@ -367,10 +367,38 @@ int flk_net::build_i3d() {
     const int cout_total = c0 + c1b + c2b_ + c3;
     ConvLayer *L0, *L1a, *L1b, *L2a, *L2b, *L3;
     const std::string b2name = bn == "Mixed_5b" ? "Conv3d_0a_3x3" : "Conv3d_0b_3x3";   // i3d.py:418
-    if ((rc = make_unit3d(bn + "/Branch_0/Conv3d_0a_1x1", 1, 1, 1, cur_c, c0, &L0)) || (rc = pack(L0))) return rc;
-    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0a_1x1", 1, 1, 1, cur_c, c1a, &L1a)) || (rc = pack(L1a))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_0/Conv3d_0a_1x1", 1, 1, 1, cur_c, c0, &L0))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0a_1x1", 1, 1, 1, cur_c, c1a, &L1a))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0b_3x3", 3, 3, 3, c1a, c1b, &L1b)) || (rc = pack(L1b))) return rc;
-    if ((rc = make_unit3d(bn + "/Branch_2/Conv3d_0a_1x1", 1, 1, 1, cur_c, c2a, &L2a)) || (rc = pack(L2a))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_2/Conv3d_0a_1x1", 1, 1, 1, cur_c, c2a, &L2a))) return rc;
+    // The three 1x1x1 units reading the block input (i3d.py:197-207) run as ONE GEMM [b0 | b1a | b2a]: one launch, the
+    // input read once; columns [0,c0) land in the concat buffer, the rest in `mid`.  Its data-gradient is one GEMM too,
+    // with K gathered from the two gradient buffers.
+    ConvLayer* Lf = nullptr;
+    {
+      const int cf = c0 + c1a + c2a;
+      auto L = std::make_unique<ConvLayer>();
+      L->name = bn + "/Branch_0+1+2/Conv3d_0a_1x1"; L->kt = L->kh = L->kw = 1; L->cin = cur_c; L->cout = cf;
+      L->w.resize((size_t)cur_c * cf);
+      for (int ci = 0; ci < cur_c; ++ci) {
+        float* d = &L->w[(size_t)ci * cf];
+        memcpy(d, &L0->w[(size_t)ci * c0], c0 * sizeof(float));
+        memcpy(d + c0, &L1a->w[(size_t)ci * c1a], c1a * sizeof(float));
+        memcpy(d + c0 + c1a, &L2a->w[(size_t)ci * c2a], c2a * sizeof(float));
+      }
+      for (ConvLayer* q : {L0, L1a, L2a}) {
+        L->scale.insert(L->scale.end(), q->scale.begin(), q->scale.end());
+        L->bias.insert(L->bias.end(), q->bias.begin(), q->bias.end());
+      }
+      std::vector<float> wT((size_t)cf * cur_c);
+      for (int ci = 0; ci < cur_c; ++ci)
+        for (int k = 0; k < cf; ++k) wT[(size_t)k * cur_c + ci] = L->w[(size_t)ci * cf + k];
+      if ((rc = flk_conv_weights_create_impl(L->w.data(), 1, 1, 1, cur_c, cf, nullptr, 0, dtype, choose_nf(cf, 1), 0, &L->wf))) return rc;
+      if ((rc = flk_conv_weights_create_impl(wT.data(), 1, 1, 1, cf, cur_c, L->scale.data(), 0, dtype, choose_nf(cur_c, 1), c0, &L->wb))) return rc;
+      if ((rc = upload(&L->d_scale, L->scale)) || (rc = upload(&L->d_bias, L->bias))) return rc;
+      Lf = L.get();
+      convs.push_back(std::move(L));
+    }
     if ((rc = make_unit3d(bn + "/Branch_2/" + b2name, 3, 3, 3, c2a, c2b_, &L2b)) || (rc = pack(L2b))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_3/Conv3d_0b_1x1", 1, 1, 1, cur_c, c3, &L3)) || (rc = pack(L3))) return rc;
     Act out, Gout, mid, Gmid, pl, Gpl, gxa;
@@ -379,10 +407,20 @@ int flk_net::build_i3d() {
     if ((rc = new_act(Gpl, cur.T, cur.H, cur.W, cur_c)) || (rc = new_act(gxa, cur.T, cur.H, cur.W, cur_c))) return rc;
     PoolRec pr3;
     // forward: [b0 | b1 | b2 | b3] slices of `out` (tf.concat axis 4, i3d.py:219)
-    emit_conv_fwd(L0, cur, 0, out, 0);
-    emit_conv_fwd(L1a, cur, 0, mid, 0);
+    {
+      flk_conv_args a{};
+      a.in = cur.p; a.in_ld = cur.ld; a.cin = cur_c; a.B = B; a.Ti = cur.T; a.Hi = cur.H; a.Wi = cur.W;
+      a.kt = a.kh = a.kw = 1; a.st = a.sh = a.sw = 1;
+      a.To = cur.T; a.Ho = cur.H; a.Wo = cur.W; a.OT = cur.T; a.OH = cur.H; a.OW = cur.W; a.ost = a.osh = a.osw = 1;
+      a.out = out.p; a.out_ld = out.ld; a.out_coff = 0; a.cout = c0 + c1a + c2a;
+      a.out2 = mid.p; a.out2_ld = mid.ld; a.out2_coff = 0; a.cout1 = c0;
+      a.scale = Lf->d_scale; a.bias = Lf->d_bias; a.relu = 1;
+      const double macs = (double)B * cur.T * cur.H * cur.W * cur_c * (c0 + c1a + c2a);
+      flk_conv_weights* wf = Lf->wf;
+      const int dt = dtype;
+      fwd.push_back(Op{Lf->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
+    }
     emit_conv_fwd(L1b, mid, 0, out, c0);
-    emit_conv_fwd(L2a, cur, 0, mid, c1a);
     emit_conv_fwd(L2b, mid, c1a, out, c0 + c1b);
     if ((rc = emit_pool_fwd(bn + "/Branch_3/MaxPool3d_0a_3x3", cur, cur_c, 3, 3, 3, 1, 1, 1, pl, pr3))) return rc;
     emit_conv_fwd(L3, pl, 0, out, c0 + c1b + c2b_);
@@ -399,9 +437,21 @@ int flk_net::build_i3d() {
       emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
       emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a);
       emit_conv_bwd(L1b, Gout, c0, Gmid, 0, nullptr, 0, 0, &mid, 0);
-      emit_conv_bwd(L0, Gout, 0, Gin, 0, gxa.p, gxa.ld, 0, nullptr, 0);
-      emit_conv_bwd(L1a, Gmid, 0, Gin, 0, Gin.p, Gin.ld, 0, nullptr, 0);
-      emit_conv_bwd(L2a, Gmid, c1a, Gin, 0, Gin.p, Gin.ld, 0, in_relu ? &in_act : nullptr, 0);
+      {
+        flk_conv_args a{};
+        a.in = Gout.p; a.in_ld = Gout.ld; a.in_coff = 0; a.cin = c0 + c1a + c2a; a.cin1 = c0;
+        a.in2 = Gmid.p; a.in2_ld = Gmid.ld; a.in2_coff = 0;
+        a.B = B; a.Ti = Gout.T; a.Hi = Gout.H; a.Wi = Gout.W;
+        a.kt = a.kh = a.kw = 1; a.st = a.sh = a.sw = 1;
+        a.To = Gin.T; a.Ho = Gin.H; a.Wo = Gin.W; a.OT = Gin.T; a.OH = Gin.H; a.OW = Gin.W; a.ost = a.osh = a.osw = 1;
+        a.out = Gin.p; a.out_ld = Gin.ld; a.out_coff = 0; a.cout = Lf->cin;
+        a.add = gxa.p; a.add_ld = gxa.ld; a.add_coff = 0;
+        if (in_relu) { a.mask = in_act.p; a.mask_ld = in_act.ld; a.mask_coff = 0; }
+        const double macs = (double)B * Gin.T * Gin.H * Gin.W * Lf->cin * (c0 + c1a + c2a);
+        flk_conv_weights* wb = Lf->wb;
+        const int dt = dtype;
+        bwd.push_back(Op{Lf->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
+      }
     });
     cur = out; Gcur = Gout; cur_c = cout_total; cur_is_relu = true;
   }

@@ -145,6 +145,177 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled variants for stride-1 SAME pooling with an odd window (the Inception branch-3 pool, i3d.py:212):
+// every cell is touched by kt*kh*kw windows, so the simple kernels above read each byte 27x through L1/L2.
+// Here a workgroup stages the halo box of ONE 64-byte channel slab once (same 4-plane LDS image as
+// conv_igemm.hip) and all window taps are LDS reads.
+struct PoolTP {
+  PoolKP k;
+  int Tt, Ht, Wt, nTt, nTh, nTw, Th, Hh, Wh, P, plane_b, rows;
+};
+
+__device__ static inline int pplane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd(const PoolTP p) {
+  constexpr int EPL = PV<T>::EPL, SLABC = 4 * EPL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const PoolKP& k = p.k;
+  const int tid = threadIdx.x, ch = tid & 3;
+  int bid = blockIdx.x;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const bool chvalid = c0 < k.C;
+  const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * p.Wt;
+  const int it0 = ot0 - k.pt, ih0 = oh0 - k.ph, iw0 = ow0 - k.pw;
+  const int HW = p.Hh * p.Wh;
+  // stage the halo (-inf outside the tensor: padded cells never win)
+  for (int hp = tid >> 2; hp < p.P; hp += 64) {
+    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+    const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
+    float v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = -INFINITY;
+    if (chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi)
+      PV<T>::ld(k.in + ((((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw) * k.in_ld + k.in_coff + c0) * sizeof(T), v);
+    PV<T>::st(smem + pplane_off(ch, p.plane_b) + hp * 16, v);
+  }
+  __syncthreads();
+  if (!chvalid) return;
+  const int hw = p.Ht * p.Wt;
+  for (int r = tid >> 2; r < p.rows; r += 64) {
+    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
+    if (ot >= k.To || oh >= k.Ho || ow >= k.Wo) continue;
+    const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * p.Wh + rw) * 16;
+    float best[EPL];
+    int bi[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    int tap = 0;
+    for (int dt = 0; dt < k.kt; ++dt)
+      for (int dh = 0; dh < k.kh; ++dh)
+        for (int dw = 0; dw < k.kw; ++dw, ++tap) {
+          float v[EPL];
+          PV<T>::ld(base + ((dt * p.Hh + dh) * p.Wh + dw) * 16, v);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e)
+            if (v[e] > best[e]) { best[e] = v[e]; bi[e] = tap; }
+        }
+    const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+    PV<T>::st(k.out + (opos * k.out_ld + k.out_coff + c0) * sizeof(T), best);
+    PV<T>::stidx(k.idx + opos * k.C + c0, bi);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_bwd(const PoolTP p) {
+  constexpr int EPL = PV<T>::EPL, SLABC = 4 * EPL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const PoolKP& k = p.k;
+  char* const sidx = smem + 4 * p.plane_b + 64;            // [chunk][halo position][EPL bytes]
+  const int tid = threadIdx.x, ch = tid & 3;
+  int bid = blockIdx.x;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const bool chvalid = c0 < k.C;
+  // tile of INPUT cells [i0, i0+tile); windows o with o - pad <= i <= o - pad + k-1  ->  o in [i - (k-1-pad), i + pad]
+  const int i_t0 = tt * p.Tt, i_h0 = th * p.Ht, i_w0 = tw * p.Wt;
+  const int o_t0 = i_t0 - (k.kt - 1 - k.pt), o_h0 = i_h0 - (k.kh - 1 - k.ph), o_w0 = i_w0 - (k.kw - 1 - k.pw);
+  const int HW = p.Hh * p.Wh;
+  for (int hp = tid >> 2; hp < p.P; hp += 64) {
+    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+    const int ot = o_t0 + a, oh = o_h0 + bq, ow = o_w0 + c;
+    uint4 g = make_uint4(0, 0, 0, 0);
+    int id[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) id[e] = 255;                // never matches a tap
+    if (chvalid && (unsigned)ot < (unsigned)k.To && (unsigned)oh < (unsigned)k.Ho && (unsigned)ow < (unsigned)k.Wo) {
+      const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+      g = *(const uint4*)(k.gout + (opos * k.gout_ld + k.gout_coff + c0) * sizeof(T));
+      PV<T>::ldidx(k.idx + opos * k.C + c0, id);
+    }
+    *(uint4*)(smem + pplane_off(ch, p.plane_b) + hp * 16) = g;
+    PV<T>::stidx((uint8_t*)sidx + ((size_t)ch * p.P + hp) * EPL, id);
+  }
+  __syncthreads();
+  if (!chvalid) return;
+  const int hw = p.Ht * p.Wt;
+  for (int r = tid >> 2; r < p.rows; r += 64) {
+    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
+    if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
+    float g[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) g[e] = 0.f;
+    // halo offset e (per dim) holds window o = o0 + local + e; this cell is its tap d = i - (o - pad) = k-1-e
+    for (int et = 0; et < k.kt; ++et)
+      for (int eh = 0; eh < k.kh; ++eh)
+        for (int ew = 0; ew < k.kw; ++ew) {
+          const int hp = ((rt + et) * p.Hh + rh + eh) * p.Wh + rw + ew;
+          const int tap = ((k.kt - 1 - et) * k.kh + (k.kh - 1 - eh)) * k.kw + (k.kw - 1 - ew);
+          int id[EPL];
+          PV<T>::ldidx((const uint8_t*)sidx + ((size_t)ch * p.P + hp) * EPL, id);
+          bool any = false;
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) any |= id[e] == tap;
+          if (!any) continue;
+          float go[EPL];
+          PV<T>::ld(smem + pplane_off(ch, p.plane_b) + hp * 16, go);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e)
+            if (id[e] == tap) g[e] += go[e];
+        }
+    const size_t ipos = (((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw);
+    if (k.mask) {
+      float mk[EPL];
+      PV<T>::ld(k.mask + (ipos * k.mask_ld + k.mask_coff + c0) * sizeof(T), mk);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) g[e] = mk[e] > 0.f ? g[e] : 0.f;
+    }
+    PV<T>::st(k.gin + (ipos * k.gin_ld + k.gin_coff + c0) * sizeof(T), g);
+  }
+}
+
+// stride-1 SAME pooling with an odd window and enough reuse to pay for the LDS staging
+static bool use_tiled(const flk_pool_args* a) {
+  return a->st == 1 && a->sh == 1 && a->sw == 1 && a->kt * a->kh * a->kw >= 8 && a->To == a->Ti && a->Ho == a->Hi &&
+         a->Wo == a->Wi && a->pt < a->kt && a->ph < a->kh && a->pw < a->kw;
+}
+
+template <typename T>
+static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipStream_t s) {
+  PoolTP tp{};
+  tp.k = kp;
+  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, 1, 1, 1);
+  tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
+  tp.nTt = (a->To + t.Tt - 1) / t.Tt; tp.nTh = (a->Ho + t.Ht - 1) / t.Ht; tp.nTw = (a->Wo + t.Wt - 1) / t.Wt;
+  tp.Th = t.Tt + a->kt - 1; tp.Hh = t.Ht + a->kh - 1; tp.Wh = t.Wt + a->kw - 1;
+  tp.P = tp.Th * tp.Hh * tp.Wh;
+  FLK_REQUIRE(tp.P <= FLK_MAX_HALO, "maxpool tiled: halo %d too large", tp.P);
+  tp.plane_b = (tp.P * 16 + 255) / 256 * 256;
+  constexpr int EPL = PV<T>::EPL;
+  const size_t lds = 4 * (size_t)tp.plane_b + 64 + (bwd ? (size_t)4 * tp.P * EPL + 16 : 0);
+  dim3 grid((unsigned)((long)a->B * tp.nTt * tp.nTh * tp.nTw), (unsigned)((a->C + 4 * EPL - 1) / (4 * EPL)));
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
+  else hipLaunchKernelGGL(maxpool_s1_tiled_fwd<T>, grid, dim3(256), lds, s, tp);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
 static int check_pool(const flk_pool_args* a) {
   FLK_REQUIRE(a && a->in && a->idx, "flk_maxpool3d: null argument");
   FLK_REQUIRE(a->C % 8 == 0 && a->in_ld % 8 == 0 && a->in_coff % 8 == 0 && a->out_ld % 8 == 0 && a->out_coff % 8 == 0,
@@ -177,6 +348,8 @@ extern "C" int flk_maxpool3d_fwd(const flk_pool_args* a, int dtype, void* stream
   FLK_REQUIRE(a->out, "flk_maxpool3d_fwd: null out");
   PoolKP kp{};
   fill(kp, a);
+  FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_maxpool3d_fwd: bad dtype");
+  if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, false, (hipStream_t)stream) : launch_tiled<float>(kp, a, false, (hipStream_t)stream);
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   const long total = (long)a->B * a->To * a->Ho * a->Wo * (a->C / epl);
   if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, kp);
@@ -200,6 +373,8 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
   kp.gin = (char*)gin; kp.gin_ld = gin_ld; kp.gin_coff = gin_coff;
   kp.mask = (const char*)mask; kp.mask_ld = mask_ld; kp.mask_coff = mask_coff;
   kp.add = nullptr;
+  FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_maxpool3d_bwd: bad dtype");
+  if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, true, (hipStream_t)stream) : launch_tiled<float>(kp, a, true, (hipStream_t)stream);
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   const long total = (long)a->B * a->Ti * a->Hi * a->Wi * (a->C / epl);
   if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, kp);

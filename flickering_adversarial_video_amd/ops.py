@@ -21,7 +21,7 @@ def same_pad(n, k, s):
 class ConvWeights:
     """Packed weights of one convolution operator (flk_conv_weights)."""
 
-    def __init__(self, w_dhwio, dtype, nf, row_scale=None, transpose=False):
+    def __init__(self, w_dhwio, dtype, nf, row_scale=None, transpose=False, cin_split=0):
         w = np.ascontiguousarray(w_dhwio, dtype=np.float32)
         assert w.ndim == 5
         self.kt, self.kh, self.kw, cin, cout = w.shape
@@ -29,8 +29,14 @@ class ConvWeights:
         self.dtype, self.nf = dtype_code(dtype), nf
         rs = None if row_scale is None else np.ascontiguousarray(row_scale, dtype=np.float32)
         h = C.c_void_p()
-        check(load().flk_conv_weights_create(ptr(w), self.kt, self.kh, self.kw, cin, cout, ptr(rs), int(transpose),
-                                             self.dtype, nf, C.byref(h)))
+        if cin_split:
+            assert not transpose
+            check(load().flk_conv_weights_create_split(ptr(w), self.kt, self.kh, self.kw, cin, cout, ptr(rs), cin_split,
+                                                       self.dtype, nf, C.byref(h)))
+        else:
+            check(load().flk_conv_weights_create(ptr(w), self.kt, self.kh, self.kw, cin, cout, ptr(rs), int(transpose),
+                                                 self.dtype, nf, C.byref(h)))
+        self.cin_split = cin_split
         self.handle = h
 
     def __del__(self):
@@ -44,7 +50,7 @@ class ConvWeights:
 
 def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
            out_stride=(1, 1, 1), out_offset=(0, 0, 0), scale=None, bias=None, add=None, add_coff=0, mask=None,
-           mask_coff=0, relu=False):
+           mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0):
     """x: [B,T,H,W,ld] channels-last; returns / fills out [B,OT,OH,OW,ld_out].  pad = pad-before per dim
     (default: TF SAME).  out_grid = logical output grid (default: SAME output size)."""
     B, Ti, Hi, Wi, in_ld = x.shape
@@ -74,6 +80,10 @@ def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, o
     if mask is not None:
         a.mask, a.mask_ld, a.mask_coff = ptr(mask), mask.shape[4], mask_coff
     a.relu = int(relu)
+    if in2 is not None:
+        a.in2, a.in2_ld, a.in2_coff, a.cin1 = ptr(in2), in2.shape[4], in2_coff, w.cin_split
+    if out2 is not None:
+        a.out2, a.out2_ld, a.out2_coff, a.cout1 = ptr(out2), out2.shape[4], out2_coff, cout1
     check(load().flk_conv3d(C.byref(a), w.handle, dtype_code(x.dtype), stream_ptr()))
     return out
 

@@ -51,6 +51,12 @@ typedef struct flk_conv_weights flk_conv_weights;
 int flk_conv_weights_create(const float* w_dhwio, int kt, int kh, int kw, int cin, int cout,
                             const float* row_scale, int transpose, int dtype, int nf,
                             flk_conv_weights** out);
+/* Same, for an operator whose INPUT channels come from two tensors (flk_conv_args.in / .in2): channels [0,cin_split)
+ * and [cin_split,cin) are each padded to a whole 64-byte slab in the packed K order.  w_dhwio is the plain
+ * [kt][kh][kw][cin][cout] array (no transpose option: build the data-gradient operator explicitly). */
+int flk_conv_weights_create_split(const float* w_dhwio, int kt, int kh, int kw, int cin, int cout,
+                                  const float* row_scale, int cin_split, int dtype, int nf,
+                                  flk_conv_weights** out);
 int flk_conv_weights_destroy(flk_conv_weights* w);
 
 /* Generic 3-D convolution as implicit GEMM on MFMA, LDS-staged T x H x W halo tiles.
@@ -76,6 +82,12 @@ typedef struct {
   const void* add; int add_ld, add_coff;       /* NULL or tensor with the physical output geometry */
   const void* mask; int mask_ld, mask_coff;    /* NULL or tensor with the physical output geometry */
   int relu;
+  /* optional second segments (fused Inception 1x1x1 convolutions: i3d.py:197-207 share one input):
+   * in2 != NULL : input channels [cin1, cin) are read from in2[:, in2_coff + (c - cin1)] (weights packed with
+   *               flk_conv_weights_create_split(cin_split = cin1));
+   * out2 != NULL: output channels [cout1, cout) are written to out2[:, out2_coff + (n - cout1)] (cout1 % 8 == 0). */
+  const void* in2; int in2_ld, in2_coff, cin1;
+  void* out2; int out2_ld, out2_coff, cout1;
 } flk_conv_args;
 int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream);
 

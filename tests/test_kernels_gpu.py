@@ -132,7 +132,9 @@ def test_conv_data_gradient(ops, dtype, k, cin, cout, nf):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("k,s,dims", [((1, 3, 3), (1, 2, 2), (4, 28, 28)), ((3, 3, 3), (2, 2, 2), (8, 14, 14)),
                                       ((2, 2, 2), (2, 2, 2), (4, 14, 14)), ((3, 3, 3), (1, 1, 1), (3, 7, 7)),
-                                      ((3, 3, 3), (2, 2, 2), (5, 7, 9))], ids=["2a", "4a", "5a", "branch3", "odd"])
+                                      ((3, 3, 3), (2, 2, 2), (5, 7, 9)), ((3, 3, 3), (1, 1, 1), (5, 13, 30)),
+                                      ((1, 3, 3), (1, 1, 1), (3, 9, 9))],
+                         ids=["2a", "4a", "5a", "branch3", "odd", "branch3_ragged_tiles", "1x3x3_s1"])
 def test_maxpool_fwd_bwd(ops, dtype, k, s, dims):
     B, C_ = 2, 24
     T, H, W = dims
@@ -248,3 +250,33 @@ def test_inception_block_forward_backward(ops, dtype, blk):
     # -> isolated O(1) differences on that unit's receptive field; everything else must agree tightly
     bad = ((Gin.float().cpu() - gx_ref).abs() > a * 4 + r * 4 * gx_ref.abs()).float().mean().item()
     assert bad < (0.01 if dtype == torch.float32 else 0.03), bad
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv_two_segment_output_and_input(ops, dtype):
+    """fused Inception 1x1x1 convolutions: one GEMM writing [b0 | b1a+b2a] into two buffers (out/out2), and its
+    data-gradient reading K from two gradient buffers (in/in2, each segment padded to a slab in the packed weights)"""
+    B, T, H, W, cin = 2, 3, 7, 9, 72
+    c0, c1 = 112, 40                     # 112 is not a multiple of the bf16 slab (32): exercises the segment padding
+    x = q(rnd((B, T, H, W, cin), 31), dtype)
+    w = q(rnd((1, 1, 1, cin, c0 + c1), 32, 0.1), dtype)
+    sc, bi = rnd((c0 + c1,), 33).abs() + 0.5, rnd((c0 + c1,), 34) * 0.1
+    ref = torch.relu(ref_conv(x, w, (1, 1, 1), (0, 0, 0), (T, H, W)) * sc + bi)
+    outA = torch.full((B, T, H, W, c0 + 16), 3.0, dtype=dtype).cuda()       # segment 1 at coff 8
+    outB = torch.full((B, T, H, W, c1 + 8), 3.0, dtype=dtype).cuda()        # segment 2 at coff 8
+    pw = ops.ConvWeights(w.numpy(), dtype, 8)
+    ops.conv3d(x.to(dtype).cuda(), pw, out=outA, out_coff=8, out2=outB, out2_coff=8, cout1=c0, scale=sc.cuda(), bias=bi.cuda(), relu=True)
+    r, a = tol(dtype, ref)
+    torch.testing.assert_close(outA.float().cpu()[..., 8:8 + c0], ref[..., :c0], rtol=r, atol=a)
+    torch.testing.assert_close(outB.float().cpu()[..., 8:], ref[..., c0:], rtol=r, atol=a)
+    assert (outA.float().cpu()[..., :8] == 3).all() and (outA.float().cpu()[..., 8 + c0:] == 3).all() and (outB.float().cpu()[..., :8] == 3).all()
+    # data gradient: gx = [gA | gB] . (a * W)^T
+    gA, gB = q(rnd((B, T, H, W, c0 + 8), 35), dtype), q(rnd((B, T, H, W, c1), 36), dtype)
+    g = torch.cat([gA[..., 8:], gB], -1)
+    xr = torch.zeros((B, T, H, W, cin), requires_grad=True)
+    (gx_ref,) = torch.autograd.grad(ref_conv(xr, w, (1, 1, 1), (0, 0, 0), (T, H, W)) * sc, xr, g)
+    wT = w[0, 0, 0].t().contiguous().reshape(1, 1, 1, c0 + c1, cin)
+    pb = ops.ConvWeights(wT.numpy(), dtype, 4, row_scale=sc.numpy(), cin_split=c0)
+    gx = ops.conv3d(gA.to(dtype).cuda(), pb, in_coff=8, cin=c0 + c1, in2=gB.to(dtype).cuda(), in2_coff=0)
+    r, a = tol(dtype, gx_ref)
+    torch.testing.assert_close(gx.float().cpu(), gx_ref, rtol=r * 2, atol=a * 2)
