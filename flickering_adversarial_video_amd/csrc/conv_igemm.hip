@@ -18,6 +18,7 @@
 //     so an accumulator lane owns ONE position and 4*NF consecutive channels -> 16-byte epilogue
 //     accesses for scale/bias/add/mask and stores.
 //   * bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32, parity mode).
+#include <stdlib.h>
 #include "flk_internal.h"
 
 struct ConvKP {
@@ -78,19 +79,25 @@ __device__ static inline int plane_off(int c, int plane_b) { return c * plane_b 
 
 constexpr int NPAIR = FLK_MAX_HALO * 4 / 256;  // (position, chunk) pairs staged per thread
 
-template <typename T, int NF>
+// WN = waves along N: the 4 waves form a (4/WN) x WN grid; the workgroup tile is 64*(4/WN) rows x 16*NF channels and
+// every wave owns 64 rows x 16*NF/WN channels.  WN > 1 trades weight re-streaming for more workgroups on the layers
+// with few output positions (Mixed_4*/Mixed_5*).
+template <typename T, int NF, int WN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   typedef Prec<T> PR;
   typedef typename PR::frag frag;
   constexpr int EPL = PR::EPL;
   constexpr int SLABC = 4 * EPL;
   constexpr int WCH = NF >= 4 ? NF / 4 : 1;   // 16-byte weight chunks per thread per (slab, tap)
+  constexpr int WM = 4 / WN, NFW = NF / WN;   // waves along M; channel fragments per wave
+  static_assert(NF % WN == 0 && 4 * NFW >= EPL, "wave tile too narrow for 16-byte epilogue groups");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const halo = smem;
   char* const wbuf = smem + 4 * p.plane_b + 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = lane & 15;
+  const int wm = wave % WM, wn = wave / WM;
 
   int bid = blockIdx.x;
   const int tw = bid % p.nTw; bid /= p.nTw;
@@ -124,11 +131,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   char* const hdst = halo + plane_off(ch, p.plane_b) + (tid >> 2) * 16;
 
   // ---- compute plan: this wave owns tile rows [64*wave, 64*wave+64), 4 fragments of 16 positions ----
-  const bool wave_active = wave * 64 < p.rows;
+  const bool wave_active = wm * 64 < p.rows;
   int rowpos[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = wave * 64 + i * 16 + m;
+    const int r = wm * 64 + i * 16 + m;
     int pos = 0;
     if (r < p.rows) {
       const int hw = p.Ht * p.Wt;
@@ -139,9 +146,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     rowpos[i] = pos * 16 + plane_off(q, p.plane_b);
   }
 
-  f32x4 acc[NF][4];
+  f32x4 acc[NFW][4];
 #pragma unroll
-  for (int f = 0; f < NF; ++f)
+  for (int f = 0; f < NFW; ++f)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -225,14 +232,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
           }
           __syncthreads();
           if (wave_active) {
-            frag bf[4], af[NF];
+            frag bf[4], af[NFW];
 #pragma unroll
             for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + rowpos[i] + tapoff);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) af[f] = *(const frag*)(wcur + (f * 64 + lane) * 16);
+            for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
             __builtin_amdgcn_sched_barrier(0);   // keep every fragment read ahead of the MFMA chain (counted lgkmcnt waits)
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int f = 0; f < NFW; ++f)
 #pragma unroll
               for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
           }
@@ -241,13 +248,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     }
   }
 
-  // ---- epilogue: lane = position (m of fragment i), channels ntile*16NF + q*4NF + [0, 4NF) ----
+  // ---- epilogue: lane = position (m of fragment i), channels ntile*16NF + q*4NF + wn*4NFW + [0, 4NFW) ----
   if (!wave_active) return;
-  const int cbase = ntile * 16 * NF + q * 4 * NF;
-  constexpr int NG = 4 * NF / EPL;   // 16-byte channel groups per lane
+  const int cbase = ntile * 16 * NF + q * 4 * NF + wn * 4 * NFW;
+  constexpr int NG = 4 * NFW / EPL;   // 16-byte channel groups per lane
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = wave * 64 + i * 16 + m;
+    const int r = wm * 64 + i * 16 + m;
     if (r >= p.rows) continue;
     const int hw = p.Ht * p.Wt;
     const int rt = r / hw, rem = r - rt * hw;
@@ -299,13 +306,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw) {
+flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows) {
+  if (max_rows <= 0 || max_rows > FLK_ROWS) max_rows = FLK_ROWS;
   flk_tile best{1, 1, 1};
   double best_eff = -1.0;
   long best_halo = 0;
-  for (int Tt = 1; Tt <= To && Tt <= FLK_ROWS; ++Tt)
-    for (int Ht = 1; Ht <= Ho && Tt * Ht <= FLK_ROWS; ++Ht) {
-      const int wmax = FLK_ROWS / (Tt * Ht) < Wo ? FLK_ROWS / (Tt * Ht) : Wo;
+  for (int Tt = 1; Tt <= To && Tt <= max_rows; ++Tt)
+    for (int Ht = 1; Ht <= Ho && Tt * Ht <= max_rows; ++Ht) {
+      const int wmax = max_rows / (Tt * Ht) < Wo ? max_rows / (Tt * Ht) : Wo;
       for (int Wt = 1; Wt <= wmax; ++Wt) {
         const long halo = (long)((Tt - 1) * st + kt) * ((Ht - 1) * sh + kh) * ((Wt - 1) * sw + kw);
         if (halo > FLK_MAX_HALO) continue;
@@ -313,8 +321,8 @@ flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st,
         // a workgroup occupies a CU slot whatever its row count: utilisation = useful rows / (tiles * 256);
         // staging cost grows with the halo (per slab) while MFMA work grows with rows * taps
         const int rows = Tt * Ht * Wt;
-        const double eff = (double)To * Ho * Wo / ((double)tiles * FLK_ROWS);
-        const double score = eff / (1.0 + 2.0 * (double)halo / ((double)FLK_ROWS * kt * kh * kw));
+        const double eff = (double)To * Ho * Wo / ((double)tiles * max_rows);
+        const double score = eff / (1.0 + 2.0 * (double)halo / ((double)max_rows * kt * kh * kw));
         (void)rows;
         if (score > best_eff + 1e-9 || (score > best_eff - 1e-9 && (Wt > best.Wt || (Wt == best.Wt && halo < best_halo)))) {
           best_eff = score; best = flk_tile{Tt, Ht, Wt}; best_halo = halo;
@@ -324,15 +332,15 @@ flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st,
   return best;
 }
 
-template <typename T, int NF>
+template <typename T, int NF, int WN>
 static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NF>,
+    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NF, WN>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, NF>), grid, dim3(256), lds, s, kp);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, NF, WN>), grid, dim3(256), lds, s, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -373,12 +381,28 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   kp.ost = a->ost; kp.osh = a->osh; kp.osw = a->osw; kp.oot = a->oot; kp.ooh = a->ooh; kp.oow = a->oow;
   kp.add_ld = a->add_ld; kp.add_coff = a->add_coff; kp.mask_ld = a->mask_ld; kp.mask_coff = a->mask_coff;
   kp.relu = a->relu;
-  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw);
+  // wave layout: start from 256-row tiles; while the launch has fewer workgroups than CUs, halve
+  // the rows per workgroup (waves then split the channel tile instead).  bf16 needs >= 2 fragments per wave.
+  const int nf = w->nf;
+  const int ntile_n = w->cout_frags / nf;
+  int wn = 1;
+  flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS);
+  {
+    const int wn_max = dtype == FLK_BF16 ? nf / 2 : nf;      // NFW >= 2 (bf16) / 1 (fp32)
+    const char* force = getenv("FLK_CONV_WN");
+    while (true) {
+      const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * ntile_n;
+      const bool more = force ? wn < atoi(force) : wgs < 256;   // fewer workgroups than CUs
+      if (!more || wn * 2 > 4 || wn * 2 > wn_max) break;
+      wn *= 2;
+      t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS / wn);
+    }
+  }
   kp.Tt = t.Tt; kp.Ht = t.Ht; kp.Wt = t.Wt; kp.rows = t.Tt * t.Ht * t.Wt;
   kp.nTt = (a->To + t.Tt - 1) / t.Tt; kp.nTh = (a->Ho + t.Ht - 1) / t.Ht; kp.nTw = (a->Wo + t.Wt - 1) / t.Wt;
   kp.Th = (t.Tt - 1) * a->st + a->kt; kp.Hh = (t.Ht - 1) * a->sh + a->kh; kp.Wh = (t.Wt - 1) * a->sw + a->kw;
   kp.P = kp.Th * kp.Hh * kp.Wh;
-  FLK_REQUIRE(kp.P <= FLK_MAX_HALO && kp.rows <= FLK_ROWS, "flk_conv3d: no tile fits (halo %d)", kp.P);
+  FLK_REQUIRE(kp.P <= FLK_MAX_HALO && kp.rows <= FLK_ROWS / wn, "flk_conv3d: no tile fits (halo %d)", kp.P);
   kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
   kp.nslab = w->nslab; kp.ntaps = w->ntaps; kp.cout_frags = w->cout_frags;
   if (a->in2) {
@@ -400,21 +424,20 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   } else {
     kp.out2 = kp.out; kp.cout1 = a->cout;
   }
-  const int nf = w->nf;
   const size_t lds = 4 * (size_t)kp.plane_b + 64 + 2 * (size_t)nf * 1024;
   const long gx = (long)a->B * kp.nTt * kp.nTh * kp.nTw;
   FLK_REQUIRE(gx < (1l << 31), "flk_conv3d: grid too large");
-  dim3 grid((unsigned)gx, (unsigned)(w->cout_frags / nf));
+  dim3 grid((unsigned)gx, (unsigned)ntile_n);
   hipStream_t s = (hipStream_t)stream;
+#define FLK_LAUNCH(TT, NFv, WNv) if (nf == NFv && wn == WNv) return launch<TT, NFv, WNv>(kp, grid, lds, s)
   if (dtype == FLK_BF16) {
-    if (nf == 2) return launch<bf16_t, 2>(kp, grid, lds, s);
-    if (nf == 4) return launch<bf16_t, 4>(kp, grid, lds, s);
-    if (nf == 8) return launch<bf16_t, 8>(kp, grid, lds, s);
+    FLK_LAUNCH(bf16_t, 2, 1); FLK_LAUNCH(bf16_t, 4, 1); FLK_LAUNCH(bf16_t, 4, 2);
+    FLK_LAUNCH(bf16_t, 8, 1); FLK_LAUNCH(bf16_t, 8, 2); FLK_LAUNCH(bf16_t, 8, 4);
   } else if (dtype == FLK_F32) {
-    if (nf == 2) return launch<float, 2>(kp, grid, lds, s);
-    if (nf == 4) return launch<float, 4>(kp, grid, lds, s);
-    if (nf == 8) return launch<float, 8>(kp, grid, lds, s);
+    FLK_LAUNCH(float, 2, 1); FLK_LAUNCH(float, 2, 2); FLK_LAUNCH(float, 4, 1); FLK_LAUNCH(float, 4, 2); FLK_LAUNCH(float, 4, 4);
+    FLK_LAUNCH(float, 8, 1); FLK_LAUNCH(float, 8, 2); FLK_LAUNCH(float, 8, 4);
   }
-  flk_set_error("flk_conv3d: unsupported dtype %d / nf %d", dtype, nf);
+#undef FLK_LAUNCH
+  flk_set_error("flk_conv3d: unsupported dtype %d / nf %d / wn %d", dtype, nf, wn);
   return FLK_EINVAL;
 }
