@@ -50,7 +50,7 @@ class ApplyArgs(C.Structure):
                 ("dclip", C.c_float), ("inv_std", C.c_float * 3),
                 ("lo", C.c_float), ("hi", C.c_float), ("adv_flag", C.c_float),
                 ("shift_x", C.c_int), ("shift_p", C.c_int),
-                ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+                ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("fold_t", C.c_int)]
 
 
 class AdamArgs(C.Structure):

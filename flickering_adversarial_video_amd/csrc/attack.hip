@@ -6,32 +6,36 @@
 // 198-209, 868.  Closed forms: SURVEY Appendix C.
 #include "flk_internal.h"
 
-template <typename TO> __device__ static inline void store32(char* dst, const float* v);   // 32 channels
-template <> __device__ inline void store32<float>(char* dst, const float* v) {
+// FT = 2: fold (t,h,w) parities, 24 used of 32 channels; FT = 1: fold (h,w) only, 12 used of 16 channels
+template <typename TO, int NCH> __device__ static inline void store_ch(char* dst, const float* v) {
+  if constexpr (sizeof(TO) == 4) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ((float4*)dst)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-}
-template <> __device__ inline void store32<bf16_t>(char* dst, const float* v) {
+    for (int i = 0; i < NCH / 4; ++i) ((float4*)dst)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bf16x8 o;
+    for (int i = 0; i < NCH / 8; ++i) {
+      bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[8 * i + e];
-    ((bf16x8*)dst)[i] = o;
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[8 * i + e];
+      ((bf16x8*)dst)[i] = o;
+    }
   }
 }
-template <typename TI> __device__ static inline void load24(const char* src, float* v);     // first 24 of 32 channels
-template <> __device__ inline void load24<float>(const char* src, float* v) {
+template <typename TI, int NUSED> __device__ static inline void load_ch(const char* src, float* v) {   // NUSED = 24 | 12
+  if constexpr (sizeof(TI) == 4) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { const float4 f = ((const float4*)src)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
-}
-template <> __device__ inline void load24<bf16_t>(const char* src, float* v) {
+    for (int i = 0; i < NUSED / 4; ++i) { const float4 f = ((const float4*)src)[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+  } else {
+    float t[(NUSED + 7) / 8 * 8];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const uint4 u = ((const uint4*)src)[i];
-    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+    for (int i = 0; i < (NUSED + 7) / 8; ++i) {
+      const uint4 u = ((const uint4*)src)[i];
+      const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { v[8 * i + 2 * k] = __uint_as_float(w[k] << 16); v[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+      for (int k = 0; k < 4; ++k) { t[8 * i + 2 * k] = __uint_as_float(w[k] << 16); t[8 * i + 2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    }
+#pragma unroll
+    for (int i = 0; i < NUSED; ++i) v[i] = t[i];
   }
 }
 
@@ -61,10 +65,11 @@ __device__ static inline float pert_at(const flk_apply_args& a, int t, int h, in
   return d * a.inv_std[c];
 }
 
-// ---- apply: one thread = one space-to-depth output position (2x2x2 input cells x 3 channels) ----
-template <typename TO>
+// ---- apply: one thread = one space-to-depth output position (FT x 2 x 2 input cells x 3 channels) ----
+template <typename TO, int FT>
 __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, char* out) {
-  const int T2 = a.T / 2, H2 = a.H / 2, W2 = a.W / 2;
+  constexpr int NCH = 16 * FT, NUSED = 12 * FT;
+  const int T2 = a.T / FT, H2 = a.H / 2, W2 = a.W / 2;
   const long total = (long)a.B * T2 * H2 * W2;
   for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
     long r = gid;
@@ -72,10 +77,10 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
     const int h2 = r % H2; r /= H2;
     const int t2 = r % T2;
     const int b = r / T2;
-    float v[32];
+    float v[NCH];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int t = 2 * t2 + qt;
+    for (int qt = 0; qt < FT; ++qt) {
+      const int t = FT * t2 + qt;
       const int tx = wrap(t - a.shift_x, a.T);      // x'[t] = x[(t - shift_x) mod T]
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
@@ -92,15 +97,16 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
       }
     }
 #pragma unroll
-    for (int i = 24; i < 32; ++i) v[i] = 0.f;
-    store32<TO>(out + (size_t)gid * 32 * sizeof(TO), v);
+    for (int i = NUSED; i < NCH; ++i) v[i] = 0.f;
+    store_ch<TO, NCH>(out + (size_t)gid * NCH * sizeof(TO), v);
   }
 }
 
 static int check_apply(const flk_apply_args* a) {
   FLK_REQUIRE(a && a->x && a->delta, "flk_perturb: null argument");
-  FLK_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && a->T % 2 == 0 && a->H % 2 == 0 && a->W % 2 == 0,
-              "flk_perturb: T,H,W must be positive and even (got %d,%d,%d)", a->T, a->H, a->W);
+  FLK_REQUIRE(a->fold_t == 0 || a->fold_t == 1 || a->fold_t == 2, "flk_perturb: fold_t must be 0, 1 or 2");
+  FLK_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && (a->fold_t == 1 || a->T % 2 == 0) && a->H % 2 == 0 && a->W % 2 == 0,
+              "flk_perturb: H,W (and T when folded) must be positive and even (got %d,%d,%d)", a->T, a->H, a->W);
   FLK_REQUIRE(a->lo <= a->hi, "flk_perturb: lo > hi");
   return FLK_OK;
 }
@@ -109,10 +115,14 @@ extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dty
   int rc = check_apply(a);
   if (rc) return rc;
   FLK_REQUIRE(out, "flk_perturb_apply_s2d: null out");
-  const long total = (long)a->B * (a->T / 2) * (a->H / 2) * (a->W / 2);
+  const int ft = a->fold_t == 1 ? 1 : 2;
+  const long total = (long)a->B * (a->T / ft) * (a->H / 2) * (a->W / 2);
   const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-  if (dtype == FLK_BF16) hipLaunchKernelGGL(apply_s2d_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (char*)out);
-  else if (dtype == FLK_F32) hipLaunchKernelGGL(apply_s2d_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, (char*)out);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FLK_BF16 && ft == 2) hipLaunchKernelGGL((apply_s2d_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
+  else if (dtype == FLK_BF16) hipLaunchKernelGGL((apply_s2d_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
+  else if (dtype == FLK_F32 && ft == 2) hipLaunchKernelGGL((apply_s2d_kernel<float, 2>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
+  else if (dtype == FLK_F32) hipLaunchKernelGGL((apply_s2d_kernel<float, 1>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
   else { flk_set_error("flk_perturb_apply_s2d: bad dtype"); return FLK_EINVAL; }
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
@@ -122,16 +132,17 @@ extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dty
 // stage 1: workgroup (b, t2, chunk of h2 rows) -> partials[wg][qt][c] = sum over its cells of
 //          g * 1[lo <= x' + a p' <= hi]      (both clip gradients are inclusive at the bounds)
 static inline int grad_nchunk(int B, int T, int H) {
-  const int bt = B * (T / 2), H2 = H / 2;
+  const int bt = B * (T / 2 > 0 ? T / 2 : 1), H2 = H / 2;
   int n = (1024 + bt - 1) / bt;
   if (n > H2) n = H2;
   if (n < 1) n = 1;
   return n;
 }
 
-template <typename TI>
+template <typename TI, int FT>
 __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a, const char* gx, int nchunk, float* partials) {
-  const int T2 = a.T / 2, H2 = a.H / 2, W2 = a.W / 2;
+  constexpr int NCH = 16 * FT, NUSED = 12 * FT;
+  const int T2 = a.T / FT, H2 = a.H / 2, W2 = a.W / 2;
   int bid = blockIdx.x;
   const int chunk = bid % nchunk; bid /= nchunk;
   const int t2 = bid % T2;
@@ -141,11 +152,11 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a
   const int ncell = (h_hi - h_lo) * W2;
   for (int i = threadIdx.x; i < ncell; i += 256) {
     const int h2 = h_lo + i / W2, w2 = i % W2;
-    float g[24];
-    load24<TI>(gx + ((((size_t)b * T2 + t2) * H2 + h2) * W2 + w2) * 32 * sizeof(TI), g);
+    float g[NUSED];
+    load_ch<TI, NUSED>(gx + ((((size_t)b * T2 + t2) * H2 + h2) * W2 + w2) * NCH * sizeof(TI), g);
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int t = 2 * t2 + qt, tx = wrap(t - a.shift_x, a.T);
+    for (int qt = 0; qt < FT; ++qt) {
+      const int t = FT * t2 + qt, tx = wrap(t - a.shift_x, a.T);
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
         const int h = 2 * h2 + qh;
@@ -179,7 +190,8 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a
 __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const float* partials, float* gdelta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.T * 3) return;
-  const int t = i / 3, c = i % 3, t2 = t >> 1, qt = t & 1, T2 = a.T / 2;
+  const int FT = a.fold_t == 1 ? 1 : 2;
+  const int t = i / 3, c = i % 3, t2 = t / FT, qt = t % FT, T2 = a.T / FT;
   float s = 0.f;
   for (int b = 0; b < a.B; ++b)
     for (int k = 0; k < nchunk; ++k) s += partials[(((size_t)b * T2 + t2) * nchunk + k) * 6 + qt * 3 + c];
@@ -190,24 +202,25 @@ __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const flo
 }
 
 // dense delta ("L12" baseline, kinetics_i3d_utils.py:308-521): no spatial reduction, sum over the batch.
-template <typename TI>
+template <typename TI, int FT>
 __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a, const char* gx, float* gdelta) {
-  const int T2 = a.T / 2, H2 = a.H / 2, W2 = a.W / 2;
+  constexpr int NCH = 16 * FT, NUSED = 12 * FT;
+  const int T2 = a.T / FT, H2 = a.H / 2, W2 = a.W / 2;
   const long total = (long)T2 * H2 * W2;
   for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
     long r = gid;
     const int w2 = r % W2; r /= W2;
     const int h2 = r % H2;
     const int t2 = r / H2;
-    float acc[24];
+    float acc[NUSED];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) acc[k] = 0.f;
+    for (int k = 0; k < NUSED; ++k) acc[k] = 0.f;
     for (int b = 0; b < a.B; ++b) {
-      float g[24];
-      load24<TI>(gx + ((((size_t)b * T2 + t2) * H2 + h2) * W2 + w2) * 32 * sizeof(TI), g);
+      float g[NUSED];
+      load_ch<TI, NUSED>(gx + ((((size_t)b * T2 + t2) * H2 + h2) * W2 + w2) * NCH * sizeof(TI), g);
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const int t = 2 * t2 + qt, tx = wrap(t - a.shift_x, a.T);
+      for (int qt = 0; qt < FT; ++qt) {
+        const int t = FT * t2 + qt, tx = wrap(t - a.shift_x, a.T);
 #pragma unroll
         for (int qh = 0; qh < 2; ++qh) {
           float x[6];
@@ -221,12 +234,12 @@ __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a,
       }
     }
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < FT; ++qt)
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          const int t = 2 * t2 + qt, ts = wrap(t - a.shift_p, a.T), c = k % 3;
+          const int t = FT * t2 + qt, ts = wrap(t - a.shift_p, a.T), c = k % 3;
           const size_t di = (((size_t)ts * a.H + 2 * h2 + qh) * a.W + 2 * w2 + k / 3) * 3 + c;
           const float d = a.delta[di];
           const bool pass = !(a.dclip > 0.f) || (d >= -a.dclip && d <= a.dclip);
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a,
 extern "C" int64_t flk_perturb_grad_scratch_bytes(int B, int T, int H, int W) {
   (void)W;
   if (B <= 0 || T <= 0 || H <= 0) return 0;
-  return (int64_t)B * (T / 2) * grad_nchunk(B, T, H) * 6 * sizeof(float);
+  return (int64_t)B * T * grad_nchunk(B, T, H) * 6 * sizeof(float);   // covers both fold_t settings
 }
 
 extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s2d, int dtype, float* gdelta,
@@ -248,17 +261,23 @@ extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s
   FLK_REQUIRE(gx_s2d && gdelta, "flk_perturb_grad_reduce: null argument");
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_perturb_grad_reduce: bad dtype");
   hipStream_t s = (hipStream_t)stream;
+  const int ft = a->fold_t == 1 ? 1 : 2;
+  const bool bf = dtype == FLK_BF16;
   if (a->delta_dense) {
-    const long total = (long)(a->T / 2) * (a->H / 2) * (a->W / 2);
+    const long total = (long)(a->T / ft) * (a->H / 2) * (a->W / 2);
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (dtype == FLK_BF16) hipLaunchKernelGGL(grad_dense_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
-    else hipLaunchKernelGGL(grad_dense_kernel<float>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
+    if (bf && ft == 2) hipLaunchKernelGGL((grad_dense_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
+    else if (bf) hipLaunchKernelGGL((grad_dense_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
+    else if (ft == 2) hipLaunchKernelGGL((grad_dense_kernel<float, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
+    else hipLaunchKernelGGL((grad_dense_kernel<float, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
   } else {
     FLK_REQUIRE(partials, "flk_perturb_grad_reduce: null scratch");
     const int nchunk = grad_nchunk(a->B, a->T, a->H);
-    const unsigned grid = (unsigned)(a->B * (a->T / 2) * nchunk);
-    if (dtype == FLK_BF16) hipLaunchKernelGGL(grad_reduce_stage1<bf16_t>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
-    else hipLaunchKernelGGL(grad_reduce_stage1<float>, dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
+    const unsigned grid = (unsigned)(a->B * (a->T / ft) * nchunk);
+    if (bf && ft == 2) hipLaunchKernelGGL((grad_reduce_stage1<bf16_t, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
+    else if (bf) hipLaunchKernelGGL((grad_reduce_stage1<bf16_t, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
+    else if (ft == 2) hipLaunchKernelGGL((grad_reduce_stage1<float, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
+    else hipLaunchKernelGGL((grad_reduce_stage1<float, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
     hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128), dim3(128), 0, s, *a, nchunk, partials, gdelta);
   }
   FLK_CHECK_HIP(hipGetLastError());

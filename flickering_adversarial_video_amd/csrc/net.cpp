@@ -48,6 +48,10 @@ struct ConvLayer {
   flk_conv_weights* wb = nullptr;
   float* d_scale = nullptr;
   float* d_bias = nullptr;
+  // generic (strided) layers: stride, symmetric padding, and the parity classes of the data-gradient
+  int st = 1, sh = 1, sw = 1, pt = 0, ph = 0, pw = 0;
+  struct BwdClass { flk_conv_weights* w; int kt, kh, kw, pbt, pbh, pbw, ot, oh, ow; };
+  std::vector<BwdClass> bcls;
 };
 
 inline void same_pad(int n, int k, int s, int& out, int& before) {
@@ -235,6 +239,12 @@ struct flk_net {
   }
 
   int build_i3d();
+  int build_videoresnet();
+  int make_conv_tv(const std::string& wname, const std::string& bnname, int cout, int cin, int kt, int kh, int kw,
+                   int st_, int sh_, int sw_, int pt_, int ph_, int pw_, ConvLayer** out);
+  int pack_generic(ConvLayer* L);
+  void emit_gen_fwd(ConvLayer* L, const Act& in, const Act& out, bool relu, const Act* add);
+  void emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const void* add, int add_ld, const Act* mask);
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -488,10 +498,312 @@ int flk_net::build_i3d() {
   return FLK_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// torchvision-0.5.0 VideoResNet family (r2plus1d_18 / r3d_18 / mc3_18; reference call site model.py:421).
+// Channel counts that are not multiples of 8 (45, 230, 460, 921) are zero-padded in storage and weights.
+static inline int pad8(int c) { return (c + 7) / 8 * 8; }
+
+int flk_net::make_conv_tv(const std::string& wname, const std::string& bnname, int cout, int cin, int kt, int kh, int kw,
+                          int st_, int sh_, int sw_, int pt_, int ph_, int pw_, ConvLayer** out) {
+  auto* w = find(wname + ".weight", (size_t)cout * cin * kt * kh * kw);      // torch layout [cout][cin][kt][kh][kw]
+  auto* g = find(bnname + ".weight", cout);
+  auto* b = find(bnname + ".bias", cout);
+  auto* mean = find(bnname + ".running_mean", cout);
+  auto* var = find(bnname + ".running_var", cout);
+  if (!w || !g || !b || !mean || !var) return FLK_EINVAL;
+  auto L = std::make_unique<ConvLayer>();
+  const int cip = pad8(cin), cop = pad8(cout);
+  L->name = wname; L->kt = kt; L->kh = kh; L->kw = kw; L->cin = cip; L->cout = cop;
+  L->st = st_; L->sh = sh_; L->sw = sw_; L->pt = pt_; L->ph = ph_; L->pw = pw_;
+  L->w.assign((size_t)kt * kh * kw * cip * cop, 0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < kt * kh * kw; ++t)
+        L->w[((size_t)t * cip + ci) * cop + co] = (*w)[((size_t)co * cin + ci) * kt * kh * kw + t];
+  L->scale.assign(cop, 0.f); L->bias.assign(cop, 0.f);
+  for (int c = 0; c < cout; ++c) {
+    const float a = (*g)[c] / sqrtf((*var)[c] + 1e-5f);                      // BatchNorm3d eval, eps 1e-5
+    L->scale[c] = a; L->bias[c] = (*b)[c] - (*mean)[c] * a;
+  }
+  *out = L.get();
+  convs.push_back(std::move(L));
+  return FLK_OK;
+}
+
+// forward operator + one data-gradient operator per input parity class (i = s*j + p):
+//   gx[s*j + p] = sum_{k = p + pad (mod s)} G[j + (p + pad - k)/s] . (a * W[k])^T
+int flk_net::pack_generic(ConvLayer* L) {
+  const int taps = L->kt * L->kh * L->kw;
+  int rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, nullptr, 0, dtype,
+                                        choose_nf(L->cout, taps), 0, &L->wf);
+  if (rc) return rc;
+  if ((rc = upload(&L->d_scale, L->scale)) || (rc = upload(&L->d_bias, L->bias))) return rc;
+  auto dim_class = [](int k, int s, int pad, int p, std::vector<int>& ks, int& off_min) {
+    ks.clear(); off_min = 0;
+    // taps of this class ordered by ASCENDING offset (descending k)
+    for (int kk = k - 1; kk >= 0; --kk)
+      if ((((p + pad - kk) % s) + s) % s == 0) ks.push_back(kk);
+    if (!ks.empty()) off_min = (p + pad - ks.front()) / s;   // may be negative
+  };
+  for (int ct = 0; ct < L->st; ++ct)
+    for (int chh = 0; chh < L->sh; ++chh)
+      for (int cw = 0; cw < L->sw; ++cw) {
+        std::vector<int> kts, khs, kws;
+        int ot, oh, ow;
+        dim_class(L->kt, L->st, L->pt, ct, kts, ot);
+        dim_class(L->kh, L->sh, L->ph, chh, khs, oh);
+        dim_class(L->kw, L->sw, L->pw, cw, kws, ow);
+        if (kts.empty() || khs.empty() || kws.empty()) continue;       // class receives no gradient from this layer
+        const int nt = (int)kts.size(), nh = (int)khs.size(), nw = (int)kws.size();
+        std::vector<float> wd((size_t)nt * nh * nw * L->cout * L->cin);
+        for (int a = 0; a < nt; ++a) for (int b2 = 0; b2 < nh; ++b2) for (int c = 0; c < nw; ++c) {
+          const int src = (kts[a] * L->kh + khs[b2]) * L->kw + kws[c];
+          for (int co = 0; co < L->cout; ++co)
+            for (int ci = 0; ci < L->cin; ++ci)
+              wd[((((size_t)a * nh + b2) * nw + c) * L->cout + co) * L->cin + ci] = L->w[((size_t)src * L->cin + ci) * L->cout + co];
+        }
+        ConvLayer::BwdClass bc{};
+        rc = flk_conv_weights_create_impl(wd.data(), nt, nh, nw, L->cout, L->cin, L->scale.data(), 0, dtype,
+                                          choose_nf(L->cin, nt * nh * nw), 0, &bc.w);
+        if (rc) return rc;
+        bc.kt = nt; bc.kh = nh; bc.kw = nw; bc.pbt = -ot; bc.pbh = -oh; bc.pbw = -ow; bc.ot = ct; bc.oh = chh; bc.ow = cw;
+        L->bcls.push_back(bc);
+      }
+  return FLK_OK;
+}
+
+void flk_net::emit_gen_fwd(ConvLayer* L, const Act& in, const Act& out, bool relu, const Act* add) {
+  flk_conv_args a{};
+  a.in = in.p; a.in_ld = in.ld; a.cin = L->cin; a.B = B; a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
+  a.kt = L->kt; a.kh = L->kh; a.kw = L->kw; a.st = L->st; a.sh = L->sh; a.sw = L->sw; a.pt = L->pt; a.ph = L->ph; a.pw = L->pw;
+  a.To = out.T; a.Ho = out.H; a.Wo = out.W; a.OT = out.T; a.OH = out.H; a.OW = out.W; a.ost = a.osh = a.osw = 1;
+  a.out = out.p; a.out_ld = out.ld; a.cout = L->cout;
+  a.scale = L->d_scale; a.bias = L->d_bias; a.relu = relu;
+  if (add) { a.add = add->p; a.add_ld = add->ld; }
+  const double macs = (double)B * out.T * out.H * out.W * L->kt * L->kh * L->kw * L->cin * L->cout;
+  flk_conv_weights* wf = L->wf;
+  const int dt = dtype;
+  fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
+}
+
+void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const void* add, int add_ld, const Act* mask) {
+  for (const auto& bc : L->bcls) {
+    flk_conv_args a{};
+    a.in = G.p; a.in_ld = G.ld; a.cin = L->cout; a.B = B; a.Ti = G.T; a.Hi = G.H; a.Wi = G.W;
+    a.kt = bc.kt; a.kh = bc.kh; a.kw = bc.kw; a.st = a.sh = a.sw = 1; a.pt = bc.pbt; a.ph = bc.pbh; a.pw = bc.pbw;
+    a.To = (gin.T - bc.ot + L->st - 1) / L->st; a.Ho = (gin.H - bc.oh + L->sh - 1) / L->sh; a.Wo = (gin.W - bc.ow + L->sw - 1) / L->sw;
+    if (a.To <= 0 || a.Ho <= 0 || a.Wo <= 0) continue;
+    a.OT = gin.T; a.OH = gin.H; a.OW = gin.W; a.ost = L->st; a.osh = L->sh; a.osw = L->sw; a.oot = bc.ot; a.ooh = bc.oh; a.oow = bc.ow;
+    a.out = gin.p; a.out_ld = gin.ld; a.cout = L->cin;
+    a.add = add; a.add_ld = add_ld;
+    if (mask) { a.mask = mask->p; a.mask_ld = mask->ld; }
+    const double macs = (double)B * a.To * a.Ho * a.Wo * bc.kt * bc.kh * bc.kw * L->cin * L->cout;
+    flk_conv_weights* wb = bc.w;
+    const int dt = dtype;
+    bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
+  }
+}
+
+int flk_net::build_videoresnet() {
+  FLK_REQUIRE(H % 2 == 0 && W % 2 == 0 && T >= 1, "VideoResNet: H and W must be even");
+  const bool r21 = arch == FLK_NET_R2PLUS1D_18;
+  int rc;
+  std::vector<std::function<void()>> bwd_emit;
+  const int H2 = H / 2, W2 = W / 2;
+  auto out_dim = [](int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; };
+
+  // ---- stem conv (kt x 7 x 7, stride 1x2x2, pad (kt-1)/2 x 3 x 3) on the (h,w) space-to-depth clip [B,T,H/2,W/2,16]:
+  //      kh = 2*j + q - 1 (j = 0..3 taps, q = parity), pad-before 2 in the folded space ----
+  const int skt = r21 ? 1 : 3, sc_out = r21 ? 45 : 64;
+  ConvLayer* stem7 = nullptr;
+  if ((rc = make_conv_tv("stem.0", "stem.1", sc_out, 3, skt, 7, 7, 1, 2, 2, (skt - 1) / 2, 3, 3, &stem7))) return rc;
+  ConvLayer* stem = nullptr;
+  {
+    auto L = std::make_unique<ConvLayer>();
+    L->name = "stem.0"; L->kt = skt; L->kh = 4; L->kw = 4; L->cin = 16; L->cout = stem7->cout;
+    L->st = L->sh = L->sw = 1; L->pt = (skt - 1) / 2; L->ph = 2; L->pw = 2;
+    L->w.assign((size_t)skt * 16 * 16 * L->cout, 0.f);
+    for (int kt = 0; kt < skt; ++kt) for (int jh = 0; jh < 4; ++jh) for (int jw = 0; jw < 4; ++jw)
+      for (int qh = 0; qh < 2; ++qh) for (int qw = 0; qw < 2; ++qw) {
+        const int kh = 2 * jh + qh - 1, kw = 2 * jw + qw - 1;
+        if (kh < 0 || kh > 6 || kw < 0 || kw > 6) continue;
+        for (int c = 0; c < 3; ++c) {
+          const float* src = &stem7->w[((((size_t)kt * 7 + kh) * 7 + kw) * stem7->cin + c) * stem7->cout];
+          float* dst = &L->w[((((size_t)kt * 4 + jh) * 4 + jw) * 16 + (qh * 2 + qw) * 3 + c) * L->cout];
+          for (int co = 0; co < L->cout; ++co) dst[co] = src[co];
+        }
+      }
+    L->scale = stem7->scale; L->bias = stem7->bias;
+    stem = L.get();
+    convs.push_back(std::move(L));
+  }
+  if ((rc = pack_generic(stem))) return rc;
+  Act a_st, G_st;
+  if ((rc = new_act(a_st, T, H2, W2, stem->cout)) || (rc = new_act(G_st, T, H2, W2, stem->cout))) return rc;
+  named[r21 ? "stem.mid" : "stem"] = {a_st, sc_out};
+  {
+    flk_conv_args a{};
+    a.in_ld = 16; a.cin = 16; a.B = B; a.Ti = T; a.Hi = H2; a.Wi = W2;
+    a.kt = skt; a.kh = a.kw = 4; a.st = a.sh = a.sw = 1; a.pt = (skt - 1) / 2; a.ph = a.pw = 2;
+    a.To = T; a.Ho = H2; a.Wo = W2; a.OT = T; a.OH = H2; a.OW = W2; a.ost = a.osh = a.osw = 1;
+    a.out = a_st.p; a.out_ld = a_st.ld; a.cout = stem->cout; a.scale = stem->d_scale; a.bias = stem->d_bias; a.relu = 1;
+    const double macs = (double)B * T * H2 * W2 * skt * 49.0 * 3 * sc_out;
+    flk_conv_weights* wf = stem->wf;
+    const int dt = dtype;
+    fwd.push_back(Op{"stem.0", K_CONV, 2.0 * macs, 0.0, [this, a, wf, dt](hipStream_t s) mutable { a.in = x_in; return flk_conv3d(&a, wf, dt, s); }});
+    const ConvLayer::BwdClass bc = stem->bcls[0];
+    flk_conv_args g{};
+    g.in = G_st.p; g.in_ld = G_st.ld; g.cin = stem->cout; g.B = B; g.Ti = T; g.Hi = H2; g.Wi = W2;
+    g.kt = bc.kt; g.kh = bc.kh; g.kw = bc.kw; g.st = g.sh = g.sw = 1; g.pt = bc.pbt; g.ph = bc.pbh; g.pw = bc.pbw;
+    g.To = T; g.Ho = H2; g.Wo = W2; g.OT = T; g.OH = H2; g.OW = W2; g.ost = g.osh = g.osw = 1;
+    g.out_ld = 16; g.cout = 16;
+    flk_conv_weights* wb = bc.w;
+    bwd_emit.push_back([this, g, wb, dt, macs]() {
+      bwd.push_back(Op{"stem.0/dgrad", K_CONV, 2.0 * macs, 0.0, [this, g, wb, dt](hipStream_t s) mutable { g.out = gx_in; return flk_conv3d(&g, wb, dt, s); }});
+    });
+  }
+  Act cur = a_st, Gcur = G_st;
+  if (r21) {
+    ConvLayer* s3 = nullptr;
+    if ((rc = make_conv_tv("stem.3", "stem.4", 64, 45, 3, 1, 1, 1, 1, 1, 1, 0, 0, &s3)) || (rc = pack_generic(s3))) return rc;
+    Act a2, G2;
+    if ((rc = new_act(a2, T, H2, W2, 64)) || (rc = new_act(G2, T, H2, W2, 64))) return rc;
+    emit_gen_fwd(s3, cur, a2, true, nullptr);
+    named["stem"] = {a2, 64};
+    const Act prev = cur, Gprev = Gcur;
+    bwd_emit.push_back([this, s3, G2, Gprev, prev]() { emit_gen_bwd(s3, G2, Gprev, nullptr, 0, &prev); });
+    cur = a2; Gcur = G2;
+  }
+  named["grad:stem"] = {Gcur, 64};
+
+  // ---- residual stages ----
+  const int planes_of[4] = {64, 128, 256, 512};
+  int inpl = 64;
+  for (int li = 1; li <= 4; ++li) {
+    const int planes = planes_of[li - 1];
+    const int kind = r21 ? 2 : ((arch == FLK_NET_R3D_18 || li == 1) ? 0 : 1);   // 0: 3x3x3, 1: 1x3x3 (no temporal), 2: (2+1)D
+    for (int bi = 0; bi < 2; ++bi) {
+      const int stride = (li > 1 && bi == 0) ? 2 : 1;
+      const bool has_ds = stride != 1 || inpl != planes;
+      const std::string pre = "layer" + std::to_string(li) + "." + std::to_string(bi);
+      const int mid = (inpl * planes * 27) / (inpl * 9 + 3 * planes);
+      const int dst = kind == 1 ? 1 : stride;        // temporal stride of the block (and of its downsample)
+      Act out, Gout;
+      if ((rc = new_act(out, out_dim(cur.T, 1, dst, 0), out_dim(cur.H, 1, stride, 0), out_dim(cur.W, 1, stride, 0), planes)) ||
+          (rc = new_act(Gout, out.T, out.H, out.W, planes))) return rc;
+      // builds conv_builder(cin -> cout, stride s) + BN; returns the layers (1 or 2) and the intermediate tensors
+      struct Unit { ConvLayer* a = nullptr; ConvLayer* b = nullptr; Act midact, Gmid; };
+      auto make_unit = [&](const std::string& up, const std::string& bnp, int ci, int co, int s, Unit& u) -> int {
+        int r;
+        if (kind == 2) {
+          if ((r = make_conv_tv(up + ".0", up + ".1", mid, ci, 1, 3, 3, 1, s, s, 0, 1, 1, &u.a)) || (r = pack_generic(u.a))) return r;
+          // second conv of Conv2Plus1D has no BN of its own inside the Sequential: the block's BN (bnp) follows it
+          if ((r = make_conv_tv(up + ".3", bnp, co, mid, 3, 1, 1, s, 1, 1, 1, 0, 0, &u.b)) || (r = pack_generic(u.b))) return r;
+        } else if (kind == 0) {
+          if ((r = make_conv_tv(up, bnp, co, ci, 3, 3, 3, s, s, s, 1, 1, 1, &u.a)) || (r = pack_generic(u.a))) return r;
+        } else {
+          if ((r = make_conv_tv(up, bnp, co, ci, 1, 3, 3, 1, s, s, 0, 1, 1, &u.a)) || (r = pack_generic(u.a))) return r;
+        }
+        return FLK_OK;
+      };
+      Unit u1, u2;
+      if ((rc = make_unit(pre + ".conv1.0", pre + ".conv1.1", inpl, planes, stride, u1))) return rc;
+      if ((rc = make_unit(pre + ".conv2.0", pre + ".conv2.1", planes, planes, 1, u2))) return rc;
+      Act h1, Gh1;
+      if ((rc = new_act(h1, out.T, out.H, out.W, planes)) || (rc = new_act(Gh1, out.T, out.H, out.W, planes))) return rc;
+      ConvLayer* ds = nullptr;
+      Act dsout;
+      if (has_ds) {
+        if ((rc = make_conv_tv(pre + ".downsample.0", pre + ".downsample.1", planes, inpl, 1, 1, 1, dst, stride, stride, 0, 0, 0, &ds)) ||
+            (rc = pack_generic(ds))) return rc;
+        if ((rc = new_act(dsout, out.T, out.H, out.W, planes))) return rc;
+      }
+      // forward
+      if (kind == 2) {
+        if ((rc = new_act(u1.midact, cur.T, out.H, out.W, u1.a->cout)) || (rc = new_act(u1.Gmid, cur.T, out.H, out.W, u1.a->cout))) return rc;
+        if ((rc = new_act(u2.midact, out.T, out.H, out.W, u2.a->cout)) || (rc = new_act(u2.Gmid, out.T, out.H, out.W, u2.a->cout))) return rc;
+        emit_gen_fwd(u1.a, cur, u1.midact, true, nullptr);
+        emit_gen_fwd(u1.b, u1.midact, h1, true, nullptr);
+        if (has_ds) emit_gen_fwd(ds, cur, dsout, false, nullptr);
+        emit_gen_fwd(u2.a, h1, u2.midact, true, nullptr);
+        emit_gen_fwd(u2.b, u2.midact, out, true, has_ds ? &dsout : &cur);
+      } else {
+        emit_gen_fwd(u1.a, cur, h1, true, nullptr);
+        if (has_ds) emit_gen_fwd(ds, cur, dsout, false, nullptr);
+        emit_gen_fwd(u2.a, h1, out, true, has_ds ? &dsout : &cur);
+      }
+      named[pre] = {out, planes};
+      named["grad:" + pre] = {Gout, planes};
+      // backward: G_out (masked by out > 0) -> conv2 -> h1 -> conv1 (+ shortcut) -> block input, masked by input > 0
+      const Act in_act = cur, Gin = Gcur;
+      const bool k2 = kind == 2;
+      bwd_emit.push_back([=]() {
+        if (k2) {
+          emit_gen_bwd(u2.b, Gout, u2.Gmid, nullptr, 0, &u2.midact);
+          emit_gen_bwd(u2.a, u2.Gmid, Gh1, nullptr, 0, &h1);
+        } else {
+          emit_gen_bwd(u2.a, Gout, Gh1, nullptr, 0, &h1);
+        }
+        // shortcut gradient first (plain), conv1's data-gradient then accumulates onto it and applies the ReLU mask
+        const void* addp; int addld;
+        if (has_ds) {
+          const size_t bytes = Gin.numel(B) * esz();
+          void* gp = Gin.p;
+          bwd.push_back(Op{pre + ".downsample/zero", K_OTHER, 0.0, (double)bytes, [gp, bytes](hipStream_t s) {
+                             FLK_CHECK_HIP(hipMemsetAsync(gp, 0, bytes, s));
+                             return FLK_OK;
+                           }});
+          emit_gen_bwd(ds, Gout, Gin, nullptr, 0, nullptr);
+          addp = Gin.p; addld = Gin.ld;
+        } else {
+          addp = Gout.p; addld = Gout.ld;
+        }
+        if (k2) {
+          emit_gen_bwd(u1.b, Gh1, u1.Gmid, nullptr, 0, &u1.midact);
+          emit_gen_bwd(u1.a, u1.Gmid, Gin, addp, addld, &in_act);
+        } else {
+          emit_gen_bwd(u1.a, Gh1, Gin, addp, addld, &in_act);
+        }
+      });
+      cur = out; Gcur = Gout; inpl = planes;
+    }
+  }
+
+  // ---- head: AdaptiveAvgPool3d(1) + Linear(512, num_classes) ----
+  {
+    auto* fw = find("fc.weight", (size_t)num_classes * 512);     // torch layout [N][C]
+    auto* fb = find("fc.bias", num_classes);
+    if (!fw || !fb) return FLK_EINVAL;
+    std::vector<float> wT((size_t)512 * num_classes);
+    for (int n = 0; n < num_classes; ++n)
+      for (int c = 0; c < 512; ++c) wT[(size_t)c * num_classes + n] = (*fw)[(size_t)n * 512 + c];
+    if ((rc = upload(&d_fcw, wT)) || (rc = upload(&d_fcb, *fb))) return rc;
+    const int Tn = cur.T;
+    std::vector<float> wt(Tn, 1.0f / (float)(cur.T * cur.H * cur.W));
+    if ((rc = upload(&d_wt, wt))) return rc;
+    if ((rc = dmalloc((void**)&d_feat, (size_t)B * 512 * 4)) || (rc = dmalloc((void**)&d_dfeat, (size_t)B * 512 * 4))) return rc;
+    const Act y = cur, Gy = Gcur;
+    const int C = 512, N = num_classes, dt = dtype;
+    fwd.push_back(Op{"fc", K_HEAD, 0.0, (double)y.numel(B) * esz(), [this, y, C, N, Tn, dt](hipStream_t s) {
+                       return flk_head_forward(y.p, y.ld, 0, C, B, Tn, y.H * y.W, d_wt, d_fcw, d_fcb, N, d_feat, logits_out, dt, s);
+                     }});
+    bwd_emit.push_back([this, y, Gy, N, Tn, dt]() {
+      const int C = 512;
+      bwd.push_back(Op{"fc/grad", K_HEAD, 0.0, 2.0 * (double)y.numel(B) * esz(), [this, y, Gy, C, N, Tn, dt](hipStream_t s) {
+                         return flk_head_backward(y.p, y.ld, 0, Gy.p, Gy.ld, 0, C, B, Tn, y.H * y.W, d_wt, d_fcw, N, dlogits_in, d_dfeat, 1, dt, s);
+                       }});
+    });
+  }
+  for (auto it = bwd_emit.rbegin(); it != bwd_emit.rend(); ++it) (*it)();
+  return FLK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------
 extern "C" int flk_net_create(int arch, int dtype, int B, int T, int H, int W, int device, flk_net** out) {
   FLK_REQUIRE(out, "flk_net_create: null out");
-  FLK_REQUIRE(arch == FLK_NET_I3D, "flk_net_create: arch %d not built yet (I3D only)", arch);
+  FLK_REQUIRE(arch == FLK_NET_I3D || arch == FLK_NET_R2PLUS1D_18 || arch == FLK_NET_R3D_18 || arch == FLK_NET_MC3_18,
+              "flk_net_create: unknown arch %d", arch);
   FLK_REQUIRE(dtype == FLK_F32 || dtype == FLK_BF16, "flk_net_create: bad dtype %d", dtype);
   FLK_REQUIRE(B > 0 && T > 0 && H > 0 && W > 0, "flk_net_create: bad dims");
   flk_net* n = new (std::nothrow) flk_net();
@@ -505,7 +817,10 @@ extern "C" int flk_net_destroy(flk_net* n) {
   if (!n) return FLK_OK;
   (void)hipSetDevice(n->device);
   for (void* p : n->allocs) (void)hipFree(p);
-  for (auto& L : n->convs) { flk_conv_weights_destroy(L->wf); flk_conv_weights_destroy(L->wb); }
+  for (auto& L : n->convs) {
+    flk_conv_weights_destroy(L->wf); flk_conv_weights_destroy(L->wb);
+    for (auto& c : L->bcls) flk_conv_weights_destroy(c.w);
+  }
   for (auto& e : n->ev_fwd) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (auto& e : n->ev_bwd) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete n;
@@ -522,7 +837,7 @@ extern "C" int flk_net_set_weight(flk_net* n, const char* name, const float* dat
 extern "C" int flk_net_finalize(flk_net* n) {
   FLK_REQUIRE(n && !n->finalized, "flk_net_finalize: bad state");
   FLK_CHECK_HIP(hipSetDevice(n->device));
-  int rc = n->build_i3d();
+  int rc = n->arch == FLK_NET_I3D ? n->build_i3d() : n->build_videoresnet();
   if (rc) return rc;
   n->weights.clear();
   for (auto& L : n->convs) { std::vector<float>().swap(L->w); }
@@ -533,7 +848,9 @@ extern "C" int flk_net_finalize(flk_net* n) {
 
 extern "C" int64_t flk_net_workspace_bytes(const flk_net* n) { return n ? (int64_t)n->alloc_bytes : 0; }
 extern "C" int64_t flk_net_input_numel(const flk_net* n) {
-  return n ? (int64_t)n->B * (n->T / 2) * (n->H / 2) * (n->W / 2) * 32 : 0;
+  if (!n) return 0;
+  return n->arch == FLK_NET_I3D ? (int64_t)n->B * (n->T / 2) * (n->H / 2) * (n->W / 2) * 32
+                                : (int64_t)n->B * n->T * (n->H / 2) * (n->W / 2) * 16;
 }
 extern "C" int flk_net_num_classes(const flk_net* n) { return n ? n->num_classes : 0; }
 

@@ -124,7 +124,7 @@ def maxpool3d_bwd(ctx, gout, mask=None):
 
 
 def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=0, shift_p=0, inv_std=(1.0, 1.0, 1.0),
-                    lo=-1.0, hi=1.0):
+                    lo=-1.0, hi=1.0, fold_t=2):
     """x: uint8 or fp32 [B,T,H,W,3] on the GPU; delta fp32 [T,3] or [T,H,W,3]."""
     B, T, H, W, c3 = x.shape
     assert c3 == 3 and x.is_contiguous() and delta.is_contiguous() and delta.dtype == torch.float32
@@ -142,13 +142,15 @@ def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=
     a.lo, a.hi, a.adv_flag = float(lo), float(hi), float(adv_flag)
     a.shift_x, a.shift_p = int(shift_x), int(shift_p)
     a.B, a.T, a.H, a.W = B, T, H, W
+    a.fold_t = fold_t
     a._keepalive = (x, delta)   # the struct holds raw pointers only
     return a
 
 
 def perturb_apply_s2d(args, dtype, out=None):
     if out is None:
-        out = torch.empty((args.B, args.T // 2, args.H // 2, args.W // 2, 32), dtype=torch_dtype(dtype_code(dtype)), device="cuda")
+        ft = 1 if args.fold_t == 1 else 2
+        out = torch.empty((args.B, args.T // ft, args.H // 2, args.W // 2, 16 * ft), dtype=torch_dtype(dtype_code(dtype)), device="cuda")
     check(load().flk_perturb_apply_s2d(C.byref(args), ptr(out), dtype_code(dtype), stream_ptr()))
     return out
 

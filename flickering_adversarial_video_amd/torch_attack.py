@@ -1,0 +1,164 @@
+"""Host-side mirror of the reference's torch attack surface (utils_cv/action_recognition/model.py:58-330) on top of
+libflicker_hip.so: ``Perturbation``, ``Losses``, ``Adversarial_metrics`` and a VideoResNet attack engine
+(``FlickerVideoResNet``, the hot loop of ``VideoLearnerAdversarial.fit_single_video_attack``, model.py:984-1205).
+
+Same names, argument meaning and error behaviour as the reference classes; the arithmetic runs in the HIP kernels
+(torch dialect flags), pinned by the reference's own golden vectors (tests/golden/torch_attack_golden.npz).
+Clips are channels-last ``[B,T,H,W,3]`` on the device (the reference's NCDHW ``[B,3,T,H,W]`` permuted once at load)."""
+import numpy as np
+import torch
+
+from . import ops, parallel
+from ._lib import FLK_NET_MC3_18, FLK_NET_R2PLUS1D_18, FLK_NET_R3D_18
+from .videoresnet_spec import DEFAULT_MEAN, DEFAULT_STD
+
+ARCH_CODES = {"r2plus1d_18": FLK_NET_R2PLUS1D_18, "r3d_18": FLK_NET_R3D_18, "mc3_18": FLK_NET_MC3_18}
+
+
+class Perturbation:
+    """model.py:58-129.  size = [3,T,1,1] (flickering); the parameter is stored time-major [T,3] on the device."""
+
+    def __init__(self, size, requires_grad=True, device="cuda", max_value=None, min_value=None, max_norm=1.0, cyclic_pert=False):
+        if len(size) != 4 or size[0] != 3 or size[2] != 1 or size[3] != 1:
+            raise NotImplementedError("only the flickering perturbation [3,T,1,1] is built (dense L12: apply/gradient kernels only)")
+        self.size, self.device, self.requires_grad = tuple(size), device, requires_grad
+        self.T = size[1]
+        # model.py:72-75: attributes are only set when the argument is None -- reproduced
+        if max_value is None:
+            self.max_value = float(np.min((1 - np.array(DEFAULT_MEAN)) / DEFAULT_STD))
+        if min_value is None:
+            self.min_value = float(np.max((0.0 - np.array(DEFAULT_MEAN)) / DEFAULT_STD))
+        self.max_norm = self.dynamic_max_norm = max_norm
+        self.cyclic_pert = cyclic_pert
+        self._rng = np.random.default_rng(0)
+        self.perturbation = None
+        self.init_perturbation()
+
+    def init_perturbation(self, perturbation=(), requires_grad=True, device="cuda"):
+        """model.py:121-126: U(-1,1)*1e-6 or the given numpy array [3,T,1,1]"""
+        if len(perturbation) == 0:
+            p = (self._rng.random((self.T, 3), dtype=np.float32) * 2 - 1) * 1e-6
+        else:
+            p = np.asarray(perturbation, dtype=np.float32).reshape(3, self.T).T
+        self.perturbation = torch.from_numpy(np.ascontiguousarray(p)).cuda()
+
+    def apply_args(self, x, adversarial=True):
+        shift = int(self._rng.integers(0, self.T)) if (self.cyclic_pert and adversarial) else 0   # model.py:91-92
+        inf = float("inf")
+        return ops.make_apply_args(x, self.perturbation, dialect="torch", dclip=self.dynamic_max_norm,
+                                   adv_flag=1.0 if adversarial else 0.0, shift_p=shift,
+                                   inv_std=tuple(1.0 / s for s in DEFAULT_STD),
+                                   lo=self.min_value if adversarial else -inf, hi=self.max_value if adversarial else inf, fold_t=1)
+
+    def clamp_perturbation(self):
+        return self.perturbation.clamp(-self.dynamic_max_norm, self.dynamic_max_norm)
+
+    def get_perturbation(self):
+        """(clamped, raw) as [3,T,1,1] like the reference (model.py:128-129)"""
+        f = lambda t: t.t().reshape(3, self.T, 1, 1)
+        return f(self.clamp_perturbation()), f(self.perturbation)
+
+    def metric_calc(self):
+        p = self.perturbation
+        return p.abs().mean() * 100.0, (torch.roll(p, 1, 0) - p).abs().mean() * 100.0
+
+
+class Losses:
+    """model.py:131-250: __call__(labels, logits, prob, perturbation) -> [loss, adv, reg]; here the adversarial part and
+    d(adv)/d(logits) come from flk_softmax_adv_loss (torch dialect), the regulariser from flk_perturb_reg_adam."""
+
+    def __init__(self, beta_1=0.5, lambda_=1.0, targeted=False, target_class=None, margin=0.05, improve_loss=False, logits=False,
+                 attack_type="flickering"):
+        if attack_type != "flickering":
+            raise NotImplementedError("L12 regulariser kernel is not built yet")
+        if targeted and improve_loss:
+            # model.py:223-225 references undefined names: the reference crashes here; refuse instead of guessing
+            raise NotImplementedError("the reference's targeted improve-loss is non-functional (model.py:223-225)")
+        self.beta_1, self.lambda_, self.targeted, self.target_class = beta_1, lambda_, targeted, target_class
+        self.margin, self.improve_loss, self.logits, self.attack_type = margin, improve_loss, logits, attack_type
+        self.label_prob = None
+
+    def adv(self, labels, model_logits, global_batch):
+        lab = labels if not self.targeted else torch.full_like(labels, self.target_class)
+        sm, dl, pc = ops.softmax_adv_loss(model_logits, lab, dialect="torch", improve_loss=self.improve_loss, use_logits=self.logits,
+                                          targeted=self.targeted, margin=self.margin, mean_scale=1.0 / global_batch)
+        self.label_prob = pc[:, 1]
+        return sm, dl, pc
+
+
+class Adversarial_metrics:
+    """model.py:253-330"""
+
+    def __init__(self, targeted=False, target_class=None):
+        self.targeted, self.target_class = targeted, target_class
+
+    def accuracy_for_eval(self, output, ground_truth, topk=(1,), clean_pred=None):
+        adv, clean = output.argmax(1), clean_pred.argmax(1)
+        correct_clean = clean == ground_truth
+        if self.targeted:
+            return (adv == self.target_class).float().sum() * (100.0 / ground_truth.numel())
+        return ((adv != ground_truth) & correct_clean).float().sum(), correct_clean.float().sum()
+
+    def adversarial_metric(self, perturbation):
+        return perturbation.abs().mean() * 100.0, (torch.roll(perturbation, 1, dims=1) - perturbation).abs().mean() * 100.0
+
+
+class FlickerVideoResNet:
+    """Attack engine for torchvision-0.5.0 r2plus1d_18 / r3d_18 / mc3_18 (model.py:337-399,984-1205)."""
+
+    def __init__(self, base_model, weights, batch_size=1, sample_length=16, image_size=112, dtype="bf16", device=0, l_inf_pert_norm=0.2,
+                 cyclic_pert=False, num_classes=400, process_group=None):
+        if base_model not in ARCH_CODES:
+            raise ValueError(f"base_model must be one of {sorted(ARCH_CODES)} (model.py:47-56), got {base_model!r}")
+        if not torch.cuda.is_available():
+            raise RuntimeError("FlickerVideoResNet needs an MI355X (HIP) device; there is no CPU fallback")
+        torch.cuda.set_device(device)
+        self.model_name, self.B, self.T, self.H, self.W, self.dtype = base_model, batch_size, sample_length, image_size, image_size, dtype
+        self.pg, self.world = process_group, parallel.world_size(process_group)
+        self.net = ops.Net(ARCH_CODES[base_model], dtype, self.B, self.T, self.H, self.W, weights, device)
+        self.pert_model = Perturbation((3, self.T, 1, 1), max_norm=l_inf_pert_norm, cyclic_pert=cyclic_pert)
+        dev = torch.device("cuda", device)
+        tdt = torch.bfloat16 if dtype in ("bf16", torch.bfloat16) else torch.float32
+        self._xs = torch.empty((self.B, self.T, self.H // 2, self.W // 2, 16), dtype=tdt, device=dev)
+        self._gx = torch.empty_like(self._xs)
+        self._logits = torch.empty((self.B, num_classes), dtype=torch.float32, device=dev)
+        self._red = torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev)
+        self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4), dtype=torch.float32, device=dev)
+        self._scalars = torch.empty(8, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(self.T, 3, device=dev)
+        self.adam_v = torch.zeros(self.T, 3, device=dev)
+        self.adam_t = 0      # the reference keeps ONE Adam instance across videos: not reset by init_perturbation
+
+    def _check_x(self, x):
+        if tuple(x.shape) != (self.B, self.T, self.H, self.W, 3) or x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError(f"clip must be a CUDA float32 channels-last tensor {(self.B, self.T, self.H, self.W, 3)}, got {tuple(x.shape)} {x.dtype}")
+        return x.contiguous()
+
+    def logits(self, x, adversarial=False):
+        """model([x, adversarial]) (model.py:1028,1073)"""
+        a = self.pert_model.apply_args(self._check_x(x), adversarial)
+        ops.perturb_apply_s2d(a, self.dtype, self._xs)
+        return self.net.forward(self._xs, self._logits)
+
+    def step(self, x, labels, criterion, lr=1e-3, update=True):
+        """one iteration of fit_single_video_attack (model.py:1073-1101): forward, Losses, backward, torch-Adam step."""
+        a = self.pert_model.apply_args(self._check_x(x), True)
+        ops.perturb_apply_s2d(a, self.dtype, self._xs)
+        self.net.forward(self._xs, self._logits)
+        gbatch = self.B * self.world
+        sm, dl, pc = criterion.adv(labels, self._logits, gbatch)
+        self.net.backward(dl, self._gx)
+        n = 3 * self.T
+        ops.perturb_grad_reduce(a, self._gx, self._red[:n].view(self.T, 3), self._scratch)
+        parallel.pack_scalars(self._red, self.T, pc)
+        parallel.allreduce_sum_(self._red, self.pg)
+        res = dict(adv_loss=self._red[n].clone(), softmax=sm, label_prob=pc[:, 1], argmax=pc[:, 3].to(torch.int64))
+        if update:
+            self.adam_t += 1
+            b1 = criterion.beta_1
+            ops.perturb_reg_adam(self._red[:n], self.pert_model.perturbation, self.adam_m, self.adam_v, self.adam_t, dialect="torch",
+                                 beta0=criterion.lambda_, beta1=b1, beta2=1 - b1, beta3=1 - b1,
+                                 dyn_max_norm=self.pert_model.dynamic_max_norm, lr=lr, scalars=self._scalars)
+            sc = self._scalars.clone()
+            res.update(reg_loss=sc[0], loss=res["adv_loss"] + criterion.lambda_ * sc[0], thickness=sc[4] * 100, roughness=sc[5] * 100)
+        return res

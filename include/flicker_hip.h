@@ -126,6 +126,9 @@ typedef struct {
   float adv_flag;            /* 0 -> clean input */
   int shift_x, shift_p;      /* cyclic temporal rolls (kinetics_i3d_utils.py:115-137), 0 = off */
   int B, T, H, W;
+  int fold_t;                /* 0/2: fold (t,h,w) parities -> [B,T/2,H/2,W/2,32] (I3D stem, stride 2x2x2);
+                                1: fold (h,w) only -> [B,T,H/2,W/2,16], channel (qh*2+qw)*3+c, 12..15 zero
+                                (VideoResNet stems, stride 1x2x2) */
 } flk_apply_args;
 int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dtype, void* stream);
 
