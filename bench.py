@@ -75,6 +75,47 @@ def cpu_baseline(W, T, budget_s=30.0):
             "sec_per_iter": sec, "conv_gflops": conv_gflop_per_clip(T) / sec, "adv_loss_last": float(adv.detach())}
 
 
+VRN_GFLOP = {"r2plus1d_18": 4 * 40.52, "r3d_18": 4 * 40.70, "mc3_18": 4 * 43.34}   # fwd + dgrad per clip @16x112x112
+
+
+def bench_videoresnet(a, world, rank, local_rank):
+    """BASELINE config 3: single-video attack on a torchvision VideoResNet, 16x112x112 (replicas only: no collective)."""
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet, Losses
+    B, T = a.batch, a.frames
+    W = vs.synthetic_weights(a.model, 42)
+    eng = FlickerVideoResNet(a.model, W, batch_size=B, sample_length=T, image_size=112, dtype=a.dtype, device=local_rank)
+    x = torch.from_numpy(vs.synthetic_clip(B, T, seed=1234 + rank)).cuda()
+    labels = eng.logits(x).argmax(-1).clone()
+    crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)      # r2plus1d_main_statistics_*.py:32-65
+    for _ in range(a.warmup):
+        eng.step(x, labels, crit)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        res = eng.step(x, labels, crit)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = B * a.steps / elapsed
+    tf = VRN_GFLOP[a.model] * (T / 16.0) * value / 1e3
+    out = {"metric": f"attack-iters/sec ({a.model} 16x112x112 single-video attack) + 3D-conv TFLOP/s", "value": value,
+           "unit": "clip-iters/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+           "data": "synthetic (seeded normalised fp32 clip resident in HBM, seeded weights)", "conv_tflops": tf,
+           "conv_frac_of_mfma_peak": tf / PEAK_TFLOPS[a.dtype],
+           "config": {"workload": f"{a.model} flickering attack iteration, {T}x112x112, bs={B}", "parallelism": "single (replicas only)"},
+           "adv_loss_last": float(res["adv_loss"])}
+    eng.net.profile(True)
+    eng.step(x, labels, crit)
+    prof = eng.net.profile_read()
+    conv = [r for r in prof if r["kind"] == "conv"]
+    ms, fl = sum(r["ms"] for r in conv), sum(r["flops"] for r in conv)
+    out["roofline"] = {"kernel": "conv_igemm_kernel", "bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_TFLOPS[a.dtype],
+                       "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_TFLOPS[a.dtype], "traffic": None, "launches_per_step": len(conv),
+                       "conv_ms_per_step": ms}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +124,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE: bs=8)")
     ap.add_argument("--frames", type=int, default=64, help="frames per clip (BASELINE: 64; reference default 90)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="i3d", choices=["i3d", "r2plus1d_18", "r3d_18", "mc3_18"],
+                    help="i3d = the headline config; the VideoResNet models are BASELINE config 3 (use --batch 1 --frames 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -98,6 +141,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
+    if a.model != "i3d":
+        return bench_videoresnet(a, world, rank, local_rank)
     from flickering_adversarial_video_amd import i3d_spec
     from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
 
