@@ -41,7 +41,7 @@ class PoolArgs(C.Structure):
                 ("pt", C.c_int), ("ph", C.c_int), ("pw", C.c_int),
                 ("To", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
                 ("out", C.c_void_p), ("out_ld", C.c_int), ("out_coff", C.c_int),
-                ("idx", C.c_void_p)]
+                ("idx", C.c_void_p), ("relu_input", C.c_int)]
 
 
 class ApplyArgs(C.Structure):

@@ -210,8 +210,9 @@ struct flk_net {
   }
   struct PoolRec { flk_pool_args a; };
   int emit_pool_fwd(const std::string& name, const Act& in, int C, int kt, int kh, int kw, int st, int sh, int sw, Act& out,
-                    PoolRec& rec) {
+                    PoolRec& rec, bool relu_input = false) {
     flk_pool_args a{};
+    a.relu_input = relu_input;
     a.in = in.p; a.in_ld = in.ld; a.in_coff = 0; a.C = C;
     a.B = B; a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
     a.kt = kt; a.kh = kh; a.kw = kw; a.st = st; a.sh = sh; a.sw = sw;
@@ -314,11 +315,12 @@ int flk_net::build_i3d() {
 
   // ---- MaxPool3d_2a_3x3 ----
   Act p2a, Gp2a; PoolRec r2a;
-  if ((rc = emit_pool_fwd("MaxPool3d_2a_3x3", a1, 64, 1, 3, 3, 1, 2, 2, p2a, r2a))) return rc;
+  // main pools read ReLU outputs whose gradient is masked by (input > 0): relu_input makes the mask read unnecessary
+  if ((rc = emit_pool_fwd("MaxPool3d_2a_3x3", a1, 64, 1, 3, 3, 1, 2, 2, p2a, r2a, true))) return rc;
   if ((rc = new_act(Gp2a, p2a.T, p2a.H, p2a.W, 64))) return rc;
   named["MaxPool3d_2a_3x3"] = {p2a, 64};
   named["grad:MaxPool3d_2a_3x3"] = {Gp2a, 64};
-  bwd_emit.push_back([this, r2a, Gp2a, G1, a1]() { emit_pool_bwd("MaxPool3d_2a_3x3", r2a, Gp2a, G1, &a1); });
+  bwd_emit.push_back([this, r2a, Gp2a, G1]() { emit_pool_bwd("MaxPool3d_2a_3x3", r2a, Gp2a, G1, nullptr); });
 
   // ---- Conv3d_2b_1x1, Conv3d_2c_3x3 ----
   ConvLayer *c2b = nullptr, *c2c = nullptr;
@@ -338,11 +340,11 @@ int flk_net::build_i3d() {
 
   // ---- MaxPool3d_3a_3x3 ----
   Act p3a, Gp3a; PoolRec r3a;
-  if ((rc = emit_pool_fwd("MaxPool3d_3a_3x3", a2c, 192, 1, 3, 3, 1, 2, 2, p3a, r3a))) return rc;
+  if ((rc = emit_pool_fwd("MaxPool3d_3a_3x3", a2c, 192, 1, 3, 3, 1, 2, 2, p3a, r3a, true))) return rc;
   if ((rc = new_act(Gp3a, p3a.T, p3a.H, p3a.W, 192))) return rc;
   named["MaxPool3d_3a_3x3"] = {p3a, 192};
   named["grad:MaxPool3d_3a_3x3"] = {Gp3a, 192};
-  bwd_emit.push_back([this, r3a, Gp3a, G2c, a2c]() { emit_pool_bwd("MaxPool3d_3a_3x3", r3a, Gp3a, G2c, &a2c); });
+  bwd_emit.push_back([this, r3a, Gp3a, G2c]() { emit_pool_bwd("MaxPool3d_3a_3x3", r3a, Gp3a, G2c, nullptr); });
 
   // ---- Inception blocks ----
   struct Blk { const char* name; int c[6]; int pool_before; int pk[3]; int ps[3]; const char* pool_name; };
@@ -364,13 +366,14 @@ int flk_net::build_i3d() {
     const std::string bn = bk.name;
     if (bk.pool_before) {
       Act po, Gpo; PoolRec pr;
-      if ((rc = emit_pool_fwd(bk.pool_name, cur, cur_c, bk.pk[0], bk.pk[1], bk.pk[2], bk.ps[0], bk.ps[1], bk.ps[2], po, pr))) return rc;
+      if ((rc = emit_pool_fwd(bk.pool_name, cur, cur_c, bk.pk[0], bk.pk[1], bk.pk[2], bk.ps[0], bk.ps[1], bk.ps[2], po, pr, true))) return rc;
       if ((rc = new_act(Gpo, po.T, po.H, po.W, cur_c))) return rc;
       named[bk.pool_name] = {po, cur_c};
       named[std::string("grad:") + bk.pool_name] = {Gpo, cur_c};
       const Act prev = cur, Gprev = Gcur;
       const std::string pn = bk.pool_name;
-      bwd_emit.push_back([this, pn, pr, Gpo, Gprev, prev]() { emit_pool_bwd(pn, pr, Gpo, Gprev, &prev); });
+      bwd_emit.push_back([this, pn, pr, Gpo, Gprev]() { emit_pool_bwd(pn, pr, Gpo, Gprev, nullptr); });
+      (void)prev;
       cur = po; Gcur = Gpo; cur_is_relu = false;
     }
     const int c0 = bk.c[0], c1a = bk.c[1], c1b = bk.c[2], c2a = bk.c[3], c2b_ = bk.c[4], c3 = bk.c[5];

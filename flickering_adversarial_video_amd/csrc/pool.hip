@@ -14,6 +14,7 @@ struct PoolKP {
   int gout_ld, gout_coff, gin_ld, gin_coff, mask_ld, mask_coff;
   int B, Ti, Hi, Wi, To, Ho, Wo;
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
+  int relu_input;
 };
 
 template <typename T> struct PV;
@@ -59,56 +60,54 @@ template <> struct PV<float> {
   }
 };
 
+// grid: x = chunks of 256 over (w, channel group) of one output row; y = h; z = b*T + t  (32-bit index math only)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolKP p) {
   constexpr int EPL = PV<T>::EPL;
   const int ng = p.C / EPL;
-  const long total = (long)p.B * p.To * p.Ho * p.Wo * ng;
-  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-    const int cg = gid % ng;
-    long pos = gid / ng;
-    const int ow = pos % p.Wo; pos /= p.Wo;
-    const int oh = pos % p.Ho; pos /= p.Ho;
-    const int ot = pos % p.To;
-    const int b = pos / p.To;
-    float best[EPL];
-    int bi[EPL];
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)(p.Wo * ng)) return;
+  const int ow = i / ng, cg = i - ow * ng;
+  const int oh = blockIdx.y, ot = blockIdx.z % p.To, b = blockIdx.z / p.To;
+  float best[EPL];
+  int bi[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) { best[e] = -INFINITY; bi[e] = 0; }
-    int tap = 0;
-    for (int dt = 0; dt < p.kt; ++dt) {
-      const int it = ot * p.st - p.pt + dt;
-      for (int dh = 0; dh < p.kh; ++dh) {
-        const int ih = oh * p.sh - p.ph + dh;
-        for (int dw = 0; dw < p.kw; ++dw, ++tap) {
-          const int iw = ow * p.sw - p.pw + dw;
-          if ((unsigned)it >= (unsigned)p.Ti || (unsigned)ih >= (unsigned)p.Hi || (unsigned)iw >= (unsigned)p.Wi) continue;
-          float v[EPL];
-          PV<T>::ld(p.in + ((((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.in_ld + p.in_coff + cg * EPL) * sizeof(T), v);
+  for (int e = 0; e < EPL; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+  int tap = 0;
+  for (int dt = 0; dt < p.kt; ++dt) {
+    const int it = ot * p.st - p.pt + dt;
+    for (int dh = 0; dh < p.kh; ++dh) {
+      const int ih = oh * p.sh - p.ph + dh;
+      for (int dw = 0; dw < p.kw; ++dw, ++tap) {
+        const int iw = ow * p.sw - p.pw + dw;
+        if ((unsigned)it >= (unsigned)p.Ti || (unsigned)ih >= (unsigned)p.Hi || (unsigned)iw >= (unsigned)p.Wi) continue;
+        float v[EPL];
+        PV<T>::ld(p.in + ((((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw) * p.in_ld + p.in_coff + cg * EPL) * sizeof(T), v);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e)
-            if (v[e] > best[e]) { best[e] = v[e]; bi[e] = tap; }
-        }
+        for (int e = 0; e < EPL; ++e)
+          if (v[e] > best[e]) { best[e] = v[e]; bi[e] = tap; }
       }
     }
-    const size_t opos = (((size_t)(b * p.To + ot) * p.Ho + oh) * p.Wo + ow);
-    PV<T>::st(p.out + (opos * p.out_ld + p.out_coff + cg * EPL) * sizeof(T), best);
-    PV<T>::stidx(p.idx + opos * p.C + cg * EPL, bi);
   }
+  if (p.relu_input) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) bi[e] = best[e] > 0.f ? bi[e] : 255;
+  }
+  const size_t opos = (((size_t)(b * p.To + ot) * p.Ho + oh) * p.Wo + ow);
+  PV<T>::st(p.out + (opos * p.out_ld + p.out_coff + cg * EPL) * sizeof(T), best);
+  PV<T>::stidx(p.idx + opos * p.C + cg * EPL, bi);
 }
 
+// grid: x = chunks of 256 over (w, channel group) of one INPUT row; y = h; z = b*T + t
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
   constexpr int EPL = PV<T>::EPL;
   const int ng = p.C / EPL;
-  const long total = (long)p.B * p.Ti * p.Hi * p.Wi * ng;
-  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-    const int cg = gid % ng;
-    long pos = gid / ng;
-    const int iw = pos % p.Wi; pos /= p.Wi;
-    const int ih = pos % p.Hi; pos /= p.Hi;
-    const int it = pos % p.Ti;
-    const int b = pos / p.Ti;
+  {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)(p.Wi * ng)) return;
+    const int iw = i / ng, cg = i - iw * ng;
+    const int ih = blockIdx.y, it = blockIdx.z % p.Ti, b = blockIdx.z / p.Ti;
     const size_t ipos = (((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw);
     float g[EPL];
 #pragma unroll
@@ -206,9 +205,95 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd(const PoolTP p) {
           for (int e = 0; e < EPL; ++e)
             if (v[e] > best[e]) { best[e] = v[e]; bi[e] = tap; }
         }
+    if (k.relu_input) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) bi[e] = best[e] > 0.f ? bi[e] : 255;
+    }
     const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
     PV<T>::st(k.out + (opos * k.out_ld + k.out_coff + c0) * sizeof(T), best);
     PV<T>::stidx(k.idx + opos * k.C + c0, bi);
+  }
+}
+
+// bf16 fast path of the tiled forward: the halo holds SORTABLE 16-bit keys (key = bits ^ (sign ? 0xffff : 0x8000): unsigned
+// order == float order); one element-tap costs 2 VALU ops: pack (key << 16 | 255 - tap) and v_max_u32 -- the larger low
+// byte wins among equal keys, i.e. the FIRST maximum in scan order.  Taps are compile-time so the LDS reads batch.
+__device__ static inline uint32_t bf16x2_to_keys(uint32_t w) {
+  const uint32_t sign = w & 0x80008000u;                 // per half: 0x8000 if negative
+  const uint32_t flip = (sign >> 15) * 0x7fffu;          // 0x7fff for negative halves
+  return w ^ (flip | 0x80008000u);                       // negative: ^0xffff, non-negative: ^0x8000
+}
+__device__ static inline uint32_t keys_to_bf16x2(uint32_t k) {
+  const uint32_t neg = (~k) & 0x80008000u;               // original sign set <=> key top bit clear
+  const uint32_t flip = (neg >> 15) * 0x7fffu;
+  return k ^ (flip | 0x80008000u);
+}
+
+template <int KT, int KH, int KW>
+__global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd_bf16(const PoolTP p) {
+  constexpr int EPL = 8, SLABC = 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const PoolKP& k = p.k;
+  const int tid = threadIdx.x, ch = tid & 3;
+  int bid = blockIdx.x;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const bool chvalid = c0 < k.C;
+  const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * p.Wt;
+  const int it0 = ot0 - k.pt, ih0 = oh0 - k.ph, iw0 = ow0 - k.pw;
+  const int HW = p.Hh * p.Wh;
+  for (int hp = tid >> 2; hp < p.P; hp += 64) {
+    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+    const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
+    uint4 v = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);     // -inf
+    if (chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi)
+      v = *(const uint4*)(k.in + ((((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw) * k.in_ld + k.in_coff + c0) * 2);
+    v.x = bf16x2_to_keys(v.x); v.y = bf16x2_to_keys(v.y); v.z = bf16x2_to_keys(v.z); v.w = bf16x2_to_keys(v.w);
+    *(uint4*)(smem + pplane_off(ch, p.plane_b) + hp * 16) = v;
+  }
+  __syncthreads();
+  if (!chvalid) return;
+  const int hw = p.Ht * p.Wt;
+  for (int r = tid >> 2; r < p.rows; r += 64) {
+    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
+    if (ot >= k.To || oh >= k.Ho || ow >= k.Wo) continue;
+    const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * p.Wh + rw) * 16;
+    uint32_t best[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dt = 0; dt < KT; ++dt)
+#pragma unroll
+      for (int dh = 0; dh < KH; ++dh)
+#pragma unroll
+        for (int dw = 0; dw < KW; ++dw) {
+          const uint32_t tag = 255u - (uint32_t)((dt * KH + dh) * KW + dw);
+          const uint4 v = *(const uint4*)(base + ((dt * p.Hh + dh) * p.Wh + dw) * 16);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            best[2 * i] = max(best[2 * i], (w[i] << 16) | tag);
+            best[2 * i + 1] = max(best[2 * i + 1], (w[i] & 0xffff0000u) | tag);
+          }
+        }
+    uint4 o;
+    o.x = keys_to_bf16x2((best[0] >> 16) | (best[1] & 0xffff0000u));
+    o.y = keys_to_bf16x2((best[2] >> 16) | (best[3] & 0xffff0000u));
+    o.z = keys_to_bf16x2((best[4] >> 16) | (best[5] & 0xffff0000u));
+    o.w = keys_to_bf16x2((best[6] >> 16) | (best[7] & 0xffff0000u));
+    if (k.relu_input) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((best[e] >> 16) <= 0x8000u) best[e] &= ~255u;      // tag 0 -> idx 255 ("no cell")
+    }
+    uint2 id;
+    id.x = (255u - (best[0] & 255u)) | ((255u - (best[1] & 255u)) << 8) | ((255u - (best[2] & 255u)) << 16) | ((255u - (best[3] & 255u)) << 24);
+    id.y = (255u - (best[4] & 255u)) | ((255u - (best[5] & 255u)) << 8) | ((255u - (best[6] & 255u)) << 16) | ((255u - (best[7] & 255u)) << 24);
+    const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+    *(uint4*)(k.out + (opos * k.out_ld + k.out_coff + c0) * 2) = o;
+    *(uint2*)(k.idx + opos * k.C + c0) = id;
   }
 }
 
@@ -311,7 +396,14 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
     attr_set = true;
   }
   if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
-  else hipLaunchKernelGGL(maxpool_s1_tiled_fwd<T>, grid, dim3(256), lds, s, tp);
+  else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
+    static bool attr2 = false;
+    if (!attr2) {
+      FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_fwd_bf16<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr2 = true;
+    }
+    hipLaunchKernelGGL((maxpool_s1_tiled_fwd_bf16<3, 3, 3>), grid, dim3(256), lds, s, tp);
+  } else hipLaunchKernelGGL(maxpool_s1_tiled_fwd<T>, grid, dim3(256), lds, s, tp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -335,6 +427,7 @@ static void fill(PoolKP& kp, const flk_pool_args* a) {
   kp.B = a->B; kp.Ti = a->Ti; kp.Hi = a->Hi; kp.Wi = a->Wi; kp.To = a->To; kp.Ho = a->Ho; kp.Wo = a->Wo;
   kp.kt = a->kt; kp.kh = a->kh; kp.kw = a->kw; kp.st = a->st; kp.sh = a->sh; kp.sw = a->sw;
   kp.pt = a->pt; kp.ph = a->ph; kp.pw = a->pw;
+  kp.relu_input = a->relu_input;
 }
 
 static unsigned grid_for(long total) {
@@ -351,10 +444,10 @@ extern "C" int flk_maxpool3d_fwd(const flk_pool_args* a, int dtype, void* stream
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_maxpool3d_fwd: bad dtype");
   if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, false, (hipStream_t)stream) : launch_tiled<float>(kp, a, false, (hipStream_t)stream);
   const int epl = dtype == FLK_BF16 ? 8 : 4;
-  const long total = (long)a->B * a->To * a->Ho * a->Wo * (a->C / epl);
-  if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, kp);
-  else if (dtype == FLK_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, kp);
-  else { flk_set_error("flk_maxpool3d_fwd: bad dtype"); return FLK_EINVAL; }
+  FLK_REQUIRE(a->Ho < 65536 && (long)a->B * a->To < 65536, "flk_maxpool3d_fwd: grid too large");
+  const dim3 grid((unsigned)((a->Wo * (a->C / epl) + 255) / 256), (unsigned)a->Ho, (unsigned)(a->B * a->To));
+  if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -376,10 +469,10 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_maxpool3d_bwd: bad dtype");
   if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, true, (hipStream_t)stream) : launch_tiled<float>(kp, a, true, (hipStream_t)stream);
   const int epl = dtype == FLK_BF16 ? 8 : 4;
-  const long total = (long)a->B * a->Ti * a->Hi * a->Wi * (a->C / epl);
-  if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, kp);
-  else if (dtype == FLK_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, kp);
-  else { flk_set_error("flk_maxpool3d_bwd: bad dtype"); return FLK_EINVAL; }
+  FLK_REQUIRE(a->Hi < 65536 && (long)a->B * a->Ti < 65536, "flk_maxpool3d_bwd: grid too large");
+  const dim3 grid((unsigned)((a->Wi * (a->C / epl) + 255) / 256), (unsigned)a->Hi, (unsigned)(a->B * a->Ti));
+  if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

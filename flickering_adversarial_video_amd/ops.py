@@ -102,7 +102,7 @@ def _pool_args(x, C_, k, s, pad, out, idx, in_coff=0, out_coff=0):
     return a
 
 
-def maxpool3d(x, k, s, C_=None):
+def maxpool3d(x, k, s, C_=None, relu_input=False):
     """tf.nn.max_pool3d SAME.  Returns (out, idx uint8, ctx) with ctx for maxpool3d_bwd."""
     B, Ti, Hi, Wi, ld = x.shape
     C_ = ld if C_ is None else C_
@@ -110,6 +110,7 @@ def maxpool3d(x, k, s, C_=None):
     out = torch.empty((B, *og, C_), dtype=x.dtype, device=x.device)
     idx = torch.empty((B, *og, C_), dtype=torch.uint8, device=x.device)
     a = _pool_args(x, C_, k, s, pad, out, idx)
+    a.relu_input = int(relu_input)
     check(load().flk_maxpool3d_fwd(C.byref(a), dtype_code(x.dtype), stream_ptr()))
     return out, idx, (x, C_, k, s, pad, out, idx)
 

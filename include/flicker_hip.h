@@ -100,7 +100,10 @@ typedef struct {
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
   int To, Ho, Wo;
   void* out; int out_ld, out_coff;
-  uint8_t* idx;            /* [B,To,Ho,Wo,C] */
+  uint8_t* idx;            /* [B,To,Ho,Wo,C]; 255 = "no cell" */
+  int relu_input;          /* forward only.  1: the input is a ReLU output whose gradient is masked by (input > 0)
+                              anyway -> windows whose maximum is <= 0 record "no cell", so the backward pass needs no
+                              mask tensor (pass mask = NULL): identical result, ~40 % less traffic */
 } flk_pool_args;
 int flk_maxpool3d_fwd(const flk_pool_args* a, int dtype, void* stream);
 /* gin[pos,c] = (add?add:0) + sum_{windows containing pos with argmax == pos} gout[window,c];

@@ -160,6 +160,11 @@ def test_maxpool_fwd_bwd(ops, dtype, k, s, dims):
     torch.testing.assert_close(masked, torch.where(pos, gref, torch.zeros_like(gref)), rtol=r, atol=a)
     # first-max-in-scan-order is torch-CPU's rule too: without ties broken differently the full tensors agree
     torch.testing.assert_close(gin.float().cpu(), gref, rtol=r, atol=a)
+    # relu_input: windows with a non-positive maximum record "no cell" -> backward WITHOUT a mask == masked backward
+    out2, idx2, ctx2 = ops.maxpool3d(x.to(dtype).cuda(), k, s, relu_input=True)
+    torch.testing.assert_close(out2.float().cpu(), out.float().cpu(), rtol=0, atol=0)
+    nomask = ops.maxpool3d_bwd(ctx2, g.to(dtype).cuda()).float().cpu()
+    torch.testing.assert_close(nomask, masked, rtol=0, atol=0)
 
 
 BLOCKS = {"small": (1, 2, 7, 7, 64, (32, 24, 48, 16, 32, 16)),
