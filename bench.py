@@ -203,9 +203,16 @@ def main():
         eng.net.profile(False)
         cv = per_kind["conv"]
         ach = cv["flops"] / (cv["ms"] * 1e-3) / 1e12
+        # HBM traffic per launch comes from the committed rocprofv3 --pmc passes of this same command (bench.py cannot
+        # profile itself): profiles/*_pmc_hbm_traffic.json, produced by tools/pmc_summary.py
+        traffic = None
+        if B == 8 and T == 64 and a.dtype == "bf16":
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1:]:
+                traffic = json.load(open(f))["kernels"]["conv_igemm_kernel"]["bytes_per_launch"]
         out["roofline"] = {"kernel": "conv_igemm_kernel (implicit-GEMM conv3d fwd + dgrad, all layers)", "bound": "mfma",
                            "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.dtype],
-                           "traffic": None, "launches_per_step": cv["launches"] // reps,
+                           "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, gfx950-corrected)", "launches_per_step": cv["launches"] // reps,
                            "avg_launch_ms": cv["ms"] / cv["launches"], "conv_ms_per_step": cv["ms"] / reps,
                            "algorithmic_gflop_per_step": cv["flops"] / reps / 1e9}
         out["kernel_ms_per_step"] = {k: v["ms"] / reps for k, v in per_kind.items()}
