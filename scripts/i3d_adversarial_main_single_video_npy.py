@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Single-video flickering attack on I3D over a folder of .npy clips -- the MI355X counterpart of the reference's
+i3d_adversarial_main_single_video_npy.py (same run_config.yml section, same result pickle).
+
+    python scripts/i3d_adversarial_main_single_video_npy.py [run_config.yml] [--max-steps N] [--frames T]
+
+Per clip (reference :115-337): clean prediction (skip if misclassified) -> delta, Adam re-initialised -> iterate until
+step > MAX_NUM_STEP and the clip is adversarial -> pickle {keys of config.RESULT_KEYS}.  One device pass per iteration
+(FlickerI3D.step) replaces the reference's four sess.run calls.  Weights: MODEL.WEIGHTS_NPZ ({variable name: array}); without
+it seeded synthetic weights are used (the checkpoint is not distributed with the reference).
+"""
+import argparse
+import glob
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flickering_adversarial_video_amd import config as cfgmod, i3d_spec  # noqa: E402
+from flickering_adversarial_video_amd.i3d_engine import FlickerI3D  # noqa: E402
+
+
+def attack_clip(eng, x, label_id, c, max_steps, target_id=None, log_every=100):
+    """returns the result dict (without file-level fields) or None if the clean clip is misclassified"""
+    clean = eng(x, adv_flag=0)[0]
+    if int(clean.argmax()) != label_id:
+        return None
+    targeted = bool(c.TARGETED_ATTACK)
+    lab = torch.tensor([target_id if targeted else label_id], device=x.device)
+    eng.reset_perturbation()
+    beta3 = c.BETA_2                       # reference :98: beta_3 := BETA_2
+    res = {k: [] for k in ("total_loss_l", "adv_loss_l", "reg_loss_l", "norm_reg_loss_l", "diff_norm_reg_loss_l", "perturbation", "softmax")}
+    step, last = 0, None
+    while True:
+        r = eng.step(x, lab, lr=1e-3, beta0=c.LAMBDA, beta1=c.BETA_1, beta2=c.BETA_2, beta3=beta3, margin=c.PROB_MARGIN,
+                     targeted=targeted, use_logits=bool(c.USE_LOGITS), improve_loss=bool(c.IMPROVE_ADV_LOSS), cyclic=float(bool(c.CYCLIC_ATTACK)))
+        h = r.host()                       # one host sync per step, like the reference's fetches
+        for k, src in (("total_loss_l", "total_loss"), ("adv_loss_l", "adv_loss"), ("reg_loss_l", "reg_loss"),
+                       ("norm_reg_loss_l", "norm_reg"), ("diff_norm_reg_loss_l", "diff_norm_reg")):
+            res[k].append(float(h[src]))
+        res["perturbation"].append(eng.perturbation.cpu().numpy().copy())
+        res["softmax"].append(h["softmax"].copy())
+        last = h
+        step += 1
+        if log_every and step % log_every == 0:
+            print(f"  step {step}: total {h['total_loss']:.5f} adv {h['adv_loss']:.5f} thick {h['thickness_relative']:.3f}% "
+                  f"rough {h['roughness_relative']:.3f}% adversarial {bool(h['is_adversarial'])}", flush=True)
+        if step > max_steps and bool(h["is_adversarial"]):
+            break
+        if step > 20 * max_steps + 100:     # the reference loops forever on a robust clip; bound it
+            print("  giving up: not adversarial", flush=True)
+            break
+    res.update(correct_cls_prob=float(clean[label_id]), softmax_init=clean.cpu().numpy(), total_steps=step,
+               fatness=float(last["thickness_relative"]), smoothness=float(last["roughness_relative"]),
+               adv_video=None, beta_0=c.LAMBDA, beta_1=c.BETA_1, beta_2=c.BETA_2, beta_3=beta3)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("config", nargs="?", default="run_config.yml")
+    ap.add_argument("--max-steps", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--dtype", default=None)
+    a = ap.parse_args()
+    cfg = cfgmod.load_config(a.config)
+    c = cfg.SINGLE_VIDEO_ATTACK
+    T = a.frames or cfg.MODEL.FRAMES
+    classes = cfgmod.load_kinetics_classes(cfg.DATA.LABEL_MAP_PATH)
+    W = dict(np.load(cfg.MODEL.WEIGHTS_NPZ)) if cfg.MODEL.WEIGHTS_NPZ else i3d_spec.synthetic_i3d_weights(42)
+    eng = FlickerI3D(W, batch_size=1, frames=T, dtype=a.dtype or cfg.MODEL.DTYPE)
+    os.makedirs(c.PKL_RESULT_PATH, exist_ok=True)
+    target_id = classes.index(c.TARGETED_CLASS) if c.TARGETED_ATTACK else None
+    for path in sorted(glob.glob(os.path.join(c.NPY_PATH, "*.npy"))):
+        cls, label_id = cfgmod.label_from_npy_name(path, classes)
+        clip = np.load(path)[0, -T:][None].astype(np.float32)          # reference :121
+        x = torch.from_numpy(np.ascontiguousarray(clip)).cuda()
+        print(f"{path}: class {cls!r} ({label_id})", flush=True)
+        res = attack_clip(eng, x, label_id, c, a.max_steps if a.max_steps is not None else c.MAX_NUM_STEP, target_id)
+        if res is None:
+            print("  clean clip is misclassified: skipped", flush=True)
+            continue
+        res.update(correct_cls=cls, correct_cls_id=label_id, rgb_sample=clip)
+        res["adv_video"] = np.clip(clip + np.clip(res["perturbation"][-1], -0.4, 0.4)[None], -1, 1)
+        out = os.path.join(c.PKL_RESULT_PATH, cfgmod.result_filename(cls, c.BETA_1, res["fatness"], res["smoothness"]))
+        with open(out, "wb") as f:
+            pickle.dump(res, f)
+        print(f"  -> {out}  ({res['total_steps']} steps, thickness {res['fatness']:.2f}% roughness {res['smoothness']:.2f}%)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
