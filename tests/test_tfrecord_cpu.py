@@ -1,0 +1,63 @@
+"""TFRecord / tf.train.Example reader (no TensorFlow): round trip, framing errors, rank sharding."""
+import numpy as np
+import pytest
+
+from flickering_adversarial_video_amd import tfrecord_io as tio
+
+
+def test_crc32c_known_answers():
+    assert tio.crc32c(b"123456789") == 0xE3069283            # RFC 3720 check value
+    assert tio.crc32c(b"") == 0
+    # TFRecord masking: ((crc >> 15) | (crc << 17)) + 0xa282ead8
+    assert tio.masked_crc(b"123456789") == ((((0xE3069283 >> 15) | (0xE3069283 << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _records(n, T=3, size=4, seed=0):
+    rng = np.random.default_rng(seed)
+    return [(rng.integers(0, 256, (T, size, size, 3), dtype=np.uint8), int(rng.integers(0, 400))) for _ in range(n)]
+
+
+def test_round_trip_and_last_frames(tmp_path):
+    recs = _records(5)
+    p = tmp_path / "a.tfrecords"
+    tio.write_records(str(p), [tio.make_example(v, l) for v, l in recs])
+    got = [tio.parse_example_uint8(d, frames=2, size=4) for d in tio.read_records(str(p), verify_crc=True)]
+    assert len(got) == 5
+    for (v, l), (gv, gl) in zip(recs, got):
+        assert gl == l
+        np.testing.assert_array_equal(gv, v[-2:])             # the LAST frames, like the reference writer/reader pair
+    with pytest.raises(ValueError):
+        tio.parse_example_uint8(next(tio.read_records(str(p))), frames=9, size=4)
+
+
+def test_negative_label_and_unpacked_int64():
+    ex = tio.parse_example(tio.make_example(np.zeros((1, 2, 2, 3), np.uint8), -3))
+    assert ex["train/label"][0] == -3
+
+
+def test_corruption_is_detected(tmp_path):
+    p = tmp_path / "a.tfrecords"
+    tio.write_records(str(p), [tio.make_example(*_records(1)[0])])
+    raw = bytearray(p.read_bytes())
+    raw[20] ^= 0xFF
+    p.write_bytes(bytes(raw))
+    with pytest.raises(ValueError):
+        list(tio.read_records(str(p), verify_crc=True))
+    p.write_bytes(bytes(raw[:30]))
+    with pytest.raises(ValueError):
+        list(tio.read_records(str(p)))
+
+
+def test_batches_shard_over_ranks(tmp_path):
+    recs = _records(11, T=2, size=224, seed=3)
+    for i in range(2):
+        tio.write_records(str(tmp_path / f"f{i}.tfrecords"), [tio.make_example(v, l) for v, l in recs[i * 6:(i + 1) * 6]], with_payload_crc=False)
+    files = tio.list_tfrecords(str(tmp_path))
+    assert len(files) == 2 and tio.list_tfrecords([str(tmp_path)], limit=1) == files[:1]
+    single = list(tio.batches(files, 2, frames=2))
+    assert len(single) == 5 and single[0][0].shape == (2, 2, 224, 224, 3) and single[0][0].dtype == np.uint8
+    r0, r1 = list(tio.batches(files, 2, frames=2, rank=0, world=2)), list(tio.batches(files, 2, frames=2, rank=1, world=2))
+    assert len(r0) == 3 and len(r1) == 2
+    # round-robin: rank 0 owns records 0,2,..,10 (3 full batches), rank 1 owns 1,3,..,9 (2 full batches, record 9 dropped)
+    assert [int(l) for b in r0 for l in b[1]] == [recs[i][1] for i in (0, 2, 4, 6, 8, 10)]
+    assert [int(l) for b in r1 for l in b[1]] == [recs[i][1] for i in (1, 3, 5, 7)]
