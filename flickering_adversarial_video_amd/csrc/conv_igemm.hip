@@ -77,7 +77,7 @@ template <> struct Prec<float> {
 
 __device__ static inline int plane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
 
-constexpr int NPAIR = FLK_MAX_HALO * 4 / 256;  // (position, chunk) pairs staged per thread
+constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pairs staged per thread (16)
 
 // WN = waves along N: the 4 waves form a (4/WN) x WN grid; the workgroup tile is 64*(4/WN) rows x 16*NF channels and
 // every wave owns 64 rows x 16*NF/WN channels.  WN > 1 trades weight re-streaming for more workgroups on the layers
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows) {
+flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows, int max_halo) {
+  if (max_halo <= 0 || max_halo > FLK_MAX_HALO) max_halo = FLK_MAX_HALO;
   if (max_rows <= 0 || max_rows > FLK_ROWS) max_rows = FLK_ROWS;
   flk_tile best{1, 1, 1};
   double best_eff = -1.0;
@@ -316,7 +317,7 @@ flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st,
       const int wmax = max_rows / (Tt * Ht) < Wo ? max_rows / (Tt * Ht) : Wo;
       for (int Wt = 1; Wt <= wmax; ++Wt) {
         const long halo = (long)((Tt - 1) * st + kt) * ((Ht - 1) * sh + kh) * ((Wt - 1) * sw + kw);
-        if (halo > FLK_MAX_HALO) continue;
+        if (halo > max_halo) continue;
         const long tiles = (long)((To + Tt - 1) / Tt) * ((Ho + Ht - 1) / Ht) * ((Wo + Wt - 1) / Wt);
         // a workgroup occupies a CU slot whatever its row count: utilisation = useful rows / (tiles * 256);
         // staging cost grows with the halo (per slab) while MFMA work grows with rows * taps
@@ -386,7 +387,9 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   const int nf = w->nf;
   const int ntile_n = w->cout_frags / nf;
   int wn = 1;
-  flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS);
+  // narrow channel tiles (nf = 2) are latency-bound: keep their halo <= 768 so that 3 workgroups fit a CU's LDS
+  const int max_halo = nf == 2 ? 768 : FLK_MAX_HALO;
+  flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS, max_halo);
   {
     const int wn_max = dtype == FLK_BF16 ? nf / 2 : nf;      // NFW >= 2 (bf16) / 1 (fp32)
     const char* force = getenv("FLK_CONV_WN");
@@ -395,7 +398,7 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
       const bool more = force ? wn < atoi(force) : wgs < 256;   // fewer workgroups than CUs
       if (!more || wn * 2 > 4 || wn * 2 > wn_max) break;
       wn *= 2;
-      t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS / wn);
+      t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS / wn, max_halo);
     }
   }
   kp.Tt = t.Tt; kp.Ht = t.Ht; kp.Wt = t.Wt; kp.rows = t.Tt * t.Ht * t.Wt;

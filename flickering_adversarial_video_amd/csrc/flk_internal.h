@@ -55,7 +55,8 @@ int flk_conv_weights_create_impl(const float* w_dhwio, int kt, int kh, int kw, i
 struct flk_tile {
   int Tt, Ht, Wt;
 };
-flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows = 256);
+flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows = 256,
+                         int max_halo = 1008);
 
-constexpr int FLK_MAX_HALO = 768;  // halo positions per tile (LDS: 4 planes x 768 x 16 B = 48 KiB)
+constexpr int FLK_MAX_HALO = 1008; // halo positions per tile (LDS: 4 planes x 1008 x 16 B = 63 KiB: 2 workgroups per CU with a 16 KiB weight ring)
 constexpr int FLK_ROWS = 256;      // output positions per workgroup tile

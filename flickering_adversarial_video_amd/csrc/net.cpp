@@ -8,6 +8,7 @@
 // buffers and hold d(loss)/d(pre-ReLU output) ("G"), the ReLU mask being applied by the PRODUCING
 // kernel's epilogue and the BN scale folded into the transposed weights.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <functional>
 #include <map>
@@ -22,8 +23,9 @@ int flk_head_backward(const void* y, int ld, int coff, void* gy, int gld, int gc
 
 namespace {
 
-enum OpKind { K_CONV = 0, K_POOL = 1, K_HEAD = 2, K_OTHER = 3 };
-const char* kKindName[] = {"conv", "pool", "head", "other"};
+enum OpKind { K_CONV = 0, K_POOL = 1, K_HEAD = 2, K_OTHER = 3, K_FORK = 4, K_JOIN = 5 };
+const char* kKindName[] = {"conv", "pool", "head", "other", "fork", "join"};
+constexpr int kSideStreams = 2;   // independent Inception branches run on the caller's stream + 2 side streams
 
 struct Op {
   std::string name;
@@ -31,6 +33,7 @@ struct Op {
   double flops;   // algorithmic flops (2*MAC) for conv ops, 0 otherwise
   double bytes;   // algorithmic HBM bytes (compulsory traffic) for memory-bound ops
   std::function<int(hipStream_t)> run;
+  int lane = 0;   // 0 = the caller's stream, 1..kSideStreams = side streams (between a fork and its join)
 };
 
 struct Act {      // channels-last activation tensor [B,T,H,W,ld]
@@ -96,6 +99,9 @@ struct flk_net {
   // head
   float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
   // profiling
+  hipStream_t side[kSideStreams] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr};
+  bool multi_stream = true;
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fwd, ev_bwd;
   bool ev_fwd_valid = false, ev_bwd_valid = false;
@@ -239,6 +245,8 @@ struct flk_net {
                      }});
   }
 
+  static void set_lane(std::vector<Op>& v, size_t from, int lane) { for (size_t i = from; i < v.size(); ++i) v[i].lane = lane; }
+  static void push_sync(std::vector<Op>& v, int kind) { v.push_back(Op{kind == K_FORK ? "@fork" : "@join", kind, 0.0, 0.0, nullptr}); }
   int build_i3d();
   int build_videoresnet();
   int make_conv_tv(const std::string& wname, const std::string& bnname, int cout, int cin, int kt, int kh, int kw,
@@ -433,10 +441,17 @@ int flk_net::build_i3d() {
       const int dt = dtype;
       fwd.push_back(Op{Lf->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
     }
+    // the three remaining branches are independent (disjoint channel slices of `out`): run them concurrently
+    push_sync(fwd, K_FORK);
     emit_conv_fwd(L1b, mid, 0, out, c0);
-    emit_conv_fwd(L2b, mid, c1a, out, c0 + c1b);
-    if ((rc = emit_pool_fwd(bn + "/Branch_3/MaxPool3d_0a_3x3", cur, cur_c, 3, 3, 3, 1, 1, 1, pl, pr3))) return rc;
-    emit_conv_fwd(L3, pl, 0, out, c0 + c1b + c2b_);
+    { const size_t m0 = fwd.size(); emit_conv_fwd(L2b, mid, c1a, out, c0 + c1b); set_lane(fwd, m0, 1); }
+    {
+      const size_t m0 = fwd.size();
+      if ((rc = emit_pool_fwd(bn + "/Branch_3/MaxPool3d_0a_3x3", cur, cur_c, 3, 3, 3, 1, 1, 1, pl, pr3))) return rc;
+      emit_conv_fwd(L3, pl, 0, out, c0 + c1b + c2b_);
+      set_lane(fwd, m0, 2);
+    }
+    push_sync(fwd, K_JOIN);
     named[bn] = {out, cout_total};
     named["grad:" + bn] = {Gout, cout_total};
     named["mid:" + bn] = {mid, c1a + c2a};
@@ -446,10 +461,16 @@ int flk_net::build_i3d() {
     const bool in_relu = cur_is_relu;
     const std::string pname = bn + "/Branch_3/MaxPool3d_0a_3x3";
     bwd_emit.push_back([=]() {
-      emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
-      emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
-      emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a);
+      push_sync(bwd, K_FORK);
+      {
+        const size_t m0 = bwd.size();
+        emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
+        emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
+        set_lane(bwd, m0, 2);
+      }
+      { const size_t m0 = bwd.size(); emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a); set_lane(bwd, m0, 1); }
       emit_conv_bwd(L1b, Gout, c0, Gmid, 0, nullptr, 0, 0, &mid, 0);
+      push_sync(bwd, K_JOIN);
       {
         flk_conv_args a{};
         a.in = Gout.p; a.in_ld = Gout.ld; a.in_coff = 0; a.cin = c0 + c1a + c2a; a.cin1 = c0;
@@ -819,6 +840,11 @@ extern "C" int flk_net_create(int arch, int dtype, int B, int T, int H, int W, i
 extern "C" int flk_net_destroy(flk_net* n) {
   if (!n) return FLK_OK;
   (void)hipSetDevice(n->device);
+  for (int l = 0; l < kSideStreams; ++l) {
+    if (n->side[l]) (void)hipStreamDestroy(n->side[l]);
+    if (n->ev_join[l]) (void)hipEventDestroy(n->ev_join[l]);
+  }
+  if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
   for (void* p : n->allocs) (void)hipFree(p);
   for (auto& L : n->convs) {
     flk_conv_weights_destroy(L->wf); flk_conv_weights_destroy(L->wb);
@@ -844,6 +870,12 @@ extern "C" int flk_net_finalize(flk_net* n) {
   if (rc) return rc;
   n->weights.clear();
   for (auto& L : n->convs) { std::vector<float>().swap(L->w); }
+  for (int l = 0; l < kSideStreams; ++l) {
+    FLK_CHECK_HIP(hipStreamCreateWithFlags(&n->side[l], hipStreamNonBlocking));
+    FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_join[l], hipEventDisableTiming));
+  }
+  FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+  n->multi_stream = !getenv("FLK_SINGLE_STREAM");
   FLK_CHECK_HIP(hipDeviceSynchronize());
   n->finalized = true;
   return FLK_OK;
@@ -866,11 +898,29 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       ev.push_back({a, b});
     }
   }
+  const bool ms = n->multi_stream && n->side[0];
   for (size_t i = 0; i < ops.size(); ++i) {
-    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].first, s));
-    int rc = ops[i].run(s);
+    Op& op = ops[i];
+    if (op.kind == K_FORK) {
+      if (ms) {
+        FLK_CHECK_HIP(hipEventRecord(n->ev_fork, s));
+        for (int l = 0; l < kSideStreams; ++l) FLK_CHECK_HIP(hipStreamWaitEvent(n->side[l], n->ev_fork, 0));
+      }
+      continue;
+    }
+    if (op.kind == K_JOIN) {
+      if (ms)
+        for (int l = 0; l < kSideStreams; ++l) {
+          FLK_CHECK_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
+          FLK_CHECK_HIP(hipStreamWaitEvent(s, n->ev_join[l], 0));
+        }
+      continue;
+    }
+    hipStream_t st = (ms && op.lane > 0) ? n->side[op.lane - 1] : s;
+    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].first, st));
+    int rc = op.run(st);
     if (rc) return rc;
-    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].second, s));
+    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].second, st));
   }
   ev_valid = n->profile;
   return FLK_OK;
@@ -906,6 +956,7 @@ extern "C" int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap) {
   auto dump = [&](std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool valid, const char* pass) -> int {
     if (!valid) return FLK_OK;
     for (size_t i = 0; i < ops.size(); ++i) {
+      if (ops[i].kind == K_FORK || ops[i].kind == K_JOIN) continue;
       FLK_CHECK_HIP(hipEventSynchronize(ev[i].second));
       float ms = 0.f;
       FLK_CHECK_HIP(hipEventElapsedTime(&ms, ev[i].first, ev[i].second));

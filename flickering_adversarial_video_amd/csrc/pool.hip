@@ -379,7 +379,7 @@ template <typename T>
 static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipStream_t s) {
   PoolTP tp{};
   tp.k = kp;
-  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, 1, 1, 1);
+  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, 1, 1, 1, 256, 768);   // 2 workgroups per CU
   tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
   tp.nTt = (a->To + t.Tt - 1) / t.Tt; tp.nTh = (a->Ho + t.Ht - 1) / t.Ht; tp.nTw = (a->Wo + t.Wt - 1) / t.Wt;
   tp.Th = t.Tt + a->kt - 1; tp.Hh = t.Ht + a->kh - 1; tp.Wh = t.Wt + a->kw - 1;
