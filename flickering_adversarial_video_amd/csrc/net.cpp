@@ -898,7 +898,8 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       ev.push_back({a, b});
     }
   }
-  const bool ms = n->multi_stream && n->side[0];
+  // per-layer profiling runs the plan serially on the caller's stream: durations of co-running kernels would overlap
+  const bool ms = n->multi_stream && n->side[0] && !n->profile;
   for (size_t i = 0; i < ops.size(); ++i) {
     Op& op = ops[i];
     if (op.kind == K_FORK) {

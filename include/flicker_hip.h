@@ -196,7 +196,8 @@ int64_t flk_net_workspace_bytes(const flk_net* n);
 int flk_net_forward(flk_net* n, const void* x_in, float* logits, int save_for_backward, void* stream);
 /* dlogits fp32 [B,C] -> gradient w.r.t. the network input (same layout/dtype as x_in) */
 int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream);
-/* per-layer HIP-event timing of the next forward/backward (bench.py roofline leg) */
+/* per-layer HIP-event timing of the next forward/backward (bench.py roofline leg).  While enabled the plan runs serially on
+ * the caller's stream (normally independent Inception branches run on parallel streams; FLK_SINGLE_STREAM=1 disables that). */
 int flk_net_profile(flk_net* n, int enable);
 int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap);
 int64_t flk_net_input_numel(const flk_net* n);
