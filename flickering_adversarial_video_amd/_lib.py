@@ -61,6 +61,11 @@ class AdamArgs(C.Structure):
                 ("step", C.c_int)]
 
 
+class DenseAdamArgs(C.Structure):
+    _fields_ = [("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("torch_dialect", C.c_int), ("beta", C.c_float), ("g_scale", C.c_float),
+                ("lr", C.c_float), ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("step", C.c_int)]
+
+
 class LossArgs(C.Structure):
     _fields_ = [("B", C.c_int), ("C", C.c_int), ("torch_dialect", C.c_int), ("improve_loss", C.c_int),
                 ("use_logits", C.c_int), ("targeted", C.c_int), ("margin", C.c_float), ("mean_scale", C.c_float)]
@@ -82,6 +87,9 @@ _SIGS = {
     "flk_perturb_grad_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "flk_perturb_grad_reduce": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_perturb_reg_adam": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_dense_adam_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "flk_perturb_dense_l12_adam": (C.c_int, [C.POINTER(DenseAdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     "flk_softmax_adv_loss": (C.c_int, [C.POINTER(LossArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "flk_net_destroy": (C.c_int, [C.c_void_p]),

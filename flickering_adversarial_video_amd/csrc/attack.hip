@@ -368,3 +368,102 @@ extern "C" int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, 
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
+
+// ---- dense delta: L12 regulariser + Adam (kinetics_i3d_L12) ------------------------------------------------------------
+// d/d(delta_t) sqrt(mean_{hwc} delta_t^2) = delta_t / (N_f * sqrt(mean_t)),  N_f = H*W*3.
+constexpr int DENSE_CHUNKS = 64;     // workgroups per frame in the reduction pass
+
+__global__ __launch_bounds__(256) void dense_frame_stats(const float* delta, int frame_elems, float* part) {
+  // part[(t*DENSE_CHUNKS + c)*4 + {0,1,2,3}] = {sum d^2, sum |d|, sum |d - d_prev_frame|, max |d|} over this chunk
+  const int t = blockIdx.y, c = blockIdx.x, T = gridDim.y;
+  const float4* d4 = (const float4*)(delta + (size_t)t * frame_elems);
+  const float4* p4 = (const float4*)(delta + (size_t)((t + T - 1) % T) * frame_elems);
+  const int n4 = frame_elems / 4;
+  float sq = 0.f, ab = 0.f, ro = 0.f, mx = 0.f;
+  for (int i = c * 256 + threadIdx.x; i < n4; i += DENSE_CHUNKS * 256) {
+    const float4 a = d4[i], b = p4[i];
+    sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    ab += fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w);
+    ro += fabsf(a.x - b.x) + fabsf(a.y - b.y) + fabsf(a.z - b.z) + fabsf(a.w - b.w);
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+  }
+  __shared__ float sh[4];
+  const float s0 = block_sum(sq, sh), s1 = block_sum(ab, sh), s2 = block_sum(ro, sh), s3 = block_max(mx, sh);
+  if (threadIdx.x == 0) {
+    float* o = part + ((size_t)t * DENSE_CHUNKS + c) * 4;
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+  }
+}
+
+__global__ void dense_frame_finish(const float* part, int T, int frame_elems, float* frame_rms, float* scalars) {
+  // one thread per frame sums its chunks in a fixed order; thread 0 then folds the frames (T <= 1024)
+  __shared__ float s_l12[1024], s_ab[1024], s_ro[1024], s_mx[1024];
+  const int t = threadIdx.x;
+  float sq = 0.f, ab = 0.f, ro = 0.f, mx = 0.f;
+  if (t < T)
+    for (int c = 0; c < DENSE_CHUNKS; ++c) {
+      const float* o = part + ((size_t)t * DENSE_CHUNKS + c) * 4;
+      sq += o[0]; ab += o[1]; ro += o[2]; mx = fmaxf(mx, o[3]);
+    }
+  const float rms = sqrtf(sq / (float)frame_elems);
+  if (t < T) frame_rms[t] = rms;
+  s_l12[t] = t < T ? rms : 0.f; s_ab[t] = ab; s_ro[t] = ro; s_mx[t] = mx;
+  __syncthreads();
+  if (t == 0 && scalars) {
+    float l12 = 0.f, a = 0.f, r = 0.f, m = 0.f;
+    for (int i = 0; i < T; ++i) { l12 += s_l12[i]; a += s_ab[i]; r += s_ro[i]; m = fmaxf(m, s_mx[i]); }
+    const float N = (float)T * (float)frame_elems;
+    scalars[0] = l12 + 1e-12f; scalars[1] = a / N; scalars[2] = r / N; scalars[3] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_adam_kernel(const flk_dense_adam_args a, int frame_elems, const float* frame_rms,
+                                                         const float* g_adv, float* delta, float* m, float* v) {
+  const int t = blockIdx.y;
+  const float rms = frame_rms[t];
+  // sqrt'(0) is unbounded in the reference too (tf.sqrt gradient at 0 -> inf); delta is initialised to 1e-8 for that reason
+  const float rcoef = a.beta / ((float)frame_elems * rms);
+  const float bc1 = 1.f - powf(a.adam_b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.adam_b2, (float)a.step));
+  const float lr_tf = a.lr * bc2s / bc1;
+  const size_t base = (size_t)t * frame_elems;
+  const int n4 = frame_elems / 4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+    const float4 d = ((const float4*)(delta + base))[i], g4 = ((const float4*)(g_adv + base))[i];
+    float4 mm = ((const float4*)(m + base))[i], vv = ((const float4*)(v + base))[i];
+    float dd[4] = {d.x, d.y, d.z, d.w};
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    float mv[4] = {mm.x, mm.y, mm.z, mm.w}, vvv[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g = a.g_scale * gg[k] + rcoef * dd[k];
+      mv[k] = a.adam_b1 * mv[k] + (1.f - a.adam_b1) * g;
+      vvv[k] = a.adam_b2 * vvv[k] + (1.f - a.adam_b2) * g * g;
+      dd[k] = a.torch_dialect ? dd[k] - (a.lr / bc1) * mv[k] / (sqrtf(vvv[k]) / bc2s + a.adam_eps)
+                              : dd[k] - lr_tf * mv[k] / (sqrtf(vvv[k]) + a.adam_eps);
+    }
+    ((float4*)(delta + base))[i] = make_float4(dd[0], dd[1], dd[2], dd[3]);
+    ((float4*)(m + base))[i] = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    ((float4*)(v + base))[i] = make_float4(vvv[0], vvv[1], vvv[2], vvv[3]);
+  }
+}
+
+extern "C" int64_t flk_dense_adam_scratch_bytes(int T, int H, int W) {
+  (void)H; (void)W;
+  return T > 0 ? (int64_t)(T * DENSE_CHUNKS * 4 + T) * sizeof(float) : 0;
+}
+
+extern "C" int flk_perturb_dense_l12_adam(const flk_dense_adam_args* a, const float* g_adv, float* delta, float* m, float* v,
+                                          float* scalars, float* scratch, void* stream) {
+  FLK_REQUIRE(a && g_adv && delta && m && v && scratch, "flk_perturb_dense_l12_adam: null argument");
+  FLK_REQUIRE(a->T > 0 && a->T <= 1024 && a->H > 0 && a->W > 0 && (a->H * a->W * 3) % 4 == 0, "flk_perturb_dense_l12_adam: bad dims");
+  FLK_REQUIRE(a->step >= 1, "flk_perturb_dense_l12_adam: step is 1-based");
+  const int fe = a->H * a->W * 3;
+  float* part = scratch;
+  float* frame_rms = scratch + (size_t)a->T * DENSE_CHUNKS * 4;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(dense_frame_stats, dim3(DENSE_CHUNKS, a->T), dim3(256), 0, s, delta, fe, part);
+  hipLaunchKernelGGL(dense_frame_finish, dim3(1), dim3(1024), 0, s, part, a->T, fe, frame_rms, scalars);
+  hipLaunchKernelGGL(dense_adam_kernel, dim3(64, a->T), dim3(256), 0, s, *a, fe, frame_rms, g_adv, delta, m, v);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}

@@ -118,7 +118,7 @@ class FlickerI3D:
         labels = true labels (untargeted) or the target class per clip (targeted).  Returned scalars are the
         PRE-update values, as the reference fetches them together with train_op."""
         if self.dense:
-            raise NotImplementedError("dense-delta (L12) Adam is not built yet; use the flicker attack")
+            return self._step_dense(x, labels, lr, beta1, margin, targeted, use_logits, improve_loss, cyclic, update)
         x = self._check_x(x)
         cyclic = self.cyclic_flag if cyclic is None else cyclic
         cyclic_pert = self.cyclic_pert_flag if cyclic_pert is None else cyclic_pert
@@ -146,6 +146,34 @@ class FlickerI3D:
             res.update(reg_loss=sc[0], norm_reg=sc[1], diff_norm_reg=sc[2], laplacian_norm_reg=sc[3], thickness=sc[4],
                        roughness=sc[5], pert_max=sc[6], pert_min=sc[7], total_loss=res["adv_loss"] + beta0 * sc[0],
                        thickness_relative=sc[4] / 2 * 100, roughness_relative=sc[5] / 2 * 100)
+        return res
+
+    def _step_dense(self, x, labels, lr, beta1, margin, targeted, use_logits, improve_loss, cyclic, update):
+        """kinetics_i3d_L12 (kinetics_i3d_utils.py:308-521) with loss = adv + beta1 * L12 (i3d_adversarial_main_universal.py:129-133):
+        dense delta [T,224,224,3]; the all-reduce payload is the full dense gradient (38.5 MB at T=64: bandwidth-bound)."""
+        x = self._check_x(x)
+        a = self._apply_args(x, 1.0, self.cyclic_flag if cyclic is None else cyclic, 0)
+        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
+        self.net.forward(self._xs2d, self._logits)
+        gbatch = self.B * self.world
+        sm, dl, pc = ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
+                                          targeted=targeted, margin=margin, mean_scale=1.0 / gbatch)
+        self.net.backward(dl, self._gx)
+        if not hasattr(self, "_gdense"):
+            self._gdense = torch.empty_like(self.eps_rgb)
+        ops.perturb_grad_reduce(a, self._gx, self._gdense)
+        tail = pc[:, :3].sum(0)
+        if self.world > 1:
+            torch.distributed.all_reduce(self._gdense, group=self.pg)
+            torch.distributed.all_reduce(tail, group=self.pg)
+        res = StepResult(adv_loss=tail[0].clone(), softmax=sm, label_prob=pc[:, 1], argmax=pc[:, 3].to(torch.int64),
+                         prob_to_min=(tail[2] if targeted else tail[1]) / gbatch, prob_to_max=(tail[1] if targeted else tail[2]) / gbatch)
+        res["is_adversarial"] = (res["argmax"] == labels).all() if targeted else (res["argmax"] != labels).all()
+        if update:
+            self.adam_t += 1
+            sc = ops.perturb_dense_l12_adam(self._gdense, self.eps_rgb, self.adam_m, self.adam_v, self.adam_t, dialect="tf", beta=beta1, lr=lr).clone()
+            res.update(reg_loss=sc[0], L12=sc[0], thickness=sc[1], roughness=sc[2], pert_max=sc[3], total_loss=res["adv_loss"] + beta1 * sc[0],
+                       thickness_relative=sc[1] / 2 * 100, roughness_relative=sc[2] / 2 * 100)
         return res
 
     def delta_gradient(self):

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (FLK_BF16, FLK_F32, AdamArgs, ApplyArgs, ConvArgs, LossArgs, PoolArgs, check, dtype_code, load, ptr,
+from ._lib import (FLK_BF16, FLK_F32, AdamArgs, ApplyArgs, ConvArgs, DenseAdamArgs, LossArgs, PoolArgs, check, dtype_code, load, ptr,
                    stream_ptr, torch_dtype)
 
 
@@ -179,6 +179,23 @@ def perturb_reg_adam(g_adv, delta, m, v, step, *, dialect="tf", beta0=1.0, beta1
     if scalars is None:
         scalars = torch.empty(8, dtype=torch.float32, device="cuda")
     check(load().flk_perturb_reg_adam(C.byref(a), ptr(g_adv), ptr(delta), ptr(m), ptr(v), ptr(scalars), stream_ptr()))
+    return scalars
+
+
+def perturb_dense_l12_adam(g_adv, delta, m, v, step, *, dialect="tf", beta=1.0, g_scale=1.0, lr=1e-3, adam=(0.9, 0.999, 1e-8),
+                           scalars=None, scratch=None):
+    """dense delta [T,H,W,3]: L12 regulariser gradient + Adam (kinetics_i3d_L12); returns scalars {L12, thickness, roughness, max}"""
+    T, H, W, _ = delta.shape
+    a = DenseAdamArgs()
+    a.T, a.H, a.W, a.torch_dialect = T, H, W, int(dialect == "torch")
+    a.beta, a.g_scale, a.lr = beta, g_scale, lr
+    a.adam_b1, a.adam_b2, a.adam_eps = adam
+    a.step = int(step)
+    if scalars is None:
+        scalars = torch.empty(4, dtype=torch.float32, device="cuda")
+    if scratch is None:
+        scratch = torch.empty(load().flk_dense_adam_scratch_bytes(T, H, W) // 4, dtype=torch.float32, device="cuda")
+    check(load().flk_perturb_dense_l12_adam(C.byref(a), ptr(g_adv), ptr(delta), ptr(m), ptr(v), ptr(scalars), ptr(scratch), stream_ptr()))
     return scalars
 
 

@@ -162,6 +162,24 @@ typedef struct {
 int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, float* delta, float* m, float* v,
                          float* scalars, void* stream);
 
+/* Dense-delta ("sparse adversarial perturbations" baseline, kinetics_i3d_L12, kinetics_i3d_utils.py:308-521): delta is
+ * [T,H,W,3] (init 1e-8, no +-0.4 clip), regulariser L12 = sum_t sqrt(mean_{hwc} delta_t^2) + 1e-12 (:409; torch dialect
+ * model.py:211-214), loss = adv + beta1 * L12 (i3d_adversarial_main_universal.py:129-133), TF or torch Adam.
+ * Two HBM-bound passes: per-frame sum of squares (deterministic two-stage reduction into frame_sq[T], fp32), then the
+ * fused gradient + Adam update streaming delta, m, v, g_adv once (5 fp32 streams = 193 MB at T=64).
+ * scalars[4] = {L12, thickness, roughness, max|delta|} of the PRE-update delta.  scratch: flk_dense_adam_scratch_bytes(). */
+typedef struct {
+  int T, H, W;
+  int torch_dialect;
+  float beta;                /* weight of L12 in the loss */
+  float g_scale;
+  float lr, adam_b1, adam_b2, adam_eps;
+  int step;
+} flk_dense_adam_args;
+int64_t flk_dense_adam_scratch_bytes(int T, int H, int W);
+int flk_perturb_dense_l12_adam(const flk_dense_adam_args* a, const float* g_adv, float* delta, float* m, float* v,
+                               float* scalars, float* scratch, void* stream);
+
 /* Loss head: softmax + adversarial loss + d(loss)/d(logits) (kinetics_i3d_utils.py:152-169,253-307;
  * model.py:177-250).  per_clip[b*4..] = {loss_b, label_prob, max_non_label_prob, argmax}. */
 typedef struct {

@@ -44,14 +44,13 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     cfg = cfgmod.load_config(a.config)
     c = cfg[a.section]
-    if not c.get("FLICKERING_ATTACK", True):
-        raise NotImplementedError("FLICKERING_ATTACK: False (dense L12 baseline) needs the dense-delta Adam kernel (not built yet)")
+    dense = not c.get("FLICKERING_ATTACK", True)      # False: dense "sparse perturbations" baseline, regulariser beta1 * L12
     T = a.frames or cfg.MODEL.FRAMES
     B = int(c.BATCH_SIZE)
     classes = cfgmod.load_kinetics_classes(cfg.DATA.LABEL_MAP_PATH)
     target_id = classes.index(c.TARGETED_CLASS) if c.TARGETED_ATTACK else None
     W = dict(np.load(cfg.MODEL.WEIGHTS_NPZ)) if cfg.MODEL.WEIGHTS_NPZ else i3d_spec.synthetic_i3d_weights(42)
-    eng = FlickerI3D(W, batch_size=B, frames=T, dtype=a.dtype or cfg.MODEL.DTYPE, device=local_rank,
+    eng = FlickerI3D(W, batch_size=B, frames=T, dtype=a.dtype or cfg.MODEL.DTYPE, device=local_rank, dense_delta=dense,
                      cyclic_flag_default_c=float(bool(c.CYCLIC_ATTACK)), cyclic_pert_flag_default_c=float(bool(c.get("CYCLIC_PERTURBATION_ATTACK", False))))
     train_files = tio.list_tfrecords(c.TF_RECORDS_TRAIN_PATH, c.get("NUM_OF_TRAIN_TF_RECORDS"))
     val_files = tio.list_tfrecords(c.TF_RECORDS_VAL_PATH, c.get("NUM_OF_VAL_TF_RECORDS"))
@@ -98,9 +97,9 @@ def main():
             step += 1; nb += 1
             if step % 10 == 0 or step == max_steps:
                 h = r.host()
-                for k, s in (("total_loss_l", "total_loss"), ("adv_loss_l", "adv_loss"), ("reg_loss_l", "reg_loss"),
-                             ("thickness_l", "thickness_relative"), ("roughness_l", "roughness_relative")):
-                    hist[k].append(float(h[s]))
+                for k, s_ in (("total_loss_l", "total_loss"), ("adv_loss_l", "adv_loss"), ("reg_loss_l", "reg_loss"),
+                              ("thickness_l", "thickness_relative"), ("roughness_l", "roughness_relative")):
+                    hist[k].append(float(h[s_]))
                 if rank == 0:
                     print(f"step {step}: total {h['total_loss']:.5f} adv {h['adv_loss']:.5f} reg {h['reg_loss']:.6f} thickness "
                           f"{h['thickness_relative']:.3f}% roughness {h['roughness_relative']:.3f}% prob_to_min {h['prob_to_min']:.4f}", flush=True)

@@ -180,3 +180,25 @@ def test_reg_adam_torch_dialect_golden_trajectory(ops, golden):
         loss = pc[:, 0].sum().item() + sc[0].item()
         np.testing.assert_allclose([loss, pc[:, 0].sum().item(), sc[0].item()], g["mini_losses"][step - 1], rtol=2e-4, atol=1e-7)
         np.testing.assert_allclose(d.cpu().t().reshape(3, 16, 1, 1).numpy(), g["mini_traj"][step - 1], rtol=2e-4, atol=3e-7)
+
+
+@pytest.mark.parametrize("dialect", ["tf", "torch"])
+def test_dense_l12_adam(ops, dialect):
+    """dense delta (kinetics_i3d_L12 / model.py:211-214): loss = g.delta + beta * (sum_t sqrt(mean_hwc delta_t^2) + 1e-12); 3 Adam steps"""
+    T, H, W = 6, 8, 10
+    rng = np.random.default_rng(4)
+    d = torch.from_numpy(rng.uniform(-0.1, 0.1, (T, H, W, 3)).astype(np.float32))
+    d[2] = 1e-8                                              # a frame at the reference's initial value
+    m, v = torch.zeros_like(d), torch.zeros_like(d)
+    dg, mg, vg = d.clone().cuda(), m.clone().cuda(), v.clone().cuda()
+    beta = 0.7
+    for step in range(1, 4):
+        gadv = torch.from_numpy(rng.standard_normal((T, H, W, 3)).astype(np.float32) * 1e-3)
+        dv = d.clone().requires_grad_(True)
+        l12 = am.tf_l12(dv)
+        (g,) = torch.autograd.grad((gadv * dv).sum() + beta * l12, dv)
+        sc = ops.perturb_dense_l12_adam(gadv.cuda(), dg, mg, vg, step, dialect=dialect, beta=beta).cpu()
+        r = am.tf_regularizers(d)
+        np.testing.assert_allclose(sc.numpy(), [l12.item(), r["thickness"].item(), r["roughness"].item(), d.abs().max().item()], rtol=2e-5)
+        d, m, v = (am.tf_adam_step if dialect == "tf" else am.torch_adam_step)(d, g, m, v, step)
+        torch.testing.assert_close(dg.cpu(), d, rtol=2e-4, atol=1e-7)

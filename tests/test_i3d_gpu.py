@@ -169,3 +169,24 @@ def test_bf16_step_runs_and_tracks_fp32(setup):
     cos = float(torch.nn.functional.cosine_similarity(out["bf16"][2].flatten(), out["f32"][2].flatten(), 0))
     print(f"bf16 vs f32: adv {out['bf16'][0]:.5f} vs {out['f32'][0]:.5f}; first-step sign agreement {agree:.3f}; grad cosine {cos:.4f}")
     assert agree >= 0.8 and cos > 0.85
+
+
+def test_dense_delta_step(setup):
+    """dense-delta baseline (kinetics_i3d_L12, kinetics_i3d_utils.py:308-521): one step from delta = 1e-8; the adversarial loss
+    matches the oracle, L12 = T * 1e-8 + 1e-12, and the first TF-Adam step moves every pixel by lr against its gradient sign"""
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, Wt, xu, _, _ = setup
+    x = xu.float() / 128 - 1
+    d = torch.full((T, 224, 224, 3), 1e-8, requires_grad=True)
+    lg = i3d_ref.i3d_logits(am.tf_apply(x, d, clip_delta=False), Wt[torch.float32])
+    label = lg.argmax(-1)
+    adv, _, _ = am.tf_improve_adversarial_loss(lg, label, 0.05, False, False)
+    (g,) = torch.autograd.grad(adv + 0.5 * am.tf_l12(d), d)
+    eng = FlickerI3D(W, batch_size=1, frames=T, dtype="f32", dense_delta=True)
+    res = eng.step(xu.cuda(), label.cuda(), lr=1e-3, beta1=0.5).host()
+    assert res["adv_loss"] == pytest.approx(adv.item(), rel=1e-3, abs=1e-6)
+    assert res["L12"] == pytest.approx(T * 1e-8 + 1e-12, rel=1e-3)
+    moved = eng.perturbation.cpu() - 1e-8
+    big = g.abs() > 0.05 * g.abs().max()
+    assert (torch.sign(moved[big]) == -torch.sign(g[big])).float().mean() > 0.995
+    assert float(moved.abs().max()) == pytest.approx(1e-3, rel=1e-2)
