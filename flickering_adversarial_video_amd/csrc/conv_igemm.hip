@@ -35,6 +35,8 @@ struct ConvKP {
   int Th, Hh, Wh, P, plane_b;
   int nslab, ntaps, cout_frags;
   int in2_ld, in2_coff, cin1, nslab1, out2_ld, out2_coff, cout1;
+  unsigned m_HW, m_Wh, m_hw, m_Wt;   // ceil(2^20 / d): exact x / d for x * d < 2^20 (x < 1024 here)
+  int ntile_n;
 };
 
 template <typename T> struct Prec;
@@ -76,6 +78,7 @@ template <> struct Prec<float> {
 };
 
 __device__ static inline int plane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
+__device__ static inline int fdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
 
 constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pairs staged per thread (16)
 
@@ -99,12 +102,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   const int q = lane >> 4, m = lane & 15;
   const int wm = wave % WM, wn = wave / WM;
 
-  int bid = blockIdx.x;
+  // 1-D grid.  Workgroups that share an activation tile (the N tiles of one position tile) get ids 8 apart: blocks b and
+  // b + 8 land on the same XCD (round-robin dispatch), so the tile is fetched into that XCD's L2 once.  Speed only.
+  int bid, ntile;
+  {
+    const int per = 8 * p.ntile_n, id = blockIdx.x;
+    const int grp = id / per, r = id - grp * per;
+    ntile = r >> 3;
+    bid = grp * 8 + (r & 7);
+  }
+  if (bid >= p.B * p.nTt * p.nTh * p.nTw) return;     // tail of the last group of 8 (whole workgroup, before any barrier)
   const int tw = bid % p.nTw; bid /= p.nTw;
   const int th = bid % p.nTh; bid /= p.nTh;
   const int tt = bid % p.nTt;
   const int b = bid / p.nTt;
-  const int ntile = blockIdx.y;
   const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * p.Wt;
   const int it0 = ot0 * p.st - p.pt, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
 
@@ -118,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       const int hp = (tid >> 2) + 64 * n;
       int g = -2;
       if (hp < p.P) {
-        const int a = hp / HW, rem = hp - a * HW;
-        const int bq = rem / p.Wh, c = rem - bq * p.Wh;
+        const int a = fdiv(hp, p.m_HW), rem = hp - a * HW;
+        const int bq = fdiv(rem, p.m_Wh), c = rem - bq * p.Wh;
         const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
         g = -1;
         if ((unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
@@ -139,8 +150,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     int pos = 0;
     if (r < p.rows) {
       const int hw = p.Ht * p.Wt;
-      const int rt = r / hw, rem = r - rt * hw;
-      const int rh = rem / p.Wt, rw = rem - rh * p.Wt;
+      const int rt = fdiv(r, p.m_hw), rem = r - rt * hw;
+      const int rh = fdiv(rem, p.m_Wt), rw = rem - rh * p.Wt;
       pos = ((rt * p.st) * p.Hh + rh * p.sh) * p.Wh + rw * p.sw;
     }
     rowpos[i] = pos * 16 + plane_off(q, p.plane_b);
@@ -257,8 +268,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     const int r = wm * 64 + i * 16 + m;
     if (r >= p.rows) continue;
     const int hw = p.Ht * p.Wt;
-    const int rt = r / hw, rem = r - rt * hw;
-    const int rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int rt = fdiv(r, p.m_hw), rem = r - rt * hw;
+    const int rh = fdiv(rem, p.m_Wt), rw = rem - rh * p.Wt;
     const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
     if (ot >= p.To || oh >= p.Ho || ow >= p.Wo) continue;
     const size_t opos = ((size_t)(b * p.OT + ot * p.ost + p.oot) * p.OH + oh * p.osh + p.ooh) * p.OW + ow * p.osw + p.oow;
@@ -428,9 +439,13 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
     kp.out2 = kp.out; kp.cout1 = a->cout;
   }
   const size_t lds = 4 * (size_t)kp.plane_b + 64 + 2 * (size_t)nf * 1024;
-  const long gx = (long)a->B * kp.nTt * kp.nTh * kp.nTw;
+  auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
+  kp.m_HW = magic(kp.Hh * kp.Wh); kp.m_Wh = magic(kp.Wh); kp.m_hw = magic(kp.Ht * kp.Wt); kp.m_Wt = magic(kp.Wt);
+  kp.ntile_n = ntile_n;
+  const long ptiles = (long)a->B * kp.nTt * kp.nTh * kp.nTw;
+  const long gx = (ptiles + 7) / 8 * 8 * ntile_n;
   FLK_REQUIRE(gx < (1l << 31), "flk_conv3d: grid too large");
-  dim3 grid((unsigned)gx, (unsigned)ntile_n);
+  dim3 grid((unsigned)gx);
   hipStream_t s = (hipStream_t)stream;
 #define FLK_LAUNCH(TT, NFv, WNv) if (nf == NFv && wn == WNv) return launch<TT, NFv, WNv>(kp, grid, lds, s)
   if (dtype == FLK_BF16) {
