@@ -95,8 +95,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   constexpr int WM = 4 / WN, NFW = NF / WN;   // waves along M; channel fragments per wave
   static_assert(NF % WN == 0 && 4 * NFW >= EPL, "wave tile too narrow for 16-byte epilogue groups");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // small halos (P <= 256: all 1x1x1 convolutions) keep TWO halo images so the K loop needs one barrier per slab
+  const bool small_halo = p.P <= 256;
+  const int halo_bytes = 4 * p.plane_b + 64;
   char* const halo = smem;
-  char* const wbuf = smem + 4 * p.plane_b + 64;
+  char* const wbuf = smem + (small_halo ? 2 : 1) * halo_bytes;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = lane >> 4, m = lane & 15;
@@ -195,7 +198,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   // slab s+1 is fetched into named registers while slab s computes, so the K loop does not expose one global-load
   // latency per slab.  Larger halos are staged after the barrier (amortised over kt*kh*kw taps; the second resident
   // workgroup covers the stall).
-  const bool small_halo = p.P <= 256;
   uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
   auto prefetch = [&](int s) {
     const char* src; int ld;
@@ -205,14 +207,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   };
   if (small_halo) prefetch(0);
   for (int s = 0; s < p.nslab; ++s) {
-    __syncthreads();  // every wave has finished reading the previous slab's halo
+    const int hsel = small_halo ? (s & 1) * halo_bytes : 0;
     if (small_halo) {
-      if (goff[0] != -2) *(uint4*)(hdst) = pre0;
-      if (goff[1] != -2) *(uint4*)(hdst + 1024) = pre1;
-      if (goff[2] != -2) *(uint4*)(hdst + 2048) = pre2;
-      if (goff[3] != -2) *(uint4*)(hdst + 3072) = pre3;
+      // image (s & 1) was last read while computing slab s-2; every wave has passed the barrier of slab s-1 since
+      char* const hd = hdst + hsel;
+      if (goff[0] != -2) *(uint4*)(hd) = pre0;
+      if (goff[1] != -2) *(uint4*)(hd + 1024) = pre1;
+      if (goff[2] != -2) *(uint4*)(hd + 2048) = pre2;
+      if (goff[3] != -2) *(uint4*)(hd + 3072) = pre3;
       if (s + 1 < p.nslab) prefetch(s + 1);
     } else {
+      __syncthreads();  // every wave has finished reading the previous slab's halo
       const char* src; int ld;
       const bool chvalid = slab_src(s, src, ld);
 #pragma unroll
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
           if (wave_active) {
             frag bf[4], af[NFW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + rowpos[i] + tapoff);
+            for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + hsel + rowpos[i] + tapoff);
 #pragma unroll
             for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
             __builtin_amdgcn_sched_barrier(0);   // keep every fragment read ahead of the MFMA chain (counted lgkmcnt waits)
@@ -438,7 +443,7 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   } else {
     kp.out2 = kp.out; kp.cout1 = a->cout;
   }
-  const size_t lds = 4 * (size_t)kp.plane_b + 64 + 2 * (size_t)nf * 1024;
+  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + 2 * (size_t)nf * 1024;
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
   kp.m_HW = magic(kp.Hh * kp.Wh); kp.m_Wh = magic(kp.Wh); kp.m_hw = magic(kp.Ht * kp.Wt); kp.m_Wt = magic(kp.Wt);
   kp.ntile_n = ntile_n;
