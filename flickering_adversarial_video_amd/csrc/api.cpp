@@ -52,7 +52,11 @@ int flk_conv_weights_create_impl(const float* w, int kt, int kh, int kw, int cin
         const int ntile = F / nf, f = F % nf;
         for (int lane = 0; lane < 64; ++lane) {
           const int q = lane >> 4, m = lane & 15;
-          const int co = ntile * 16 * nf + (m >> 2) * 4 * nf + f * 4 + (m & 3);
+          // channel owned by accumulator row m = 4q + r of fragment f.  16-byte store group G = f / (epl/4) of lane group q
+          // covers channels [G*4*epl + q*epl, +epl): in ONE store instruction the four lane groups q write four consecutive
+          // 16-byte pieces (64 contiguous bytes per position).
+          const int fpg = epl / 4, G = f / fpg;
+          const int co = ntile * 16 * nf + G * 4 * epl + (m >> 2) * epl + (f % fpg) * 4 + (m & 3);
           for (int j = 0; j < epl; ++j, ++o) {
             int ci = s * slabc + q * epl + j;          // position in the (segment-padded) K order -> channel
             bool civalid = ci < ocin;

@@ -264,10 +264,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     }
   }
 
-  // ---- epilogue: lane = position (m of fragment i), channels ntile*16NF + q*4NF + wn*4NFW + [0, 4NFW) ----
+  // ---- epilogue: lane = position (m of fragment i); lane group q owns EPL channels of every 4*EPL-channel store group ----
   if (!wave_active) return;
-  const int cbase = ntile * 16 * NF + q * 4 * NF + wn * 4 * NFW;
+  // store group g of this wave = global group wn*NG + g: channels ntile*16NF + (wn*NG + g)*4*EPL + q*EPL + [0, EPL)
   constexpr int NG = 4 * NFW / EPL;   // 16-byte channel groups per lane
+  const int cbase = ntile * 16 * NF + wn * NG * 4 * EPL + q * EPL;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = wm * 64 + i * 16 + m;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     const size_t opos = ((size_t)(b * p.OT + ot * p.ost + p.oot) * p.OH + oh * p.osh + p.ooh) * p.OW + ow * p.osw + p.oow;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int c0 = cbase + g * EPL;
+      const int c0 = cbase + g * 4 * EPL;
       if (c0 >= p.cout) continue;
       float v[EPL];
 #pragma unroll

@@ -36,9 +36,11 @@ static inline int flk_esize(int dtype) { return dtype == FLK_BF16 ? 2 : 4; }
 // Layout on device: [nslab][ntaps][cout_frags][64 lanes][EPL elems] where EPL = 16 B / elem size,
 // a slab = 4*EPL input channels (one 64-byte run per position) and fragment F = ntile*nf + f of
 // lane l=(q=l>>4, m=l&15) holds, for j < EPL,
-//     W[tap][cin = slab*4*EPL + q*EPL + j][cout = ntile*16*nf + (m>>2)*4*nf + f*4 + (m&3)]
-// (zero outside cin/cout).  With this permutation an MFMA accumulator lane owns 4*nf CONSECUTIVE
-// output channels of one position, so the epilogue issues 16-byte stores.
+//     W[tap][cin = slab*4*EPL + q*EPL + j][cout = ntile*16*nf + G*4*EPL + (m>>2)*EPL + (f % (EPL/4))*4 + (m&3)],
+//     G = f / (EPL/4)
+// (zero outside cin/cout).  With this permutation accumulator lane group q' = m>>2 ... of store group G owns EPL
+// consecutive output channels (one 16-byte access) and the four lane groups of a wave cover 64 contiguous bytes of a
+// position in ONE instruction.
 struct flk_conv_weights {
   void* dev = nullptr;
   int kt = 0, kh = 0, kw = 0, cin = 0, cout = 0;   // of THIS operator (after optional transpose)
