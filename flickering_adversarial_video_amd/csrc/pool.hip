@@ -5,6 +5,7 @@
 //   backward: gather form -- every INPUT position sums the output gradients whose saved argmax points
 //             at it.  No atomics, bitwise reproducible.  Optional accumulate (+add) and relu mask of the
 //             producing layer (mask > 0) fused in.
+#include <stdlib.h>
 #include "flk_internal.h"
 
 struct PoolKP {
@@ -369,6 +370,73 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_bwd(const PoolTP p) {
   }
 }
 
+// Scatter form of the stride-1 backward: every OUTPUT window adds its gradient to the cell its argmax points at -- one
+// LDS float atomic per element instead of kt*kh*kw index compares per input cell (the gather form above is VALU-bound).
+// A workgroup owns a tile of INPUT cells (fp32 accumulators in LDS) and walks the halo of windows that can reach it,
+// reading idx / gout straight from global memory.  The order of the <= kt*kh*kw fp32 additions per cell is not fixed
+// (atomics), so the last bit of a sum may differ between runs; the result is rounded to the storage type afterwards.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void maxpool_s1_scatter_bwd(const PoolTP p, unsigned m_khkw, unsigned m_kw) {
+  constexpr int EPL = PV<T>::EPL, SLABC = 4 * EPL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const acc = (float*)smem;                        // [chunk][row][EPL]
+  const PoolKP& k = p.k;
+  const int tid = threadIdx.x, ch = tid & 3;
+  int bid = blockIdx.x;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const bool chvalid = c0 < k.C;
+  const int i_t0 = tt * p.Tt, i_h0 = th * p.Ht, i_w0 = tw * p.Wt;
+  const int o_t0 = i_t0 - (k.kt - 1 - k.pt), o_h0 = i_h0 - (k.kh - 1 - k.ph), o_w0 = i_w0 - (k.kw - 1 - k.pw);
+  for (int i = tid; i < 4 * p.rows * EPL; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const int HW = p.Hh * p.Wh, khkw = k.kh * k.kw;
+  float* const myacc = acc + (size_t)ch * p.rows * EPL;
+  if (chvalid)
+    for (int hp = tid >> 2; hp < p.P; hp += 64) {
+      const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+      const int ot = o_t0 + a, oh = o_h0 + bq, ow = o_w0 + c;
+      if ((unsigned)ot >= (unsigned)k.To || (unsigned)oh >= (unsigned)k.Ho || (unsigned)ow >= (unsigned)k.Wo) continue;
+      const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+      int id[EPL];
+      float go[EPL];
+      PV<T>::ldidx(k.idx + opos * k.C + c0, id);
+      PV<T>::ld(k.gout + (opos * k.gout_ld + k.gout_coff + c0) * sizeof(T), go);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const int tap = id[e];                                    // 255 ("no cell") decodes out of range below
+        const int dt = (int)(((unsigned)tap * m_khkw) >> 20), r2 = tap - dt * khkw;
+        const int dh = (int)(((unsigned)r2 * m_kw) >> 20), dw = r2 - dh * k.kw;
+        // window o covers cells o - pad + d; local cell = halo coordinate - (k-1) + d
+        const int lt = a - (k.kt - 1) + dt, lh = bq - (k.kh - 1) + dh, lw = c - (k.kw - 1) + dw;
+        if ((unsigned)lt < (unsigned)p.Tt && (unsigned)lh < (unsigned)p.Ht && (unsigned)lw < (unsigned)p.Wt && dt < k.kt)
+          atomicAdd(&myacc[((lt * p.Ht + lh) * p.Wt + lw) * EPL + e], go[e]);
+      }
+    }
+  __syncthreads();
+  if (!chvalid) return;
+  const int hw = p.Ht * p.Wt;
+  for (int r = tid >> 2; r < p.rows; r += 64) {
+    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
+    if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
+    float g[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) g[e] = myacc[r * EPL + e];
+    const size_t ipos = (((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw);
+    if (k.mask) {
+      float mk[EPL];
+      PV<T>::ld(k.mask + (ipos * k.mask_ld + k.mask_coff + c0) * sizeof(T), mk);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) g[e] = mk[e] > 0.f ? g[e] : 0.f;
+    }
+    PV<T>::st(k.gin + (ipos * k.gin_ld + k.gin_coff + c0) * sizeof(T), g);
+  }
+}
+
 // stride-1 SAME pooling with an odd window and enough reuse to pay for the LDS staging
 static bool use_tiled(const flk_pool_args* a) {
   return a->st == 1 && a->sh == 1 && a->sw == 1 && a->kt * a->kh * a->kw >= 8 && a->To == a->Ti && a->Ho == a->Hi &&
@@ -395,7 +463,17 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
     FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
+  static const bool use_gather = getenv("FLK_POOL_GATHER") != nullptr;     // bitwise-reproducible gather form on request
+  if (bwd && !use_gather) {
+    static bool attr3 = false;
+    if (!attr3) {
+      FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_scatter_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      attr3 = true;
+    }
+    auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
+    const size_t lds2 = (size_t)4 * tp.rows * EPL * sizeof(float);
+    hipLaunchKernelGGL(maxpool_s1_scatter_bwd<T>, grid, dim3(256), lds2, s, tp, magic(a->kh * a->kw), magic(a->kw));
+  } else if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
   else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
     static bool attr2 = false;
     if (!attr2) {

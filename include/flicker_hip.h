@@ -93,7 +93,9 @@ int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, voi
 
 /* tf.nn.max_pool3d SAME (i3d.py:174,189,212,252,398): padded cells never win; argmax = FIRST
  * maximum in (t,h,w) scan order, stored as a uint8 window index for the backward pass.
- * MaxPool3DGrad: gather form (deterministic), optional add and relu-mask like flk_conv3d. */
+ * MaxPool3DGrad: gather form (bitwise reproducible) for strided windows; stride-1 odd windows (the Inception branch-3 pool)
+ * use an LDS scatter with float atomics (<= kt*kh*kw fp32 additions per cell in arbitrary order; FLK_POOL_GATHER=1 selects
+ * the reproducible gather form).  Optional relu-mask like flk_conv3d. */
 typedef struct {
   const void* in; int in_ld, in_coff; int C;
   int B, Ti, Hi, Wi;

@@ -164,7 +164,8 @@ def test_maxpool_fwd_bwd(ops, dtype, k, s, dims):
     out2, idx2, ctx2 = ops.maxpool3d(x.to(dtype).cuda(), k, s, relu_input=True)
     torch.testing.assert_close(out2.float().cpu(), out.float().cpu(), rtol=0, atol=0)
     nomask = ops.maxpool3d_bwd(ctx2, g.to(dtype).cuda()).float().cpu()
-    torch.testing.assert_close(nomask, masked, rtol=0, atol=0)
+    # stride-1 windows use the scatter kernel (LDS float atomics): the order of the <= 27 additions per cell is not fixed
+    torch.testing.assert_close(nomask, masked, rtol=1e-5, atol=1e-6 * float(g.abs().max()))
 
 
 BLOCKS = {"small": (1, 2, 7, 7, 64, (32, 24, 48, 16, 32, 16)),
