@@ -38,17 +38,21 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const char* y, int ld, i
   if (grp == 0 && c < C) feat[(size_t)b * C + c] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
 }
 
-// logits[b,n] = bias[n] + sum_c feat[b,c] * W[c,n]     grid (ceil(N/256), B)
+// logits[b,n] = bias[n] + sum_c feat[b,c] * W[c,n]     grid (ceil(N/64), B): 64 outputs x 4 channel groups per workgroup
 __global__ __launch_bounds__(256) void head_fc_kernel(const float* feat, const float* W, const float* bias, int C, int N,
                                                       float* logits) {
-  const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
   __shared__ float sf[2048];
+  __shared__ float part[4][64];
+  const int nl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl, b = blockIdx.y;
   for (int c = threadIdx.x; c < C; c += 256) sf[c] = feat[(size_t)b * C + c];
   __syncthreads();
-  if (n >= N) return;
-  float acc = bias ? bias[n] : 0.f;
-  for (int c = 0; c < C; ++c) acc += sf[c] * W[(size_t)c * N + n];
-  logits[(size_t)b * N + n] = acc;
+  float acc = 0.f;
+  if (n < N)
+    for (int c = grp; c < C; c += 4) acc += sf[c] * W[(size_t)c * N + n];
+  part[grp][nl] = acc;
+  __syncthreads();
+  if (grp == 0 && n < N) logits[(size_t)b * N + n] = (bias ? bias[n] : 0.f) + part[0][nl] + part[1][nl] + part[2][nl] + part[3][nl];
 }
 
 // dfeat[b,c] = sum_n dlogits[b,n] * W[c,n]      grid (ceil(C/256), B)
@@ -85,7 +89,7 @@ int flk_head_forward(const void* y, int ld, int coff, int C, int B, int Tn, int 
   dim3 g1((C + 63) / 64, B);
   if (dtype == FLK_BF16) hipLaunchKernelGGL(head_pool_kernel<bf16_t>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
   else hipLaunchKernelGGL(head_pool_kernel<float>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
-  hipLaunchKernelGGL(head_fc_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, feat, W, bias, C, N, logits);
+  hipLaunchKernelGGL(head_fc_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, feat, W, bias, C, N, logits);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

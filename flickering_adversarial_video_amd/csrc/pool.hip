@@ -1,10 +1,13 @@
 // tf.nn.max_pool3d (SAME) forward and MaxPool3DGrad, channels-last, 16-byte vectorised over channels.
-// HBM-bound elementwise kernels: one thread = one position x one 16-byte channel group.
+// HBM-bound kernels: one thread = one position x one 16-byte channel group.
 //   forward : first maximum in (t,h,w) scan order wins (strict >), padded cells never win
 //             (i3d.py:174,189,212,252,398); the winning window index is kept as one byte.
-//   backward: gather form -- every INPUT position sums the output gradients whose saved argmax points
-//             at it.  No atomics, bitwise reproducible.  Optional accumulate (+add) and relu mask of the
-//             producing layer (mask > 0) fused in.
+//   backward: default = scatter form (maxpool_scatter_bwd): a workgroup owns a tile of INPUT cells in LDS and every
+//             window that reaches the tile adds its gradient to the cell its saved argmax names.  bf16 mode sums in
+//             32-bit fixed point with integer LDS atomics (order-independent, bitwise reproducible); fp32 mode uses
+//             float LDS atomics (sum order not fixed: last-ulp differences between runs).
+//             FLK_POOL_GATHER=1 selects the gather forms (every input cell scans the windows containing it; fixed
+//             summation order in both precisions).  Optional relu mask of the producing layer (mask > 0) fused in.
 #include <stdlib.h>
 #include "flk_internal.h"
 
@@ -152,10 +155,20 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
 // conv_igemm.hip) and all window taps are LDS reads.
 struct PoolTP {
   PoolKP k;
-  int Tt, Ht, Wt, nTt, nTh, nTw, Th, Hh, Wh, P, plane_b, rows;
+  int Tt, Ht, Wt, nTt, nTh, nTw, Th, Hh, Wh, P, plane_b, rows, ntiles, nslab;
 };
 
 __device__ static inline int pplane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
+
+// 1-D grid -> (tile, channel slab).  Workgroups are dealt to the 8 XCDs round-robin, so the slabs of ONE tile are put
+// on consecutive slots of the SAME XCD: together they touch whole cache lines of every position while those lines
+// are still in that XCD's L2 (a slab is only 64 B of a position's row).
+__device__ static inline bool tile_slab_of_block(int ntiles, int nslab, int& tile, int& slab) {
+  const int bid = blockIdx.x, xcd = bid & 7, r = bid >> 3;
+  slab = r % nslab;
+  tile = (r / nslab) * 8 + xcd;
+  return tile < ntiles;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd(const PoolTP p) {
@@ -163,12 +176,13 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd(const PoolTP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PoolKP& k = p.k;
   const int tid = threadIdx.x, ch = tid & 3;
-  int bid = blockIdx.x;
+  int bid, cslab;
+  if (!tile_slab_of_block(p.ntiles, p.nslab, bid, cslab)) return;
   const int tw = bid % p.nTw; bid /= p.nTw;
   const int th = bid % p.nTh; bid /= p.nTh;
   const int tt = bid % p.nTt;
   const int b = bid / p.nTt;
-  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const int c0 = cslab * SLABC + ch * EPL;
   const bool chvalid = c0 < k.C;
   const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * p.Wt;
   const int it0 = ot0 - k.pt, ih0 = oh0 - k.ph, iw0 = ow0 - k.pw;
@@ -236,12 +250,13 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd_bf16(const PoolTP
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const PoolKP& k = p.k;
   const int tid = threadIdx.x, ch = tid & 3;
-  int bid = blockIdx.x;
+  int bid, cslab;
+  if (!tile_slab_of_block(p.ntiles, p.nslab, bid, cslab)) return;
   const int tw = bid % p.nTw; bid /= p.nTw;
   const int th = bid % p.nTh; bid /= p.nTh;
   const int tt = bid % p.nTt;
   const int b = bid / p.nTt;
-  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const int c0 = cslab * SLABC + ch * EPL;
   const bool chvalid = c0 < k.C;
   const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * p.Wt;
   const int it0 = ot0 - k.pt, ih0 = oh0 - k.ph, iw0 = ow0 - k.pw;
@@ -305,12 +320,13 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_bwd(const PoolTP p) {
   const PoolKP& k = p.k;
   char* const sidx = smem + 4 * p.plane_b + 64;            // [chunk][halo position][EPL bytes]
   const int tid = threadIdx.x, ch = tid & 3;
-  int bid = blockIdx.x;
+  int bid, cslab;
+  if (!tile_slab_of_block(p.ntiles, p.nslab, bid, cslab)) return;
   const int tw = bid % p.nTw; bid /= p.nTw;
   const int th = bid % p.nTh; bid /= p.nTh;
   const int tt = bid % p.nTt;
   const int b = bid / p.nTt;
-  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const int c0 = cslab * SLABC + ch * EPL;
   const bool chvalid = c0 < k.C;
   // tile of INPUT cells [i0, i0+tile); windows o with o - pad <= i <= o - pad + k-1  ->  o in [i - (k-1-pad), i + pad]
   const int i_t0 = tt * p.Tt, i_h0 = th * p.Ht, i_w0 = tw * p.Wt;
@@ -370,50 +386,107 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_bwd(const PoolTP p) {
   }
 }
 
-// Scatter form of the stride-1 backward: every OUTPUT window adds its gradient to the cell its argmax points at -- one
-// LDS float atomic per element instead of kt*kh*kw index compares per input cell (the gather form above is VALU-bound).
-// A workgroup owns a tile of INPUT cells (fp32 accumulators in LDS) and walks the halo of windows that can reach it,
-// reading idx / gout straight from global memory.  The order of the <= kt*kh*kw fp32 additions per cell is not fixed
-// (atomics), so the last bit of a sum may differ between runs; the result is rounded to the storage type afterwards.
+// Scatter form of the backward (any stride): every OUTPUT window adds its gradient to the cell its argmax points at --
+// one LDS atomic per element instead of kt*kh*kw index compares per input cell (the gather form above is VALU-bound).
+// A workgroup owns a tile of INPUT cells (accumulators in LDS) and walks the windows that can reach it, reading
+// idx / gout straight from global memory.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void maxpool_s1_scatter_bwd(const PoolTP p, unsigned m_khkw, unsigned m_kw) {
-  constexpr int EPL = PV<T>::EPL, SLABC = 4 * EPL;
+__global__ __launch_bounds__(256, 4) void maxpool_scatter_bwd(const PoolTP p, unsigned m_khkw, unsigned m_kw) {
+  constexpr int EPL = PV<T>::EPL, SLABC = 4 * EPL, UNR = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const acc = (float*)smem;                        // [chunk][row][EPL]
+  // accumulators [e][chunk][cell], plane stride RS = 16 (mod 64) floats: the 64 lanes of one ds_add_f32 (fixed e; 4
+  // chunks x 16 neighbouring cells) fall on 64 different banks instead of the 4-8 a [cell][e] layout would give
+  float* const acc = (float*)smem;
+  const int RS = p.plane_b;
   const PoolKP& k = p.k;
   const int tid = threadIdx.x, ch = tid & 3;
-  int bid = blockIdx.x;
+  int bid, cslab;
+  if (!tile_slab_of_block(p.ntiles, p.nslab, bid, cslab)) return;
   const int tw = bid % p.nTw; bid /= p.nTw;
   const int th = bid % p.nTh; bid /= p.nTh;
   const int tt = bid % p.nTt;
   const int b = bid / p.nTt;
-  const int c0 = blockIdx.y * SLABC + ch * EPL;
+  const int c0 = cslab * SLABC + ch * EPL;
   const bool chvalid = c0 < k.C;
   const int i_t0 = tt * p.Tt, i_h0 = th * p.Ht, i_w0 = tw * p.Wt;
-  const int o_t0 = i_t0 - (k.kt - 1 - k.pt), o_h0 = i_h0 - (k.kh - 1 - k.ph), o_w0 = i_w0 - (k.kw - 1 - k.pw);
-  for (int i = tid; i < 4 * p.rows * EPL; i += 256) acc[i] = 0.f;
-  __syncthreads();
-  const int HW = p.Hh * p.Wh, khkw = k.kh * k.kw;
-  float* const myacc = acc + (size_t)ch * p.rows * EPL;
-  if (chvalid)
-    for (int hp = tid >> 2; hp < p.P; hp += 64) {
-      const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
-      const int ot = o_t0 + a, oh = o_h0 + bq, ow = o_w0 + c;
-      if ((unsigned)ot >= (unsigned)k.To || (unsigned)oh >= (unsigned)k.Ho || (unsigned)ow >= (unsigned)k.Wo) continue;
-      const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
-      int id[EPL];
-      float go[EPL];
-      PV<T>::ldidx(k.idx + opos * k.C + c0, id);
-      PV<T>::ld(k.gout + (opos * k.gout_ld + k.gout_coff + c0) * sizeof(T), go);
+  // windows that touch the tile: o in [ceil((i0 + pad - k + 1) / s), floor((i0 + tile - 1 + pad) / s)], clipped to the grid
+  const int o_t0 = max(0, (i_t0 + k.pt - k.kt + k.st) / k.st), o_t1 = min(k.To - 1, (i_t0 + p.Tt - 1 + k.pt) / k.st);
+  const int o_h0 = max(0, (i_h0 + k.ph - k.kh + k.sh) / k.sh), o_h1 = min(k.Ho - 1, (i_h0 + p.Ht - 1 + k.ph) / k.sh);
+  const int o_w0 = max(0, (i_w0 + k.pw - k.kw + k.sw) / k.sw), o_w1 = min(k.Wo - 1, (i_w0 + p.Wt - 1 + k.pw) / k.sw);
+  const int nt = max(0, o_t1 - o_t0 + 1), nh = max(0, o_h1 - o_h0 + 1), nw = max(0, o_w1 - o_w0 + 1);
+  const int nhw = nh * nw, P = nt * nhw;
+  const float inv_hw = 1.0f / (float)max(nhw, 1), inv_w = 1.0f / (float)max(nw, 1);
+  for (int i = tid; i < 4 * RS * EPL; i += 256) acc[i] = 0.f;
+  // bf16 mode accumulates in 32-bit FIXED POINT with a per-workgroup power-of-two scale: ds_add_f32 (and
+  // ds_cmpst_rtn_b32) run ~10x slower than the integer LDS atomics on gfx950 (measured: 0.28 ms vs 0.12 ms for the
+  // Mixed_3c pool), and integer sums are associative, so the result does not depend on the order the waves arrive in.
+  // Scale = 2^24 / 2^floor(log2 max|gout|) over the windows this workgroup reads: |v * scale| < 2^25, <= 27 addends
+  // < 2^30; a bf16 gradient (8 significant bits) within 2^-17 of the largest one is represented exactly and the
+  // absolute error of a cell is < 27 * 2^-25 * max|gout|, far below the bf16 rounding of the stored result.
+  // fp32 mode (the parity mode) keeps exact float atomics.
+  constexpr bool FIXED = sizeof(T) == 2;
+  float scale = 1.f, inv_scale = 1.f;
+  if (FIXED) {
+    unsigned* const smax = (unsigned*)(acc + 4 * RS * EPL);
+    if (tid == 0) *smax = 0u;
+    __syncthreads();
+    unsigned mx = 0u;
+    if (chvalid)
+      for (int hp = tid >> 2; hp < P; hp += 64) {
+        const int a = (int)(((float)hp + 0.5f) * inv_hw), rem = hp - a * nhw;
+        const int bq = (int)(((float)rem + 0.5f) * inv_w), c = rem - bq * nw;
+        const size_t opos = (((size_t)(b * k.To + o_t0 + a) * k.Ho + o_h0 + bq) * k.Wo + o_w0 + c);
+        const uint4 g = *(const uint4*)(k.gout + (opos * k.gout_ld + k.gout_coff + c0) * sizeof(T));
+        // largest |bf16| of the 8 packed values, as an fp32 bit pattern (magnitudes order like unsigned integers)
+        const unsigned w[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) {
-        const int tap = id[e];                                    // 255 ("no cell") decodes out of range below
-        const int dt = (int)(((unsigned)tap * m_khkw) >> 20), r2 = tap - dt * khkw;
-        const int dh = (int)(((unsigned)r2 * m_kw) >> 20), dw = r2 - dh * k.kw;
-        // window o covers cells o - pad + d; local cell = halo coordinate - (k-1) + d
-        const int lt = a - (k.kt - 1) + dt, lh = bq - (k.kh - 1) + dh, lw = c - (k.kw - 1) + dw;
-        if ((unsigned)lt < (unsigned)p.Tt && (unsigned)lh < (unsigned)p.Ht && (unsigned)lw < (unsigned)p.Wt && dt < k.kt)
-          atomicAdd(&myacc[((lt * p.Ht + lh) * p.Wt + lw) * EPL + e], go[e]);
+        for (int i = 0; i < 4; ++i) mx = max(mx, max((w[i] << 16) & 0x7fffffffu, w[i] & 0x7fff0000u));
+      }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if ((tid & 63) == 0) atomicMax(smax, mx);
+    __syncthreads();
+    int ex = (int)(*smax >> 23);                               // biased exponent of the largest magnitude
+    ex = min(max(ex, 26), 254);                                // (inf/nan gradients are not representable; clamp)
+    scale = __uint_as_float((unsigned)(127 + 24 + 127 - ex) << 23);
+    inv_scale = __uint_as_float((unsigned)(127 - 24 - 127 + ex) << 23);
+  }
+  __syncthreads();
+  const int khkw = k.kh * k.kw;
+  float* const myacc = acc + ch * RS;
+  if (chvalid)
+    for (int base = tid >> 2; base < P; base += 64 * UNR) {
+      int id[UNR][EPL];
+      float go[UNR][EPL];
+      int lt0[UNR], lh0[UNR], lw0[UNR];
+      // all loads of the UNR positions are issued before the first atomic: one memory round trip per UNR positions
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int hp = min(base + u * 64, P - 1);
+        const int a = (int)(((float)hp + 0.5f) * inv_hw), rem = hp - a * nhw;
+        const int bq = (int)(((float)rem + 0.5f) * inv_w), c = rem - bq * nw;
+        const int ot = o_t0 + a, oh = o_h0 + bq, ow = o_w0 + c;
+        const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+        PV<T>::ldidx(k.idx + opos * k.C + c0, id[u]);
+        PV<T>::ld(k.gout + (opos * k.gout_ld + k.gout_coff + c0) * sizeof(T), go[u]);
+        // window o covers cells o*s - pad + d; local cell = that - tile origin
+        lt0[u] = ot * k.st - k.pt - i_t0; lh0[u] = oh * k.sh - k.ph - i_h0; lw0[u] = ow * k.sw - k.pw - i_w0;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (base + u * 64 >= P) break;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int tap = id[u][e];                                    // 255 ("no cell") decodes out of range below
+          const int dt = (int)(((unsigned)tap * m_khkw) >> 20), r2 = tap - dt * khkw;
+          const int dh = (int)(((unsigned)r2 * m_kw) >> 20), dw = r2 - dh * k.kw;
+          const int lt = lt0[u] + dt, lh = lh0[u] + dh, lw = lw0[u] + dw;
+          if ((unsigned)lt < (unsigned)p.Tt && (unsigned)lh < (unsigned)p.Ht && (unsigned)lw < (unsigned)p.Wt && dt < k.kt) {
+            float* const cell = &myacc[e * 4 * RS + (lt * p.Ht + lh) * p.Wt + lw];
+            if (FIXED) atomicAdd((unsigned*)cell, (unsigned)__float2int_rn(go[u][e] * scale));
+            else atomicAdd(cell, go[u][e]);
+          }
+        }
       }
     }
   __syncthreads();
@@ -425,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_scatter_bwd(const PoolTP p,
     if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
     float g[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) g[e] = myacc[r * EPL + e];
+    for (int e = 0; e < EPL; ++e) g[e] = FIXED ? (float)(int)__float_as_uint(myacc[e * 4 * RS + r]) * inv_scale : myacc[e * 4 * RS + r];
     const size_t ipos = (((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw);
     if (k.mask) {
       float mk[EPL];
@@ -435,6 +508,43 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_scatter_bwd(const PoolTP p,
     }
     PV<T>::st(k.gin + (ipos * k.gin_ld + k.gin_coff + c0) * sizeof(T), g);
   }
+}
+
+// input-cell tile for the scatter backward: minimise bytes moved per useful cell (tile writes + the windows read,
+// which overlap between neighbouring tiles) plus a fixed per-workgroup cost
+static flk_tile choose_scatter_tile(const flk_pool_args* a) {
+  flk_tile best{1, 1, 1};
+  double best_cost = 1e300;
+  for (int Tt = 1; Tt <= a->Ti && Tt <= 8; ++Tt)
+    for (int Ht = 1; Ht <= a->Hi && Tt * Ht <= 256; ++Ht) {
+      const int wmax = 256 / (Tt * Ht) < a->Wi ? 256 / (Tt * Ht) : a->Wi;
+      for (int Wt = 1; Wt <= wmax; ++Wt) {
+        const double tiles = (double)((a->Ti + Tt - 1) / Tt) * ((a->Hi + Ht - 1) / Ht) * ((a->Wi + Wt - 1) / Wt);
+        const double outs = (double)((Tt + a->kt - 2) / a->st + 1) * ((Ht + a->kh - 2) / a->sh + 1) * ((Wt + a->kw - 2) / a->sw + 1);
+        const double passes = (double)(((long)outs + 255) / 256);           // 64 position threads x 4-deep unroll
+        const double cost = tiles * (Tt * Ht * Wt * 16.0 + outs * 24.0 + passes * 2048.0 + 2048.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = flk_tile{Tt, Ht, Wt}; }
+      }
+    }
+  return best;
+}
+
+template <typename T>
+static int launch_scatter_bwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t s) {
+  constexpr int EPL = PV<T>::EPL;
+  PoolTP tp{};
+  tp.k = kp;
+  const flk_tile t = choose_scatter_tile(a);
+  tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
+  tp.nTt = (a->Ti + t.Tt - 1) / t.Tt; tp.nTh = (a->Hi + t.Ht - 1) / t.Ht; tp.nTw = (a->Wi + t.Wt - 1) / t.Wt;
+  tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 4 * EPL - 1) / (4 * EPL);
+  const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
+  auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
+  tp.plane_b = (tp.rows + 47) / 64 * 64 + 16;                         // accumulator plane stride in floats, = 16 (mod 64)
+  const size_t lds = (size_t)(4 * tp.plane_b * EPL + 256) * sizeof(float);    // <= 35 KiB (+ one dummy word per thread)
+  hipLaunchKernelGGL(maxpool_scatter_bwd<T>, grid, dim3(256), lds, s, tp, magic(a->kh * a->kw), magic(a->kw));
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
 }
 
 // stride-1 SAME pooling with an odd window and enough reuse to pay for the LDS staging
@@ -456,24 +566,15 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
   tp.plane_b = (tp.P * 16 + 255) / 256 * 256;
   constexpr int EPL = PV<T>::EPL;
   const size_t lds = 4 * (size_t)tp.plane_b + 64 + (bwd ? (size_t)4 * tp.P * EPL + 16 : 0);
-  dim3 grid((unsigned)((long)a->B * tp.nTt * tp.nTh * tp.nTw), (unsigned)((a->C + 4 * EPL - 1) / (4 * EPL)));
+  tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 4 * EPL - 1) / (4 * EPL);
+  const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   static bool attr_set = false;
   if (!attr_set) {
     FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  static const bool use_gather = getenv("FLK_POOL_GATHER") != nullptr;     // bitwise-reproducible gather form on request
-  if (bwd && !use_gather) {
-    static bool attr3 = false;
-    if (!attr3) {
-      FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_scatter_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr3 = true;
-    }
-    auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
-    const size_t lds2 = (size_t)4 * tp.rows * EPL * sizeof(float);
-    hipLaunchKernelGGL(maxpool_s1_scatter_bwd<T>, grid, dim3(256), lds2, s, tp, magic(a->kh * a->kw), magic(a->kw));
-  } else if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
+  if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
   else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
     static bool attr2 = false;
     if (!attr2) {
@@ -545,6 +646,9 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
   kp.mask = (const char*)mask; kp.mask_ld = mask_ld; kp.mask_coff = mask_coff;
   kp.add = nullptr;
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_maxpool3d_bwd: bad dtype");
+  static const bool use_gather = getenv("FLK_POOL_GATHER") != nullptr;     // bitwise-reproducible gather forms on request
+  if (!use_gather)
+    return dtype == FLK_BF16 ? launch_scatter_bwd<bf16_t>(kp, a, (hipStream_t)stream) : launch_scatter_bwd<float>(kp, a, (hipStream_t)stream);
   if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, true, (hipStream_t)stream) : launch_tiled<float>(kp, a, true, (hipStream_t)stream);
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   FLK_REQUIRE(a->Hi < 65536 && (long)a->B * a->Ti < 65536, "flk_maxpool3d_bwd: grid too large");
