@@ -85,8 +85,11 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // WN = waves along N: the 4 waves form a (4/WN) x WN grid; the workgroup tile is 64*(4/WN) rows x 16*NF channels and
 // every wave owns 64 rows x 16*NF/WN channels.  WN > 1 trades weight re-streaming for more workgroups on the layers
 // with few output positions (Mixed_4*/Mixed_5*).
-template <typename T, int NF, int WN>
+// MODE 0: weights through the LDS ring (wide wave tiles).  MODE 1: every wave streams its own fragments into registers
+// ("direct A").  MODE 2: direct A for a 1x1x1 convolution (activation slabs prefetched in depth as well).
+template <typename T, int NF, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
+  constexpr bool K1 = MODE == 2;
   typedef Prec<T> PR;
   typedef typename PR::frag frag;
   constexpr int EPL = PR::EPL;
@@ -166,17 +169,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // weight stream: (slab, tap) step k lives at w + (k*cout_frags + ntile*NF) KiB.  Every thread moves WCH 16-byte
-  // chunks per step, unconditionally (NF=2: threads t and t+128 move the same chunk) so the prefetch stays in VGPRs.
-  const int wchunk = NF >= 4 ? tid : (tid & 127);
-  const char* wsrc = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
-  const size_t wstep = (size_t)p.cout_frags * 1024;
-  uint4 wreg0 = *(const uint4*)wsrc, wreg1 = make_uint4(0, 0, 0, 0);   // named scalars: an array here is demoted to scratch
-  if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
-  wsrc += wstep;
-
-  int it_w = 0;
-  const int nsteps = p.nslab * p.ntaps;
   // src = segment base + (coff + slab*SLABC + ch*EPL) elements; ld = that segment's channel stride
   auto ldhalo = [&](const char* src, int ld, int g, bool chvalid) -> uint4 {
     const bool ok = g >= 0 && chvalid;
@@ -194,74 +186,213 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     src = p.in2 + (size_t)(p.in2_coff + s2 * SLABC + ch * EPL) * sizeof(T); ld = p.in2_ld;
     return s2 * SLABC + ch * EPL < p.cin - p.cin1;
   };
-  // Small halos (every 1x1x1 convolution, small tiles: P <= 256 -> 4 pairs per thread) are software-pipelined:
-  // slab s+1 is fetched into named registers while slab s computes, so the K loop does not expose one global-load
-  // latency per slab.  Larger halos are staged after the barrier (amortised over kt*kh*kw taps; the second resident
-  // workgroup covers the stall).
-  uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
-  auto prefetch = [&](int s) {
-    const char* src; int ld;
-    const bool chvalid = slab_src(s, src, ld);
-    pre0 = ldhalo(src, ld, goff[0], chvalid); pre1 = ldhalo(src, ld, goff[1], chvalid);
-    pre2 = ldhalo(src, ld, goff[2], chvalid); pre3 = ldhalo(src, ld, goff[3], chvalid);
-  };
-  if (small_halo) prefetch(0);
-  for (int s = 0; s < p.nslab; ++s) {
-    const int hsel = small_halo ? (s & 1) * halo_bytes : 0;
-    if (small_halo) {
-      // image (s & 1) was last read while computing slab s-2; every wave has passed the barrier of slab s-1 since
-      char* const hd = hdst + hsel;
-      if (goff[0] != -2) *(uint4*)(hd) = pre0;
-      if (goff[1] != -2) *(uint4*)(hd + 1024) = pre1;
-      if (goff[2] != -2) *(uint4*)(hd + 2048) = pre2;
-      if (goff[3] != -2) *(uint4*)(hd + 3072) = pre3;
-      if (s + 1 < p.nslab) prefetch(s + 1);
-    } else {
-      __syncthreads();  // every wave has finished reading the previous slab's halo
+  const int nsteps = p.nslab * p.ntaps;
+  const size_t wstep = (size_t)p.cout_frags * 1024;
+  if constexpr (MODE == 0) {
+    // ---- wide wave tiles (>= 32 MFMAs per K step): weights through a double-buffered LDS tile shared by the 4 waves,
+    // register prefetch one step ahead, nested tap loops.
+    // weight stream: (slab, tap) step k lives at w + (k*cout_frags + ntile*NF) KiB.  Every thread moves WCH 16-byte
+    // chunks per step, unconditionally (NF=2: threads t and t+128 move the same chunk) so the prefetch stays in VGPRs.
+    const int wchunk = NF >= 4 ? tid : (tid & 127);
+    const char* wsrc = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
+    uint4 wreg0 = *(const uint4*)wsrc, wreg1 = make_uint4(0, 0, 0, 0);   // named scalars: an array here is demoted to scratch
+    if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+    wsrc += wstep;
+
+    int it_w = 0;
+    // Small halos (every 1x1x1 convolution, small tiles: P <= 256 -> 4 pairs per thread) are software-pipelined:
+    // slab s+1 is fetched into named registers while slab s computes, so the K loop does not expose one global-load
+    // latency per slab.  Larger halos are staged after the barrier (amortised over kt*kh*kw taps; the second resident
+    // workgroup covers the stall).
+    uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+    auto prefetch = [&](int s) {
       const char* src; int ld;
       const bool chvalid = slab_src(s, src, ld);
-#pragma unroll
-      for (int n0 = 0; n0 < NPAIR; n0 += 4) {
-        if (n0 * 64 >= p.P) break;
-        uint4 v[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-          if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
+      pre0 = ldhalo(src, ld, goff[0], chvalid); pre1 = ldhalo(src, ld, goff[1], chvalid);
+      pre2 = ldhalo(src, ld, goff[2], chvalid); pre3 = ldhalo(src, ld, goff[3], chvalid);
+    };
+    if (small_halo) prefetch(0);
+    for (int s = 0; s < p.nslab; ++s) {
+      const int hsel = small_halo ? (s & 1) * halo_bytes : 0;
+      if (small_halo) {
+        // image (s & 1) was last read while computing slab s-2; every wave has passed the barrier of slab s-1 since
+        char* const hd = hdst + hsel;
+        if (goff[0] != -2) *(uint4*)(hd) = pre0;
+        if (goff[1] != -2) *(uint4*)(hd + 1024) = pre1;
+        if (goff[2] != -2) *(uint4*)(hd + 2048) = pre2;
+        if (goff[3] != -2) *(uint4*)(hd + 3072) = pre3;
+        if (s + 1 < p.nslab) prefetch(s + 1);
+      } else {
+        __syncthreads();  // every wave has finished reading the previous slab's halo
+        const char* src; int ld;
+        const bool chvalid = slab_src(s, src, ld);
+  #pragma unroll
+        for (int n0 = 0; n0 < NPAIR; n0 += 4) {
+          if (n0 * 64 >= p.P) break;
+          uint4 v[4];
+  #pragma unroll
+          for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+  #pragma unroll
+          for (int n = 0; n < 4; ++n)
+            if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
+        }
       }
-    }
-    int tapoff_t = 0;
-    for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.Hh * p.Wh * 16) {
-      int tapoff_h = tapoff_t;
-      for (int dh = 0; dh < p.kh; ++dh, tapoff_h += p.Wh * 16) {
-        int tapoff = tapoff_h;
-        for (int dw = 0; dw < p.kw; ++dw, tapoff += 16) {
-          char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
-          *(uint4*)(wcur + wchunk * 16) = wreg0;
-          if (WCH == 2) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
-          ++it_w;
-          if (it_w < nsteps) {
-            wreg0 = *(const uint4*)wsrc;
-            if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
-            wsrc += wstep;
-          }
-          __syncthreads();
-          if (wave_active) {
-            frag bf[4], af[NFW];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + hsel + rowpos[i] + tapoff);
-#pragma unroll
-            for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
-            __builtin_amdgcn_sched_barrier(0);   // keep every fragment read ahead of the MFMA chain (counted lgkmcnt waits)
-#pragma unroll
-            for (int f = 0; f < NFW; ++f)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
+      int tapoff_t = 0;
+      for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.Hh * p.Wh * 16) {
+        int tapoff_h = tapoff_t;
+        for (int dh = 0; dh < p.kh; ++dh, tapoff_h += p.Wh * 16) {
+          int tapoff = tapoff_h;
+          for (int dw = 0; dw < p.kw; ++dw, tapoff += 16) {
+            char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
+            *(uint4*)(wcur + wchunk * 16) = wreg0;
+            if (WCH == 2) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
+            ++it_w;
+            if (it_w < nsteps) {
+              wreg0 = *(const uint4*)wsrc;
+              if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+              wsrc += wstep;
+            }
+            __syncthreads();
+            if (wave_active) {
+              frag bf[4], af[NFW];
+  #pragma unroll
+              for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + hsel + rowpos[i] + tapoff);
+  #pragma unroll
+              for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
+              __builtin_amdgcn_sched_barrier(0);   // keep every fragment read ahead of the MFMA chain (counted lgkmcnt waits)
+  #pragma unroll
+              for (int f = 0; f < NFW; ++f)
+  #pragma unroll
+                for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
+            }
           }
         }
       }
     }
+
+  } else {
+    // ---- narrow wave tiles (WN >= 2) and small grids of narrow channel tiles: few MFMAs per K step, so one step is
+    // far shorter than a memory round trip or a workgroup barrier.  Every wave reads ITS OWN weight fragments straight
+    // from global memory into registers (the 4/WN waves that share them meet in the L1): no LDS hop and NO per-step barrier -- waves only meet when
+    // the halo image changes (once per slab).  The K loop is flattened over (slab, tap) and unrolled by D; the
+    // fragment loads run D steps ahead in a register queue indexed with compile-time constants only.  They are
+    // issued from inline asm with hand-counted s_waitcnt vmcnt(N): hipcc's own bookkeeping falls back to a
+    // near-complete drain at the loop's merge points, which puts one full memory latency into every K step.  Loads
+    // the compiler issues itself (halo prefetch) only make the hand-written counts wait longer, never shorter.
+    //   * K1 (one tap per slab): the activation slabs are prefetched D slabs ahead as well.
+    constexpr int D = (NFW <= 2 && !K1) ? 8 : 4;   // K1 also keeps D activation slabs (16 VGPRs each) in flight
+    // fragment f of this wave at step k = w + (k*cout_frags + ntile*NF + wn*NFW + f) KiB + lane*16
+    const char* const wfirst = p.w + (size_t)ntile * NF * 1024 + (wn * NFW * 64 + lane) * 16;
+    const char* const wlast = wfirst + (size_t)(nsteps - 1) * wstep;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: inline asm takes it in registers
+    u32x4 wq[D][NFW];
+    auto wload = [&](u32x4 (&dst)[NFW], const char* ws) {
+      ws = ws < wlast ? ws : wlast;                     // past the end: re-read the last step (never used)
+      static_assert(NFW <= 4, "offset field");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0]) : "v"(ws) : "memory");
+      if constexpr (NFW > 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024" : "=v"(dst[1]) : "v"(ws) : "memory");
+      if constexpr (NFW > 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048" : "=v"(dst[2]) : "v"(ws) : "memory");
+      if constexpr (NFW > 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(dst[3]) : "v"(ws) : "memory");
+    };
+    // wait until at most N of the loads issued so far are outstanding, and make the queue entry depend on that wait
+    auto wwait = [&](u32x4 (&q)[NFW]) {
+      constexpr int N = (D - 1) * NFW;
+      if constexpr (NFW == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q[0]), "+v"(q[1]) : "i"(N) : "memory");
+      else if constexpr (NFW == 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "i"(N) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[0]) : "i"(N) : "memory");
+    };
+    static_assert(NFW == 1 || NFW == 2 || NFW == 4, "queue wait is written for 1, 2 or 4 fragments per wave");
+#pragma unroll
+    for (int j = 0; j < D; ++j) wload(wq[j], wfirst + (size_t)j * wstep);
+    const char* wnext = wfirst + (size_t)D * wstep;
+
+    uint4 pre[D][4];
+    auto prefetch = [&](uint4 (&dst)[4], int s) {
+      const char* src; int ld;
+      const bool chvalid = slab_src(s < p.nslab ? s : p.nslab - 1, src, ld);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) dst[n] = ldhalo(src, ld, goff[n], chvalid);
+    };
+    auto put_halo = [&](const uint4 (&v)[4], char* hd) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        if (goff[n] != -2) *(uint4*)(hd + n * 1024) = v[n];
+    };
+    if (K1) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) prefetch(pre[j], j);
+    } else if (small_halo) prefetch(pre[0], 0);
+
+    int s = 0, dt = 0, dh = 0, dw = 0, tapoff_t = 0, tapoff_h = 0, tapoff = 0, hsel = 0;
+    bool newslab = true;
+    for (int k0 = 0; k0 < nsteps; k0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int kk = k0 + j;
+        if (kk >= nsteps) break;
+        // halo image: two images alternate for small halos.  Image i is rewritten only after a barrier that every
+        // wave reaches after its last read of it (the barrier of the slab in between).
+        if (K1) {
+          hsel = (kk & 1) * halo_bytes;
+          put_halo(pre[j], hdst + hsel);
+          prefetch(pre[j], kk + D);
+          __syncthreads();
+        } else if (newslab) {
+          newslab = false;
+          if (small_halo) {
+            hsel = (s & 1) * halo_bytes;
+            put_halo(pre[0], hdst + hsel);
+            prefetch(pre[0], s + 1);
+            __syncthreads();
+          } else {
+            __syncthreads();  // every wave has finished reading the previous slab's halo
+            const char* src; int ld;
+            const bool chvalid = slab_src(s, src, ld);
+#pragma unroll
+            for (int n0 = 0; n0 < NPAIR; n0 += 4) {
+              if (n0 * 64 >= p.P) break;
+              uint4 v[4];
+#pragma unroll
+              for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+#pragma unroll
+              for (int n = 0; n < 4; ++n)
+                if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
+            }
+            __syncthreads();
+          }
+        }
+        frag bf[4];
+        if (wave_active) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + hsel + rowpos[i] + tapoff);
+        }
+        wwait(wq[j]);
+        if (wave_active) {
+#pragma unroll
+          for (int f = 0; f < NFW; ++f)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) PR::mma(__builtin_bit_cast(frag, wq[j][f]), bf[i], acc[f][i]);
+        }
+        wload(wq[j], wnext);          // refill this queue slot for step kk + D
+        wnext += wstep;
+        if (!K1) {   // next tap (scalar state): w fastest, then h, then t, then the next slab
+          if (++dw < p.kw) tapoff += 16;
+          else {
+            dw = 0;
+            if (++dh < p.kh) tapoff_h += p.Wh * 16;
+            else {
+              dh = 0;
+              if (++dt < p.kt) tapoff_t += p.Hh * p.Wh * 16;
+              else { dt = 0; tapoff_t = 0; ++s; newslab = true; }
+              tapoff_h = tapoff_t;
+            }
+            tapoff = tapoff_h;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the queue's tail before the wave may end
   }
 
   // ---- epilogue: lane = position (m of fragment i); lane group q owns EPL channels of every 4*EPL-channel store group ----
@@ -350,15 +481,15 @@ flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st,
   return best;
 }
 
-template <typename T, int NF, int WN>
+template <typename T, int NF, int WN, int MODE>
 static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NF, WN>,
+    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NF, WN, MODE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, NF, WN>), grid, dim3(256), lds, s, kp);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, NF, WN, MODE>), grid, dim3(256), lds, s, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -444,7 +575,6 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   } else {
     kp.out2 = kp.out; kp.cout1 = a->cout;
   }
-  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + 2 * (size_t)nf * 1024;
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
   kp.m_HW = magic(kp.Hh * kp.Wh); kp.m_Wh = magic(kp.Wh); kp.m_hw = magic(kp.Ht * kp.Wt); kp.m_Wt = magic(kp.Wt);
   kp.ntile_n = ntile_n;
@@ -453,15 +583,39 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   FLK_REQUIRE(gx < (1l << 31), "flk_conv3d: grid too large");
   dim3 grid((unsigned)gx);
   hipStream_t s = (hipStream_t)stream;
-#define FLK_LAUNCH(TT, NFv, WNv) if (nf == NFv && wn == WNv) return launch<TT, NFv, WNv>(kp, grid, lds, s)
-  if (dtype == FLK_BF16) {
-    FLK_LAUNCH(bf16_t, 2, 1); FLK_LAUNCH(bf16_t, 4, 1); FLK_LAUNCH(bf16_t, 4, 2);
-    FLK_LAUNCH(bf16_t, 8, 1); FLK_LAUNCH(bf16_t, 8, 2); FLK_LAUNCH(bf16_t, 8, 4);
-  } else if (dtype == FLK_F32) {
-    FLK_LAUNCH(float, 2, 1); FLK_LAUNCH(float, 2, 2); FLK_LAUNCH(float, 4, 1); FLK_LAUNCH(float, 4, 2); FLK_LAUNCH(float, 4, 4);
-    FLK_LAUNCH(float, 8, 1); FLK_LAUNCH(float, 8, 2); FLK_LAUNCH(float, 8, 4);
+  // Weight path.  Direct-A (modes 1/2) wherever a K step holds few MFMAs per wave and the waves would otherwise stall
+  // on the per-step barrier: all WN >= 2 layouts, and narrow channel tiles (nf <= 4) on grids of at most two
+  // workgroups per CU.  Everything else shares the weights through the LDS ring (mode 0).
+  int mode = 0;
+  {
+    static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
+    const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);
+    if (wn >= 2 || narrow_small) mode = (kp.ntaps == 1 && kp.P <= 256) ? 2 : 1;
   }
-#undef FLK_LAUNCH
+  // two halo images for small halos; the LDS weight ring only in mode 0
+  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + (mode == 0 ? 2 * (size_t)nf * 1024 : 0);
+  {
+    static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
+    if (dbg)
+      fprintf(stderr, "conv %dx%dx%d s%d%d%d cin %d cout %d out %dx%dx%dx%d | nf %d wn %d tile %dx%dx%d rows %d halo %d wgs %ld mode %d lds %zu\n",
+              a->kt, a->kh, a->kw, a->st, a->sh, a->sw, a->cin, a->cout, a->B, a->To, a->Ho, a->Wo, nf, wn, kp.Tt, kp.Ht, kp.Wt,
+              kp.rows, kp.P, ptiles * ntile_n, mode, lds);
+  }
+#define FLK_LAUNCH0(TT, NFv, WNv) if (nf == NFv && wn == WNv && mode == 0) return launch<TT, NFv, WNv, 0>(kp, grid, lds, s)
+#define FLK_LAUNCHD(TT, NFv, WNv)                                                         \
+  if (nf == NFv && wn == WNv && mode == 1) return launch<TT, NFv, WNv, 1>(kp, grid, lds, s); \
+  if (nf == NFv && wn == WNv && mode == 2) return launch<TT, NFv, WNv, 2>(kp, grid, lds, s)
+  if (dtype == FLK_BF16) {
+    FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1);
+    FLK_LAUNCHD(bf16_t, 2, 1); FLK_LAUNCHD(bf16_t, 4, 1); FLK_LAUNCHD(bf16_t, 4, 2);
+    FLK_LAUNCHD(bf16_t, 8, 2); FLK_LAUNCHD(bf16_t, 8, 4);
+  } else if (dtype == FLK_F32) {
+    FLK_LAUNCH0(float, 2, 1); FLK_LAUNCH0(float, 4, 1); FLK_LAUNCH0(float, 8, 1);
+    FLK_LAUNCHD(float, 2, 1); FLK_LAUNCHD(float, 4, 1); FLK_LAUNCHD(float, 2, 2); FLK_LAUNCHD(float, 4, 2);
+    FLK_LAUNCHD(float, 4, 4); FLK_LAUNCHD(float, 8, 2); FLK_LAUNCHD(float, 8, 4);
+  }
+#undef FLK_LAUNCH0
+#undef FLK_LAUNCHD
   flk_set_error("flk_conv3d: unsupported dtype %d / nf %d / wn %d", dtype, nf, wn);
   return FLK_EINVAL;
 }
