@@ -86,6 +86,7 @@ _SIGS = {
     "flk_perturb_apply_s2d": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "flk_perturb_grad_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "flk_perturb_grad_reduce": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_pack_batch_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "flk_perturb_reg_adam": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_dense_adam_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "flk_perturb_dense_l12_adam": (C.c_int, [C.POINTER(DenseAdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -284,6 +284,21 @@ extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s
   return FLK_OK;
 }
 
+__global__ void pack_batch_sums_kernel(const float* per_clip, int B, float prob_scale, float* out3) {
+  const int k = threadIdx.x;
+  if (k >= 3) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += per_clip[b * 4 + k];
+  out3[k] = k == 0 ? s : s * prob_scale;
+}
+
+extern "C" int flk_pack_batch_sums(const float* per_clip, int B, float prob_scale, float* out3, void* stream) {
+  FLK_REQUIRE(per_clip && out3 && B > 0, "flk_pack_batch_sums: bad arguments");
+  hipLaunchKernelGGL(pack_batch_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, per_clip, B, prob_scale, out3);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
 // ---- regulariser gradient + Adam: one workgroup, delta is [T,3] ----------------------------------
 __device__ static inline float block_sum(float v, float* sh) {
 #pragma unroll

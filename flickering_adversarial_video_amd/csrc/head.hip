@@ -38,21 +38,36 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const char* y, int ld, i
   if (grp == 0 && c < C) feat[(size_t)b * C + c] = part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl];
 }
 
-// logits[b,n] = bias[n] + sum_c feat[b,c] * W[c,n]     grid (ceil(N/64), B): 64 outputs x 4 channel groups per workgroup
-__global__ __launch_bounds__(256) void head_fc_kernel(const float* feat, const float* W, const float* bias, int C, int N,
-                                                      float* logits) {
+// logits[b,n] = bias[n] + sum_c feat[b,c] * W[c,n]     grid (ceil(N/64), B): 64 outputs x 16 channel groups per workgroup,
+// 8 weight loads in flight per thread (the loop is latency-bound: W is read once, 1.6 MB for I3D)
+__global__ __launch_bounds__(1024) void head_fc_kernel(const float* feat, const float* W, const float* bias, int C, int N,
+                                                       float* logits) {
   __shared__ float sf[2048];
-  __shared__ float part[4][64];
+  __shared__ float part[16][64];
   const int nl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + nl, b = blockIdx.y;
-  for (int c = threadIdx.x; c < C; c += 256) sf[c] = feat[(size_t)b * C + c];
+  for (int c = threadIdx.x; c < C; c += 1024) sf[c] = feat[(size_t)b * C + c];
   __syncthreads();
   float acc = 0.f;
-  if (n < N)
-    for (int c = grp; c < C; c += 4) acc += sf[c] * W[(size_t)c * N + n];
+  if (n < N) {
+    int c = grp;
+    for (; c + 7 * 16 < C; c += 8 * 16) {
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = W[(size_t)(c + u * 16) * N + n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += sf[c + u * 16] * w[u];
+    }
+    for (; c < C; c += 16) acc += sf[c] * W[(size_t)c * N + n];
+  }
   part[grp][nl] = acc;
   __syncthreads();
-  if (grp == 0 && n < N) logits[(size_t)b * N + n] = (bias ? bias[n] : 0.f) + part[0][nl] + part[1][nl] + part[2][nl] + part[3][nl];
+  if (grp == 0 && n < N) {
+    float v = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += part[g][nl];
+    logits[(size_t)b * N + n] = v;
+  }
 }
 
 // dfeat[b,c] = sum_n dlogits[b,n] * W[c,n]      grid (ceil(C/256), B)
@@ -89,7 +104,7 @@ int flk_head_forward(const void* y, int ld, int coff, int C, int B, int Tn, int 
   dim3 g1((C + 63) / 64, B);
   if (dtype == FLK_BF16) hipLaunchKernelGGL(head_pool_kernel<bf16_t>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
   else hipLaunchKernelGGL(head_pool_kernel<float>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
-  hipLaunchKernelGGL(head_fc_kernel, dim3((N + 63) / 64, B), dim3(256), 0, s, feat, W, bias, C, N, logits);
+  hipLaunchKernelGGL(head_fc_kernel, dim3((N + 63) / 64, B), dim3(1024), 0, s, feat, W, bias, C, N, logits);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

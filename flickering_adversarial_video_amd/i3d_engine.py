@@ -22,10 +22,48 @@ IMAGE_SIZE = 224           # kinetics_i3d_utils.py:9
 
 
 class StepResult(dict):
-    """Scalars of one attack iteration as device tensors; ``.host()`` fetches them (one sync)."""
+    """Scalars of one attack iteration as device tensors; ``.host()`` fetches them (one sync).
+
+    The kernels write straight into one of ``RESULT_SLOTS`` result slots of the engine, so the tensors stay valid for
+    the next ``RESULT_SLOTS - 1`` iterations (copy them to keep them longer).  Quantities that are pure functions of
+    the stored ones (``is_adversarial``, ``argmax``, ``total_loss``, the ``*_relative`` percentages) are computed on
+    first access -- an iteration that nobody inspects launches no bookkeeping kernels."""
+
+    _DERIVED = ("argmax", "is_adversarial", "total_loss", "thickness_relative", "roughness_relative")
+
+    def __missing__(self, key):
+        if key == "argmax":
+            v = self["_argmax_f"].to(torch.int64)
+        elif key == "is_adversarial":
+            v = (self["argmax"] == self["_labels"]).all() if self["_targeted"] else (self["argmax"] != self["_labels"]).all()
+        elif key == "total_loss" and "reg_loss" in self:
+            v = self["adv_loss"] + self["_reg_weight"] * self["reg_loss"]
+        elif key == "thickness_relative" and "thickness" in self:
+            v = self["thickness"] / 2 * 100
+        elif key == "roughness_relative" and "roughness" in self:
+            v = self["roughness"] / 2 * 100
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def materialize(self):
+        for k in self._DERIVED:
+            self.get(k)
+        return self
 
     def host(self):
-        return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in self.items()}
+        self.materialize()
+        return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in self.items() if not k.startswith("_")}
+
+
+RESULT_SLOTS = 4
 
 
 class FlickerI3D:
@@ -64,6 +102,13 @@ class FlickerI3D:
         self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4),
                                     dtype=torch.float32, device=dev)
         self._scalars = torch.empty(8, dtype=torch.float32, device=dev)
+        # result slots: [payload | softmax | per-clip table | scalars] written by the kernels, rotated per iteration
+        self._slots = [dict(payload=torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev),
+                            sm=torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev),
+                            pc=torch.empty((self.B, 4), dtype=torch.float32, device=dev),
+                            scalars=torch.zeros(8, dtype=torch.float32, device=dev)) for _ in range(RESULT_SLOTS)]
+        self._dl = torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev)
+        self._it = 0
         self._rng = np.random.default_rng(seed)
 
     @property
@@ -123,29 +168,31 @@ class FlickerI3D:
         cyclic = self.cyclic_flag if cyclic is None else cyclic
         cyclic_pert = self.cyclic_pert_flag if cyclic_pert is None else cyclic_pert
         a = self._apply_args(x, 1.0, cyclic, cyclic_pert)
+        slot = self._slots[self._it % RESULT_SLOTS]
+        self._it += 1
+        red, sm, pc = slot["payload"], slot["sm"], slot["pc"]
+        self._red = red
         ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
         self.net.forward(self._xs2d, self._logits)
         gbatch = self.B * self.world
-        sm, dl, pc = ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
-                                          targeted=targeted, margin=margin, mean_scale=1.0 / gbatch)
-        self.net.backward(dl, self._gx)
+        ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
+                             targeted=targeted, margin=margin, mean_scale=1.0 / gbatch, out=(sm, self._dl, pc))
+        self.net.backward(self._dl, self._gx)
         n = self.T * 3
-        ops.perturb_grad_reduce(a, self._gx, self._red[:n].view(self.T, 3), self._scratch)
-        parallel.pack_scalars(self._red, self.T, pc)
-        parallel.allreduce_sum_(self._red, self.pg)                    # RCCL over xGMI: (T*3+3) floats
-        _, adv_sum, p_lab, p_non = parallel.unpack(self._red, self.T, gbatch)
+        ops.perturb_grad_reduce(a, self._gx, red[:n].view(self.T, 3), self._scratch)
+        ops.pack_batch_sums(pc, 1.0 / gbatch, red[n:])                 # [sum adv | mean label prob | mean max-other prob]
+        parallel.allreduce_sum_(red, self.pg)                          # RCCL over xGMI: (T*3+3) floats
+        p_lab, p_non = red[n + 1], red[n + 2]
         # to_min / to_max probabilities swap roles for targeted attacks (kinetics_i3d_utils.py:265-278)
-        res = StepResult(adv_loss=adv_sum.clone(), prob_to_min=p_non if targeted else p_lab, prob_to_max=p_lab if targeted else p_non,
-                         softmax=sm, label_prob=pc[:, 1], argmax=pc[:, 3].to(torch.int64))
-        res["is_adversarial"] = (res["argmax"] == labels).all() if targeted else (res["argmax"] != labels).all()
+        res = StepResult(adv_loss=red[n], prob_to_min=p_non if targeted else p_lab, prob_to_max=p_lab if targeted else p_non,
+                         softmax=sm, label_prob=pc[:, 1], _argmax_f=pc[:, 3], _labels=labels, _targeted=bool(targeted))
         if update:
             self.adam_t += 1
-            ops.perturb_reg_adam(self._red[:n], self.eps_rgb, self.adam_m, self.adam_v, self.adam_t, dialect="tf", beta0=beta0,
-                                 beta1=beta1, beta2=beta2, beta3=beta3, lr=lr, scalars=self._scalars)
-            sc = self._scalars.clone()
+            sc = slot["scalars"]
+            ops.perturb_reg_adam(red[:n], self.eps_rgb, self.adam_m, self.adam_v, self.adam_t, dialect="tf", beta0=beta0,
+                                 beta1=beta1, beta2=beta2, beta3=beta3, lr=lr, scalars=sc)
             res.update(reg_loss=sc[0], norm_reg=sc[1], diff_norm_reg=sc[2], laplacian_norm_reg=sc[3], thickness=sc[4],
-                       roughness=sc[5], pert_max=sc[6], pert_min=sc[7], total_loss=res["adv_loss"] + beta0 * sc[0],
-                       thickness_relative=sc[4] / 2 * 100, roughness_relative=sc[5] / 2 * 100)
+                       roughness=sc[5], pert_max=sc[6], pert_min=sc[7], _reg_weight=beta0)
         return res
 
     def _step_dense(self, x, labels, lr, beta1, margin, targeted, use_logits, improve_loss, cyclic, update):

@@ -199,16 +199,27 @@ def perturb_dense_l12_adam(g_adv, delta, m, v, step, *, dialect="tf", beta=1.0, 
     return scalars
 
 
+def pack_batch_sums(per_clip, prob_scale, out3):
+    """out3 = [sum loss_b, prob_scale * sum p_label, prob_scale * sum p_max_other] from softmax_adv_loss's per-clip table"""
+    assert per_clip.dtype == torch.float32 and per_clip.is_contiguous() and per_clip.shape[1] == 4 and out3.dtype == torch.float32
+    check(load().flk_pack_batch_sums(ptr(per_clip), per_clip.shape[0], float(prob_scale), ptr(out3), stream_ptr()))
+    return out3
+
+
 def softmax_adv_loss(logits, labels, *, dialect="tf", improve_loss=True, use_logits=False, targeted=False, margin=0.05,
-                     mean_scale=1.0):
+                     mean_scale=1.0, out=None):
+    """out: optional (softmax, dlogits, per_clip) buffers to write into"""
     B, Cn = logits.shape
     a = LossArgs()
     a.B, a.C = B, Cn
     a.torch_dialect, a.improve_loss, a.use_logits, a.targeted = int(dialect == "torch"), int(improve_loss), int(use_logits), int(targeted)
     a.margin, a.mean_scale = margin, mean_scale
-    sm = torch.empty_like(logits)
-    dl = torch.empty_like(logits)
-    pc = torch.empty((B, 4), dtype=torch.float32, device=logits.device)
+    if out is None:
+        sm = torch.empty_like(logits)
+        dl = torch.empty_like(logits)
+        pc = torch.empty((B, 4), dtype=torch.float32, device=logits.device)
+    else:
+        sm, dl, pc = out
     assert logits.dtype == torch.float32 and labels.dtype == torch.int64 and logits.is_contiguous()
     check(load().flk_softmax_adv_loss(C.byref(a), ptr(logits), ptr(labels), ptr(sm), ptr(dl), ptr(pc), stream_ptr()))
     return sm, dl, pc

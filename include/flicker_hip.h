@@ -145,6 +145,12 @@ int64_t flk_perturb_grad_scratch_bytes(int B, int T, int H, int W);
 int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s2d, int dtype,
                             float* gdelta, float* partials, void* stream);
 
+/* Tail of the data-parallel payload (flickering_adversarial_video_amd/parallel.py; replaces the per-iteration
+ * reduce_sum / reduce_mean fetches of i3d_adversarial_main_single_video_npy.py:213-217): from the per-clip
+ * outputs of flk_softmax_adv_loss ([B,4] = loss, p_label, p_max_other, argmax)
+ *   out3 = { sum_b loss_b, prob_scale * sum_b p_label, prob_scale * sum_b p_max_other }   (fixed summation order). */
+int flk_pack_batch_sums(const float* per_clip, int B, float prob_scale, float* out3, void* stream);
+
 /* Regulariser gradient + Adam on delta (flicker, [T,3] time-major; the torch dialect's [3,T] is
  * transposed by the host wrapper).  TF dialect: kinetics_i3d_utils.py:177-186 +
  * i3d_adversarial_main_single_video_npy.py:56-59,79-84 (regulariser on the RAW delta, TF Adam).
