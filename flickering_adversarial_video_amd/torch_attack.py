@@ -85,6 +85,16 @@ class Losses:
         self.label_prob = pc[:, 1]
         return sm, dl, pc
 
+    def flickering_regularization_loss(self, perturbation):
+        """model.py:198-209 on the CLAMPED perturbation [3,T,1,1] (model.py:1078): value only -- the gradient and the same
+        value during an update come from flk_perturb_reg_adam.  Used for evaluation passes (no Adam step)."""
+        p = perturbation
+        right, left = torch.roll(p, 1, dims=1), torch.roll(p, -1, dims=1)
+        norm_reg = torch.mean(p ** 2) + 1e-12
+        diff_norm_reg = torch.mean((p - right) ** 2) + 1e-12
+        laplacian_norm_reg = torch.mean((-2 * p + right + left) ** 2) + 1e-12
+        return self.beta_1 * norm_reg + (1 - self.beta_1) * (diff_norm_reg + laplacian_norm_reg)
+
 
 class Adversarial_metrics:
     """model.py:253-330"""
@@ -161,4 +171,98 @@ class FlickerVideoResNet:
                                  dyn_max_norm=self.pert_model.dynamic_max_norm, lr=lr, scalars=self._scalars)
             sc = self._scalars.clone()
             res.update(reg_loss=sc[0], loss=res["adv_loss"] + criterion.lambda_ * sc[0], thickness=sc[4] * 100, roughness=sc[5] * 100)
+        else:
+            reg = criterion.flickering_regularization_loss(self.pert_model.get_perturbation()[0])
+            res.update(reg_loss=reg, loss=res["adv_loss"] + criterion.lambda_ * reg)
         return res
+
+    # ---- drivers around step(): VideoLearnerAdversarial's loops without the plotting ------------------------------------
+    def fit_single_video_attack(self, inputs, target, criterion, lr=1e-3, n_iter=3000, targeted_attack=False, target_class_id=None,
+                                restart_after=3000, norm_growth=1.3, max_restarts=4, log_every=0):
+        """``VideoLearnerAdversarial.fit_single_video_attack`` (model.py:984-1205).
+
+        Returns None when the clean clip is misclassified (model.py:1030-1032).  Otherwise iterates
+        ``while step < n_iter or not is_adversarial`` (model.py:1056); whenever ``step > restart_after`` the clamp norm
+        grows by ``norm_growth`` and the step counter restarts, giving up after ``max_restarts`` (model.py:1061-1066:
+        3000 / 1.3 / 4).  The result dict has the reference's keys (model.py:1193-1203); per-iteration values are host
+        floats (the reference syncs every iteration as well: ``loss.item()``)."""
+        outputs_no_adv = self.logits(inputs, False).clone()
+        if not bool((outputs_no_adv.argmax(1) == target).all()):
+            return None
+        tot, adv_l, reg_l, thick_l, rough_l, maxp_l, corr_l, isadv_l, pert_l = [], [], [], [], [], [], [], [], []
+        step, new_chance, is_adversarial = 0, 0, False
+        while step < n_iter or not is_adversarial:
+            if step > restart_after:
+                new_chance += 1
+                self.pert_model.dynamic_max_norm *= norm_growth
+                step = 0
+            if new_chance == max_restarts:
+                break
+            r = self.step(inputs, target, criterion, lr=lr)
+            adv_class = r["argmax"]
+            is_adversarial = bool((adv_class == target_class_id).all()) if targeted_attack else not bool(adv_class.equal(target))
+            isadv_l.append(is_adversarial)
+            tot.append(float(r["loss"])); adv_l.append(float(r["adv_loss"])); reg_l.append(float(r["reg_loss"]))
+            p = self.pert_model.get_perturbation()[0].cpu().numpy()          # after the update, like model.py:1110-1112
+            pert_l.append(p)
+            thick_l.append(float(np.abs(p).mean())); rough_l.append(float(np.abs(np.roll(p, 1, 1) - p).mean()))
+            maxp_l.append(float(r["softmax"].max())); corr_l.append(float(r["label_prob"][0]))
+            if log_every and step % log_every == 0:
+                print(f"batch {step} of {n_iter} | loss = {tot[-1]:.4f} | adv loss = {adv_l[-1]:.4f} | reg loss = {reg_l[-1]:.4f} | "
+                      f"pert_thickness = {thick_l[-1]:.4f} | pert_roughness = {rough_l[-1]:.4f}", flush=True)
+            step += 1
+        p = self.pert_model.get_perturbation()[0].cpu().numpy()
+        return {"loss/total": tot, "loss/adv_loss": adv_l, "loss/reg_loss": reg_l, "perturbation/thickness": thick_l,
+                "perturbation/roughness": rough_l, "perturbation/inf_norm": float(np.abs(p).max()), "perturbation": pert_l,
+                "prob_clean_input": outputs_no_adv, "label": target.cpu().numpy(), "is_adversarial": isadv_l,
+                "max_prob": maxp_l, "correct_cls_prob": corr_l, "restarts": new_chance}
+
+    def train_an_epoch(self, data_loaders, criterion, metric, lr):
+        """``train_an_epoch`` (model.py:627-789): 'train' then 'valid' over iterables of (inputs, target, _); the valid phase
+        evaluates the same loss without an update.  Result keys as model.py:780-786."""
+        import time
+        result = {}
+        for phase in ("train", "valid"):
+            t0 = time.time()
+            n, loss_sum, miss, valid = 0, 0.0, 0.0, 0.0
+            for inputs, target, *_ in data_loaders[phase]:
+                clean = self.logits(inputs, False).clone()
+                r = self.step(inputs, target, criterion, lr=lr, update=(phase == "train"))
+                adv_logits = self._logits
+                m = metric.accuracy_for_eval(adv_logits, target, topk=(1,), clean_pred=clean)
+                if isinstance(m, tuple):
+                    miss += float(m[0]); valid += float(m[1])
+                else:                                           # targeted: a percentage (model.py:300-302)
+                    miss += float(m) / 100.0 * target.numel(); valid += target.numel()
+                bs = inputs.shape[0]
+                loss_sum += float(r["loss"] if "loss" in r else r["adv_loss"]) * bs
+                n += bs
+            p = self.pert_model.get_perturbation()[0].cpu().numpy()
+            result[f"{phase}/time"] = time.time() - t0
+            result[f"{phase}/loss"] = loss_sum / max(n, 1)
+            result[f"{phase}/fooling_ratio"] = miss / valid if valid else float("nan")
+            result[f"{phase}/pert_thickness"] = float(np.abs(p).mean())
+            result[f"{phase}/pert_roughness"] = float(np.abs(np.roll(p, 1, 1) - p).mean())
+            result[f"{phase}/inf_norm"] = float(np.abs(p).max())
+            result[f"{phase}/perturbation"] = p
+        return result
+
+    def fit(self, data_loaders, criterion, metric, lr=1e-3, epochs=1, lr_gamma=0.1, lr_step_size=None, model_dir=None,
+            model_name=None, save_model=False, start_epoch=1):
+        """``VideoLearnerAdversarial.fit`` (model.py:460-625) with the step-decay schedule (StepLR, model.py:571-573:
+        lr_e = lr * gamma ** floor((e - start_epoch) / lr_step_size), default step = ceil(2/3 * epochs), model.py:496-497).
+        Returns the list of per-epoch result dicts; ``save_model`` writes ``{model_name}_{epoch:03d}.npy`` (model.py:613-619)."""
+        import os
+        if lr_step_size is None:
+            lr_step_size = int(np.ceil(2 / 3 * epochs))
+        results = []
+        for e in range(start_epoch, epochs + 1):
+            lr_e = lr * lr_gamma ** ((e - start_epoch) // max(int(lr_step_size), 1))
+            res = self.train_an_epoch(data_loaders, criterion, metric, lr_e)
+            res["lr"] = lr_e
+            results.append(res)
+            if save_model and model_dir:
+                os.makedirs(model_dir, exist_ok=True)
+                np.save(os.path.join(model_dir, f"{model_name or self.model_name}_{str(e).zfill(3)}.npy"), np.array(results, dtype=object),
+                        allow_pickle=True)
+        return results

@@ -86,3 +86,48 @@ def test_videoresnet_forward_backward(arch):
             big = r64["gtot"].abs() > 0.05 * r64["gtot"].abs().max()
             assert (torch.sign(moved[big]) == -torch.sign(r64["gtot"][big]).float()).all()
         del eng
+
+
+@pytest.mark.gpu
+def test_videoresnet_drivers():
+    """fit_single_video_attack (restart-with-1.3x-norm schedule, model.py:1056-1066) and fit / train_an_epoch (StepLR,
+    model.py:496-497,571-573) around the step: loop control, result keys, schedule; the evaluation-pass regulariser equals
+    the kernel's value."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import Adversarial_metrics, FlickerVideoResNet, Losses
+    arch = "r3d_18"
+    W = vs.synthetic_weights(arch, 42)
+    x = torch.from_numpy(vs.synthetic_clip(1, T, HW, HW, seed=5)).cuda()
+    eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype="f32", l_inf_pert_norm=0.2)
+    label = eng.logits(x, False).argmax(1).clone()
+    crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)
+    # a wrong label -> None (model.py:1030-1032)
+    assert eng.fit_single_video_attack(x, (label + 1) % 400, crit) is None
+    # evaluation pass and update pass report the same regulariser for the same delta
+    r_eval = eng.step(x, label, crit, update=False)
+    r_upd = eng.step(x, label, crit, lr=0.0)
+    assert float(r_eval["reg_loss"]) == pytest.approx(float(r_upd["reg_loss"]), rel=1e-4, abs=1e-14)
+    # restart schedule: a tiny lr never fools the net -> steps 0..restart_after of each chance, norm grown by 1.3 per restart
+    eng.pert_model.dynamic_max_norm = 0.2
+    res = eng.fit_single_video_attack(x, label, crit, lr=1e-9, n_iter=2, restart_after=2, max_restarts=3)
+    assert res["restarts"] == 3 and not any(res["is_adversarial"])
+    assert eng.pert_model.dynamic_max_norm == pytest.approx(0.2 * 1.3 ** 3)
+    assert len(res["loss/total"]) == len(res["perturbation"]) == len(res["is_adversarial"]) == 9     # 3 chances x steps 0,1,2
+    for k in ("loss/total", "loss/adv_loss", "loss/reg_loss", "perturbation/thickness", "perturbation/roughness",
+              "perturbation/inf_norm", "perturbation", "prob_clean_input", "label", "is_adversarial"):
+        assert k in res
+    assert res["perturbation"][0].shape == (3, T, 1, 1)
+    # a real attack terminates once n_iter steps are done and the clip is fooled
+    eng.pert_model.dynamic_max_norm = 0.2
+    eng.pert_model.init_perturbation()
+    res = eng.fit_single_video_attack(x, label, crit, lr=2e-2, n_iter=3, restart_after=200, max_restarts=2)
+    assert len(res["loss/total"]) >= 3 and (res["is_adversarial"][-1] or res["restarts"] == 2)
+    # epochs: StepLR with the default step = ceil(2/3 epochs)
+    dl = {"train": [(x, label, None)] * 2, "valid": [(x, label, None)]}
+    out = eng.fit(dl, crit, Adversarial_metrics(), lr=1e-3, epochs=3, lr_gamma=0.1)
+    assert [r["lr"] for r in out] == pytest.approx([1e-3, 1e-3, 1e-4])
+    for r in out:
+        for ph in ("train", "valid"):
+            assert 0.0 <= r[f"{ph}/fooling_ratio"] <= 1.0 and np.isfinite(r[f"{ph}/loss"]) and r[f"{ph}/perturbation"].shape == (3, T, 1, 1)
