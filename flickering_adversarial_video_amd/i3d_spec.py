@@ -72,3 +72,17 @@ def synthetic_i3d_weights(seed=42):
 def synthetic_clip_u8(B, T, H=224, W=224, seed=1234):
     """uint8 clips as the TFRecord path delivers them (pre_process_rgb_flow.py:226-234): x = u8/128 - 1."""
     return np.random.default_rng(seed).integers(0, 256, (B, T, H, W, 3), dtype=np.uint8)
+
+
+def load_i3d_weights(model_cfg):
+    """Weights for FlickerI3D from the MODEL section of run_config.yml: ``WEIGHTS_NPZ`` ({variable name: array} archive) if
+    set, else the TF checkpoint ``CKPT_PATH`` (the reference's ``init_model``, kinetics_i3d_utils.py:41-62, read without
+    TensorFlow by tf_checkpoint.py) if its ``.index`` file exists, else seeded synthetic weights."""
+    import os
+    if model_cfg.get("WEIGHTS_NPZ"):
+        return dict(np.load(model_cfg["WEIGHTS_NPZ"])), "npz"
+    ckpt = model_cfg.get("CKPT_PATH")
+    if ckpt and os.path.exists(ckpt + ".index"):
+        from .tf_checkpoint import load_i3d_checkpoint
+        return load_i3d_checkpoint(ckpt, "RGB"), "tf-checkpoint"
+    return synthetic_i3d_weights(42), "synthetic"

@@ -70,7 +70,8 @@ def main():
     c = cfg.SINGLE_VIDEO_ATTACK
     T = a.frames or cfg.MODEL.FRAMES
     classes = cfgmod.load_kinetics_classes(cfg.DATA.LABEL_MAP_PATH)
-    W = dict(np.load(cfg.MODEL.WEIGHTS_NPZ)) if cfg.MODEL.WEIGHTS_NPZ else i3d_spec.synthetic_i3d_weights(42)
+    W, wsrc = i3d_spec.load_i3d_weights(cfg.MODEL)
+    print(f"I3D weights: {wsrc}", flush=True)
     eng = FlickerI3D(W, batch_size=1, frames=T, dtype=a.dtype or cfg.MODEL.DTYPE)
     os.makedirs(c.PKL_RESULT_PATH, exist_ok=True)
     target_id = classes.index(c.TARGETED_CLASS) if c.TARGETED_ATTACK else None

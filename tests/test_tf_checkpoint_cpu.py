@@ -1,0 +1,90 @@
+"""TF-free checkpoint bundle and TensorBoard event files: round trips, table structure, error paths."""
+import struct
+
+import numpy as np
+import pytest
+
+from flickering_adversarial_video_amd import tb_events, tf_checkpoint as tc
+from flickering_adversarial_video_amd.tfrecord_io import masked_crc
+
+
+def _tensors(n=40, seed=0):
+    rng = np.random.default_rng(seed)
+    t = {}
+    for i in range(n):
+        t[f"RGB/inception_i3d/Mixed_{i // 7}b/Branch_{i % 4}/Conv3d_0a_1x1/conv_3d/w"] = rng.standard_normal((1, 1, 1, 3 + i, 5)).astype(np.float32)
+        t[f"RGB/inception_i3d/Mixed_{i // 7}b/Branch_{i % 4}/Conv3d_0a_1x1/batch_norm/moving_mean_{i}"] = rng.standard_normal((1, 1, 1, 1, 5)).astype(np.float32)
+    t["global_step"] = np.array(1234, dtype=np.int64)
+    t["Flow/other"] = np.arange(6, dtype=np.int32).reshape(2, 3)
+    t["RGB/half"] = rng.standard_normal(7).astype(np.float16)
+    return t
+
+
+def test_bundle_round_trip(tmp_path):
+    t = _tensors()
+    prefix = str(tmp_path / "ckpt" / "model.ckpt")
+    tc.write_bundle(prefix, t)
+    back = tc.read_bundle(prefix, verify_crc=True)
+    assert set(back) == set(t)
+    for k in t:
+        assert back[k].dtype == t[k].dtype and back[k].shape == t[k].shape and np.array_equal(back[k], t[k]), k
+    lv = tc.list_variables(prefix)
+    assert lv["global_step"] == (9, ()) and lv["Flow/other"] == (3, (2, 3))
+    rgb = tc.load_i3d_checkpoint(prefix, "RGB")
+    assert rgb and all(k.startswith("RGB/") for k in rgb) and "Flow/other" not in rgb
+    assert set(tc.read_bundle(prefix, names=["global_step"])) == {"global_step"}
+
+
+def test_table_blocks_and_prefix_compression(tmp_path):
+    # many keys with long shared prefixes over several data blocks: exercises restarts, shared-prefix decoding, the index block
+    items = [(f"scope/layer_{i:04d}/kernel".encode(), bytes([i % 251]) * (i % 17)) for i in range(500)]
+    p = str(tmp_path / "t.index")
+    tc.write_table(p, items, block_size=512)
+    assert tc.read_table(p, verify=True) == items
+    raw = open(p, "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == tc.TABLE_MAGIC
+    # a hand-built single-entry block decodes: shared=0, unshared=3, vlen=2, "abc", "xy", restarts [0], 1
+    blk = bytes([0, 3, 2]) + b"abcxy" + struct.pack("<II", 0, 1)
+    assert list(tc._block_entries(memoryview(blk))) == [(b"abc", b"xy")]
+
+
+def test_bundle_errors(tmp_path):
+    prefix = str(tmp_path / "m")
+    tc.write_bundle(prefix, {"a": np.ones(3, np.float32)})
+    raw = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    raw[0] ^= 0xFF
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="crc"):
+        tc.read_bundle(prefix, verify_crc=True)
+    assert tc.read_bundle(prefix)["a"].shape == (3,)                    # unverified read still works
+    bad = str(tmp_path / "bad.index")
+    open(bad, "wb").write(b"\x00" * 64)
+    with pytest.raises(ValueError, match="magic"):
+        tc.read_table(bad)
+    with pytest.raises(TypeError):
+        tc.write_bundle(str(tmp_path / "c"), {"s": np.array(["x"])})
+
+
+def test_bfloat16_entry(tmp_path):
+    # a DT_BFLOAT16 entry (code 14) written by hand reads back as float32
+    prefix = str(tmp_path / "b")
+    vals = np.array([1.0, -2.5, 0.15625], np.float32)
+    raw = (vals.view(np.uint32) >> 16).astype(np.uint16).tobytes()
+    open(prefix + ".data-00000-of-00001", "wb").write(raw)
+    header = bytes([0x08, 0x01])
+    tc.write_table(prefix + ".index", [(b"", header), (b"w", tc._enc_entry(14, (3,), 0, len(raw), masked_crc(raw)))])
+    assert np.array_equal(tc.read_bundle(prefix, verify_crc=True)["w"], vals)
+
+
+def test_tensorboard_scalars(tmp_path):
+    w = tb_events.SummaryWriter(str(tmp_path / "train"))
+    host = dict(total_loss=1.5, adv_loss=1.0, reg_loss=0.5, norm_reg=0.1, diff_norm_reg=0.2, laplacian_norm_reg=0.3,
+                thickness_relative=2.0, roughness_relative=3.0, pert_max=0.01, pert_min=-0.02, prob_to_min=0.9, prob_to_max=0.05)
+    w.add_step_result(50, host, beta0=2.0)
+    w.add_scalars(100, {"Loss/total": 0.25})
+    w.close()
+    ev = tb_events.read_scalars(w.path)
+    assert [s for s, _ in ev] == [50, 100]
+    assert set(ev[0][1]) == set(tb_events.SCALAR_TAGS) | {"Loss/regularizer_loss_weighted"}
+    assert ev[0][1]["Loss/regularizer_loss_weighted"] == pytest.approx(1.0) and ev[0][1]["Perturbation/min"] == pytest.approx(-0.02)
+    assert ev[1][1] == {"Loss/total": 0.25}
