@@ -237,3 +237,23 @@ class FlickerI3D:
             clean = self.logits(x, 0.0, 0).argmax(-1) if exclude_misclassify else None
             cnt.update(adv, clean, y, targeted_attack, target_class_id, exclude_misclassify)
         return cnt.result(self.pg)
+
+
+class FlickerI3DInference(FlickerI3D):
+    """``kinetics_i3d_inference`` (kinetics_i3d_utils.py:574-647): softmax of a clip under a FIXED perturbation with
+    independent random rolls of the clip (``cyclic_input_flag``) and of the perturbation (``cyclic_eps_flag``).  Unlike the
+    training graph the perturbation is not clipped to +-0.4 here (kinetics_i3d_utils.py:619-624); only the perturbed clip
+    is clipped to [-1, 1]."""
+
+    def set_perturbation(self, delta):
+        """load eps_rgb ([T,1,1,3] or [T,3]), e.g. ``tf_checkpoint.read_bundle(ckpt)['RGB/eps']``"""
+        self.reset_perturbation(delta)
+
+    def __call__(self, inputs, adv_flag=0, cyclic_input_flag=0, cyclic_eps_flag=0):
+        x = self._check_x(inputs)
+        self.last_shift_x = int(self._rng.integers(0, self.T)) if cyclic_input_flag else 0
+        self.last_shift_p = int(self._rng.integers(0, self.T)) if cyclic_eps_flag else 0
+        a = ops.make_apply_args(x, self.eps_rgb, dialect="tf", dclip=0.0, adv_flag=float(adv_flag), shift_x=self.last_shift_x,
+                                shift_p=self.last_shift_p)
+        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
+        return torch.softmax(self.net.forward(self._xs2d, self._logits), -1)
