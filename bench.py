@@ -98,7 +98,7 @@ def bench_videoresnet(a, world, rank, local_rank):
     elapsed = time.perf_counter() - t0
     value = B * a.steps / elapsed
     tf = VRN_GFLOP[a.model] * (T / 16.0) * value / 1e3
-    out = {"metric": f"attack-iters/sec ({a.model} 16x112x112 single-video attack) + 3D-conv TFLOP/s", "value": value,
+    out = {"metric": f"attack-iters/sec ({a.model} {T}x112x112, bs={B} single-video attack) + 3D-conv TFLOP/s", "value": value,
            "unit": "clip-iters/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
            "data": "synthetic (seeded normalised fp32 clip resident in HBM, seeded weights)", "conv_tflops": tf,
@@ -176,7 +176,7 @@ def main():
     value = B * world * a.steps / elapsed
     conv_tflops = conv_gflop_per_clip(T) * value / 1e3
     out = {
-        "metric": "attack-iters/sec (I3D 64x224x224, bs=8 per GPU; clip attack-iterations per second, whole job) + 3D-conv TFLOP/s",
+        "metric": f"attack-iters/sec (I3D {T}x224x224, bs={B} per GPU; clip attack-iterations per second, whole job) + 3D-conv TFLOP/s",
         "value": value, "unit": "clip-iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.dtype, "data": "synthetic (seeded uint8 clips resident in HBM, seeded He-normal weights)",
