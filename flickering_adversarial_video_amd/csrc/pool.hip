@@ -148,6 +148,89 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
   }
 }
 
+// Backward of the STRIDED pools (MaxPool3d_2a/3a/4a/5a, i3d.py:174,189,252,398; pad-before 0, window <= 2 * stride):
+// one thread = one output window x one 16-byte channel group, and it OWNS the stride^3 input cells o*s + a, a in [0,s).
+// A cell is covered by its own window (tap a) and, where a + s < k, by the previous window of that dimension (tap
+// a + s): every thread loads the index bytes and gradients of its <= 8 candidate windows up front (independent loads,
+// shared with its neighbours through L1/L2), then resolves its cells in registers in a fixed order -- no atomics,
+// no dependent load chains, and each gradient cell is written exactly once (64-byte runs per thread).
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW>
+__global__ __launch_bounds__(256) void maxpool_strided_bwd(const PoolKP p) {
+  constexpr int EPL = PV<T>::EPL;
+  constexpr int NT = KT > ST ? 2 : 1, NH = KH > SH ? 2 : 1, NW = KW > SW ? 2 : 1;     // candidate windows per dimension
+  static_assert(KT <= 2 * ST && KH <= 2 * SH && KW <= 2 * SW, "a cell may see at most two windows per dimension");
+  const int ng = p.C / EPL;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)(p.Wo * ng)) return;
+  const int ow = i / ng, cg = i - ow * ng;
+  const int oh = blockIdx.y, ot = blockIdx.z % p.To, b = blockIdx.z / p.To;
+  int id[NT * NH * NW][EPL];
+  float go[NT * NH * NW][EPL];
+  bool ok[NT * NH * NW];
+#pragma unroll
+  for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+    for (int dh = 0; dh < NH; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < NW; ++dw) {
+        const int w = (dt * NH + dh) * NW + dw;
+        ok[w] = ot - dt >= 0 && oh - dh >= 0 && ow - dw >= 0;
+        const size_t opos = (((size_t)(b * p.To + max(ot - dt, 0)) * p.Ho + max(oh - dh, 0)) * p.Wo + max(ow - dw, 0));
+        PV<T>::ldidx(p.idx + opos * p.C + cg * EPL, id[w]);
+        PV<T>::ld(p.gout + (opos * p.gout_ld + p.gout_coff + cg * EPL) * sizeof(T), go[w]);
+      }
+#pragma unroll
+  for (int at = 0; at < ST; ++at)
+#pragma unroll
+    for (int ah = 0; ah < SH; ++ah)
+#pragma unroll
+      for (int aw = 0; aw < SW; ++aw) {
+        const int it = ot * ST + at, ih = oh * SH + ah, iw = ow * SW + aw;
+        if (it >= p.Ti || ih >= p.Hi || iw >= p.Wi) continue;
+        float g[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) g[e] = 0.f;
+        // candidates in ascending window order (the order the simple gather kernel uses): previous window first
+#pragma unroll
+        for (int dt = NT - 1; dt >= 0; --dt)
+#pragma unroll
+          for (int dh = NH - 1; dh >= 0; --dh)
+#pragma unroll
+            for (int dw = NW - 1; dw >= 0; --dw) {
+              const int tt = at + dt * ST, th = ah + dh * SH, tw = aw + dw * SW;
+              if (tt >= KT || th >= KH || tw >= KW) continue;                    // compile-time after unrolling
+              const int w = (dt * NH + dh) * NW + dw, tap = (tt * KH + th) * KW + tw;
+              if (!ok[w]) continue;
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) g[e] += id[w][e] == tap ? go[w][e] : 0.f;
+            }
+        const size_t ipos = (((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw);
+        if (p.mask) {
+          float mk[EPL];
+          PV<T>::ld(p.mask + (ipos * p.mask_ld + p.mask_coff + cg * EPL) * sizeof(T), mk);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) g[e] = mk[e] > 0.f ? g[e] : 0.f;
+        }
+        PV<T>::st(p.gin + (ipos * p.gin_ld + p.gin_coff + cg * EPL) * sizeof(T), g);
+      }
+}
+
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW>
+static int launch_strided_bwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t s) {
+  constexpr int EPL = PV<T>::EPL;
+  FLK_REQUIRE(a->Ho < 65536 && (long)a->B * a->To < 65536, "flk_maxpool3d_bwd: grid too large");
+  const dim3 grid((unsigned)((a->Wo * (a->C / EPL) + 255) / 256), (unsigned)a->Ho, (unsigned)(a->B * a->To));
+  hipLaunchKernelGGL((maxpool_strided_bwd<T, KT, KH, KW, ST, SH, SW>), grid, dim3(256), 0, s, kp);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+// the owner form needs pad-before 0 and every input cell inside some window's stride box
+static bool strided_owner_ok(const flk_pool_args* a, int kt, int kh, int kw, int st, int sh, int sw) {
+  return a->kt == kt && a->kh == kh && a->kw == kw && a->st == st && a->sh == sh && a->sw == sw && a->pt == 0 && a->ph == 0 &&
+         a->pw == 0 && a->Ti <= a->To * st && a->Hi <= a->Ho * sh && a->Wi <= a->Wo * sw;
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS-tiled variants for stride-1 SAME pooling with an odd window (the Inception branch-3 pool, i3d.py:212):
 // every cell is touched by kt*kh*kw windows, so the simple kernels above read each byte 27x through L1/L2.
@@ -647,6 +730,16 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
   kp.add = nullptr;
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_maxpool3d_bwd: bad dtype");
   static const bool use_gather = getenv("FLK_POOL_GATHER") != nullptr;     // bitwise-reproducible gather forms on request
+  static const bool no_owner = getenv("FLK_POOL_NO_OWNER") != nullptr;
+  if (!no_owner) {
+    hipStream_t s = (hipStream_t)stream;
+#define FLK_OWNER(KT, KH, KW, ST, SH, SW)                                                                   \
+    if (strided_owner_ok(a, KT, KH, KW, ST, SH, SW))                                                          \
+      return dtype == FLK_BF16 ? launch_strided_bwd<bf16_t, KT, KH, KW, ST, SH, SW>(kp, a, s)                 \
+                               : launch_strided_bwd<float, KT, KH, KW, ST, SH, SW>(kp, a, s)
+    FLK_OWNER(1, 3, 3, 1, 2, 2); FLK_OWNER(3, 3, 3, 2, 2, 2); FLK_OWNER(2, 2, 2, 2, 2, 2);
+#undef FLK_OWNER
+  }
   if (!use_gather)
     return dtype == FLK_BF16 ? launch_scatter_bwd<bf16_t>(kp, a, (hipStream_t)stream) : launch_scatter_bwd<float>(kp, a, (hipStream_t)stream);
   if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, true, (hipStream_t)stream) : launch_tiled<float>(kp, a, true, (hipStream_t)stream);
