@@ -102,6 +102,56 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
   }
 }
 
+// Fast path of the headline configuration (uint8 clip, flicker delta [T,3], FT = 2, W % 8 == 0): one thread = 4
+// consecutive output positions.  It reads its 24 source bytes of each of the 4 (frame, row) pairs as three aligned
+// 8-byte loads (the generic kernel above issues 2-byte loads), evaluates the 6 perturbation values (2 frames x RGB) once,
+// and decodes its position with 32-bit arithmetic from a 3-D grid.  Same arithmetic per element as the generic kernel.
+template <typename TO>
+__global__ __launch_bounds__(256) void apply_s2d_u8_flicker_kernel(const flk_apply_args a, char* out) {
+  constexpr int NCH = 32;
+  const int H2 = a.H / 2, W2 = a.W / 2, WG = W2 / 4;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)(H2 * WG)) return;
+  const int h2 = i / WG, wg = i - h2 * WG;
+  const int t2 = blockIdx.y, b = blockIdx.z;
+  float pv[2][3];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pv[qt][c] = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, 2 * t2 + qt, 0, 0, c) : 0.f;
+  uint2 raw[2][2][3];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int tx = wrap(2 * t2 + qt - a.shift_x, a.T);
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      const uint2* src = (const uint2*)((const uint8_t*)a.x + ((((size_t)b * a.T + tx) * a.H + 2 * h2 + qh) * a.W + 8 * wg) * 3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) raw[qt][qh][k] = src[k];
+    }
+  }
+  char* dst = out + ((((size_t)b * (a.T / 2) + t2) * H2 + h2) * W2 + 4 * wg) * NCH * sizeof(TO);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                   // output position 4*wg + j: source pixels 2j, 2j+1 of the 8-pixel run
+    float v[NCH];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int qh = 0; qh < 2; ++qh) {
+        const uint32_t w[6] = {raw[qt][qh][0].x, raw[qt][qh][0].y, raw[qt][qh][1].x, raw[qt][qh][1].y, raw[qt][qh][2].x, raw[qt][qh][2].y};
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {              // byte 6j + e of the 24-byte run
+          const int bi = 6 * j + e;
+          const float x = (float)((w[bi >> 2] >> (8 * (bi & 3))) & 255u) * a.x_scale + a.x_bias;
+          v[(qt * 4 + qh * 2 + e / 3) * 3 + e % 3] = clipf(x + pv[qt][e % 3], a.lo, a.hi);
+        }
+      }
+#pragma unroll
+    for (int k = 24; k < NCH; ++k) v[k] = 0.f;
+    store_ch<TO, NCH>(dst + (size_t)j * NCH * sizeof(TO), v);
+  }
+}
+
 static int check_apply(const flk_apply_args* a) {
   FLK_REQUIRE(a && a->x && a->delta, "flk_perturb: null argument");
   FLK_REQUIRE(a->fold_t == 0 || a->fold_t == 1 || a->fold_t == 2, "flk_perturb: fold_t must be 0, 1 or 2");
@@ -119,6 +169,14 @@ extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dty
   const long total = (long)a->B * (a->T / ft) * (a->H / 2) * (a->W / 2);
   const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
+  if (ft == 2 && a->x_is_u8 && !a->delta_dense && a->W % 8 == 0 && a->T / 2 < 65536 && a->B < 65536 && !getenv("FLK_APPLY_GENERIC")) {
+    const dim3 g3((unsigned)(((a->H / 2) * (a->W / 8) + 255) / 256), (unsigned)(a->T / 2), (unsigned)a->B);
+    if (dtype == FLK_BF16) hipLaunchKernelGGL(apply_s2d_u8_flicker_kernel<bf16_t>, g3, dim3(256), 0, st, *a, (char*)out);
+    else if (dtype == FLK_F32) hipLaunchKernelGGL(apply_s2d_u8_flicker_kernel<float>, g3, dim3(256), 0, st, *a, (char*)out);
+    else { flk_set_error("flk_perturb_apply_s2d: bad dtype"); return FLK_EINVAL; }
+    FLK_CHECK_HIP(hipGetLastError());
+    return FLK_OK;
+  }
   if (dtype == FLK_BF16 && ft == 2) hipLaunchKernelGGL((apply_s2d_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
   else if (dtype == FLK_BF16) hipLaunchKernelGGL((apply_s2d_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
   else if (dtype == FLK_F32 && ft == 2) hipLaunchKernelGGL((apply_s2d_kernel<float, 2>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
