@@ -86,10 +86,11 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // every wave owns 64 rows x 16*NF/WN channels.  WN > 1 trades weight re-streaming for more workgroups on the layers
 // with few output positions (Mixed_4*/Mixed_5*).
 // MODE 0: weights through the LDS ring (wide wave tiles).  MODE 1: every wave streams its own fragments into registers
-// ("direct A").  MODE 2: direct A for a 1x1x1 convolution (activation slabs prefetched in depth as well).
+// ("direct A").  MODE 2: direct A for a 1x1x1 convolution (activation slabs prefetched in depth as well).  MODE 3: LDS ring
+// for a 1x1x1 convolution with wide wave tiles, activations and weights prefetched in depth with hand-counted waits.
 template <typename T, int NF, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
-  constexpr bool K1 = MODE == 2;
+  constexpr bool K1 = MODE == 2 || MODE == 3;
   typedef Prec<T> PR;
   typedef typename PR::frag frag;
   constexpr int EPL = PR::EPL;
@@ -127,11 +128,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 
   // ---- staging plan: pair n of this thread = (halo position (tid>>2) + 64 n, chunk tid&3) ----
   const int ch = tid & 3;
-  int goff[NPAIR];  // linear input position of the pair, -1 = zero fill (padding), -2 = beyond the halo
+  constexpr int NPK = K1 ? 4 : NPAIR;   // 1x1x1 tiles have P <= 256: 4 pairs per thread
+  int goff[NPK];  // linear input position of the pair, -1 = zero fill (padding), -2 = beyond the halo
   {
     const int HW = p.Hh * p.Wh;
 #pragma unroll
-    for (int n = 0; n < NPAIR; ++n) {
+    for (int n = 0; n < NPK; ++n) {
       const int hp = (tid >> 2) + 64 * n;
       int g = -2;
       if (hp < p.P) {
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         const char* src; int ld;
         const bool chvalid = slab_src(s, src, ld);
   #pragma unroll
-        for (int n0 = 0; n0 < NPAIR; n0 += 4) {
+        for (int n0 = 0; n0 < NPK; n0 += 4) {
           if (n0 * 64 >= p.P) break;
           uint4 v[4];
   #pragma unroll
@@ -270,6 +272,88 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       }
     }
 
+  } else if constexpr (MODE == 3) {
+    // ---- 1x1x1 convolution, wide wave tiles: a GEMM whose K loop is only cin/32 steps long, each step a new slab from
+    // HBM.  Activation slabs run D steps ahead and weight chunks 2 steps ahead in register queues, issued from inline
+    // asm in a FIXED order (every step: W(k+2) then A(k+D); the prologue replays that order from step -D), so one
+    // hand-counted s_waitcnt vmcnt(N) per step retires exactly what the step consumes.
+    static_assert(WN == 1, "mode 3 shares the weights through LDS");
+    constexpr int D = NF >= 8 ? 2 : 4;
+    constexpr int NWAIT = D == 2 ? WCH + 4 : 8 + WCH;      // loads younger than the youngest load step k consumes
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int wchunk = NF >= 4 ? tid : (tid & 127);
+    const char* const wfirst = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
+    const char* const wlast = wfirst + (size_t)(nsteps - 1) * wstep;
+    u32x4 pre[D][4], wq[2][2];
+    auto aload = [&](u32x4 (&dst)[4], int s) {
+      const char* src; int ld;
+      const bool chvalid = slab_src(s < p.nslab ? s : p.nslab - 1, src, ld);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const char* ptr = src + (size_t)((goff[n] >= 0 && chvalid) ? goff[n] : 0) * ld * sizeof(T);   // position 0 is always readable
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[n]) : "v"(ptr) : "memory");
+      }
+    };
+    auto wload = [&](u32x4 (&dst)[2], int k) {
+      const char* ws = wfirst + (size_t)k * wstep;
+      ws = ws < wlast ? ws : wlast;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0]) : "v"(ws) : "memory");
+      if constexpr (WCH == 2) {
+        const char* ws1 = ws + 4096;                                    // (beyond the 13-bit immediate offset)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[1]) : "v"(ws1) : "memory");
+      }
+    };
+#pragma unroll
+    for (int k = -D; k < 0; ++k) {                          // the steady-state issue order, replayed from step -D
+      if (k + 2 >= 0) wload(wq[(k + 2) & 1], k + 2);
+      aload(pre[(k + D) % D], k + D);
+    }
+    constexpr int U = D < 2 ? 2 : D;                        // unroll so that both queues are indexed statically
+    for (int k0 = 0; k0 < nsteps; k0 += U) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int kk = k0 + j;
+        if (kk >= nsteps) break;
+        u32x4 (&a4)[4] = pre[j % D];
+        u32x4 (&w2)[2] = wq[j & 1];
+        if constexpr (WCH == 2)
+          asm volatile("s_waitcnt vmcnt(%6) ; release %0 %1 %2 %3 %4 %5" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]), "+v"(w2[0]), "+v"(w2[1]) : "i"(NWAIT) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%5) ; release %0 %1 %2 %3 %4" : "+v"(a4[0]), "+v"(a4[1]), "+v"(a4[2]), "+v"(a4[3]), "+v"(w2[0]) : "i"(NWAIT) : "memory");
+        const int hsel = (kk & 1) * halo_bytes;
+        {
+          const char* src; int ld;
+          const bool chvalid = slab_src(kk, src, ld);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if (goff[n] == -2) continue;
+            const u32x4 v = (goff[n] >= 0 && chvalid) ? a4[n] : u32x4{0u, 0u, 0u, 0u};
+            *(u32x4*)(hdst + hsel + n * 1024) = v;
+          }
+        }
+        char* const wcur = wbuf + (kk & 1) * (NF * 1024);
+        *(u32x4*)(wcur + wchunk * 16) = w2[0];
+        if (WCH == 2) *(u32x4*)(wcur + wchunk * 16 + 4096) = w2[1];
+        // unconditional (clamped past the end): every queue register has ONE definition per step on every path, so the
+        // compiler has no reason to copy a register whose load is still in flight (tools/audit_asm_loads.py checks this)
+        wload(w2, kk + 2);
+        aload(a4, kk + D);
+        __syncthreads();
+        if (wave_active) {
+          frag bf[4], af[NFW];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + hsel + rowpos[i]);
+#pragma unroll
+          for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int f = 0; f < NFW; ++f)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   } else {
     // ---- narrow wave tiles (WN >= 2) and small grids of narrow channel tiles: few MFMAs per K step, so one step is
     // far shorter than a memory round trip or a workgroup barrier.  Every wave reads ITS OWN weight fragments straight
@@ -295,12 +379,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       if constexpr (NFW > 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072" : "=v"(dst[3]) : "v"(ws) : "memory");
     };
     // wait until at most N of the loads issued so far are outstanding, and make the queue entry depend on that wait
+    // wait until at most N of the loads issued so far are outstanding, and make the queue entry depend on that wait
     auto wwait = [&](u32x4 (&q)[NFW]) {
       constexpr int N = (D - 1) * NFW;
-      if constexpr (NFW == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(q[0]), "+v"(q[1]) : "i"(N) : "memory");
+      if constexpr (NFW == 2) asm volatile("s_waitcnt vmcnt(%2) ; release %0 %1" : "+v"(q[0]), "+v"(q[1]) : "i"(N) : "memory");
       else if constexpr (NFW == 4)
-        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "i"(N) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(q[0]) : "i"(N) : "memory");
+        asm volatile("s_waitcnt vmcnt(%4) ; release %0 %1 %2 %3" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) : "i"(N) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%1) ; release %0" : "+v"(q[0]) : "i"(N) : "memory");
     };
     static_assert(NFW == 1 || NFW == 2 || NFW == 4, "queue wait is written for 1, 2 or 4 fragments per wave");
 #pragma unroll
@@ -350,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
             const char* src; int ld;
             const bool chvalid = slab_src(s, src, ld);
 #pragma unroll
-            for (int n0 = 0; n0 < NPAIR; n0 += 4) {
+            for (int n0 = 0; n0 < NPK; n0 += 4) {
               if (n0 * 64 >= p.P) break;
               uint4 v[4];
 #pragma unroll
@@ -374,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) PR::mma(__builtin_bit_cast(frag, wq[j][f]), bf[i], acc[f][i]);
         }
-        wload(wq[j], wnext);          // refill this queue slot for step kk + D
+        wload(wq[j], wnext);          // refill this queue slot for step kk + D (clamped past the end: never used)
         wnext += wstep;
         if (!K1) {   // next tap (scalar state): w fastest, then h, then t, then the next slab
           if (++dw < p.kw) tapoff += 16;
@@ -590,10 +675,12 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   {
     static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
     const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);
-    if (wn >= 2 || narrow_small) mode = (kp.ntaps == 1 && kp.P <= 256) ? 2 : 1;
+    const bool k1 = kp.ntaps == 1 && kp.P <= 256;
+    if (wn >= 2 || narrow_small) mode = k1 ? 2 : 1;
+    else if (k1 && kp.nslab >= 4 && !getenv("FLK_CONV_NO_K1")) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
   }
   // two halo images for small halos; the LDS weight ring only in mode 0
-  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + (mode == 0 ? 2 * (size_t)nf * 1024 : 0);
+  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3) ? 2 * (size_t)nf * 1024 : 0);
   {
     static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
     if (dbg)
@@ -601,7 +688,9 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
               a->kt, a->kh, a->kw, a->st, a->sh, a->sw, a->cin, a->cout, a->B, a->To, a->Ho, a->Wo, nf, wn, kp.Tt, kp.Ht, kp.Wt,
               kp.rows, kp.P, ptiles * ntile_n, mode, lds);
   }
-#define FLK_LAUNCH0(TT, NFv, WNv) if (nf == NFv && wn == WNv && mode == 0) return launch<TT, NFv, WNv, 0>(kp, grid, lds, s)
+#define FLK_LAUNCH0(TT, NFv, WNv)                                                           \
+  if (nf == NFv && wn == WNv && mode == 0) return launch<TT, NFv, WNv, 0>(kp, grid, lds, s); \
+  if (nf == NFv && wn == WNv && mode == 3) return launch<TT, NFv, WNv, 3>(kp, grid, lds, s)
 #define FLK_LAUNCHD(TT, NFv, WNv)                                                         \
   if (nf == NFv && wn == WNv && mode == 1) return launch<TT, NFv, WNv, 1>(kp, grid, lds, s); \
   if (nf == NFv && wn == WNv && mode == 2) return launch<TT, NFv, WNv, 2>(kp, grid, lds, s)

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Static audit of the hand-issued asynchronous loads in conv_igemm.hip (cdna_hip_programming.md, "What hipcc does not do", 1).
+
+The direct-A / mode-3 K loops issue `global_load_dwordx4` from inline asm and retire them with hand-counted
+`s_waitcnt vmcnt(N)` statements that name the destination registers ("; release v[a:b] ...").  hipcc treats an asm load's
+destination as written when the statement ends, so nothing stops it from copying, spilling or reusing such a register
+while the data is still in flight -- which shows up as garbage operands or a memory fault.  This script compiles the file
+to assembly and checks, for every kernel, that on no path between an asm load and the wait statement that releases its
+destination a compiler-generated instruction reads or writes that register (forward dataflow over the kernel's CFG).
+
+Usage: audit_asm_loads.py [path/to/conv_igemm.hip]   (exit code 1 on a violation).  Needs hipcc; no GPU."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def compile_asm(src):
+    hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc") if c and (os.path.exists(c) or c == "hipcc")), "hipcc")
+    out = os.path.join(tempfile.mkdtemp(prefix="flk_audit_"), "k.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def audit_kernel(name, lines):
+    """lines: the kernel body.  Forward may-dataflow of the set of registers with an asm load in flight over the kernel's
+    control-flow graph (gen: asm load destination; kill: a wait statement that names the register, or any vmcnt(0));
+    every compiler-generated instruction is then checked against the set that can reach it.
+    Returns (number of asm loads, list of violations)."""
+    # ---- instructions: (kind, payload)
+    ins, in_asm = [], False
+    for raw in lines:
+        st = raw.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if st.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", raw)
+        if m:
+            ins.append(("label", m.group(1), raw))
+            continue
+        code = st.split(";")[0].strip()
+        if in_asm:
+            if "global_load_dwordx4" in st:
+                ins.append(("gen", regs_of(st.split(",")[0]), raw))
+            elif "s_waitcnt" in st and "vmcnt" in st:
+                ins.append(("kill", regs_of(st.split("release", 1)[1]) if "release" in st else (None if "vmcnt(0)" in st else set()), raw))
+            continue
+        if not code or code.startswith(".") or code.endswith(":"):
+            continue
+        mb = re.match(r"(s_cbranch\w*|s_branch)\s+(\.LBB\d+_\d+)", code)
+        if mb:
+            ins.append(("branch", (mb.group(1) == "s_branch", mb.group(2)), raw))
+        elif code.startswith("s_endpgm"):
+            ins.append(("end", None, raw))
+        elif code.startswith("s_waitcnt") and "vmcnt(0)" in code:
+            ins.append(("kill", None, raw))                  # a compiler drain retires the hand-issued loads as well
+        else:
+            ins.append(("op", regs_of(code), raw))
+    # ---- basic blocks
+    starts = {0}
+    for i, (k, p, _) in enumerate(ins):
+        if k == "label":
+            starts.add(i)
+        if k in ("branch", "end") and i + 1 < len(ins):
+            starts.add(i + 1)
+    starts = sorted(starts)
+    block_of = {s0: n for n, s0 in enumerate(starts)}
+    label_block = {p: block_of[i] for i, (k, p, _) in enumerate(ins) if k == "label"}
+    blocks = [(s0, starts[n + 1] if n + 1 < len(starts) else len(ins)) for n, s0 in enumerate(starts)]
+    succ = []
+    for n, (lo, hi) in enumerate(blocks):
+        k, p, _ = ins[hi - 1]
+        out = []
+        if k == "branch":
+            if p[1] in label_block:
+                out.append(label_block[p[1]])
+            if not p[0] and n + 1 < len(blocks):
+                out.append(n + 1)
+        elif k != "end" and n + 1 < len(blocks):
+            out.append(n + 1)
+        succ.append(out)
+
+    def transfer(n, inset, check):
+        cur = set(inset)
+        for i in range(*blocks[n]):
+            k, p, raw = ins[i]
+            if k == "gen":
+                cur |= p
+            elif k == "kill":
+                cur = set() if p is None else cur - p
+            elif k == "op" and check and cur & p:
+                check.append((i, sorted(cur & p), raw.strip()))
+        return cur
+
+    inn = [set() for _ in blocks]
+    work = [0]
+    seen_out = [None] * len(blocks)
+    while work:
+        n = work.pop()
+        out = transfer(n, inn[n], None)
+        if seen_out[n] is not None and out <= seen_out[n]:
+            continue
+        seen_out[n] = out if seen_out[n] is None else seen_out[n] | out
+        for m in succ[n]:
+            if not out <= inn[m]:
+                inn[m] |= out
+                work.append(m)
+            elif seen_out[m] is None:
+                work.append(m)
+    violations = []
+    for n in range(len(blocks)):
+        transfer(n, inn[n], violations)
+    return sum(1 for k, _, _ in ins if k == "gen"), violations
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_igemm.hip")
+    text = compile_asm(src)
+    bad = total = 0
+    for m in re.finditer(r"^(_Z\S*conv_igemm_kernel\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+        name, body = m.group(1), m.group(2).split("\n")
+        nloads, viol = audit_kernel(name, body)
+        if nloads:
+            total += 1
+            uniq = sorted({(v[0], tuple(v[1]), v[2]) for v in viol})
+            print(f"{name}: {nloads} asm loads, {len(uniq)} violation(s)")
+            for i, regs, l in uniq[:10]:
+                print(f"    line {i}: touches in-flight v{list(regs)}: {l}")
+            bad += bool(uniq)
+    print(f"{total} kernels with asm loads audited, {bad} with violations")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
