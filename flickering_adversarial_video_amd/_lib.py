@@ -78,6 +78,7 @@ _SIGS = {
                                           C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "flk_conv_weights_create_split": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "flk_conv_weights_create_s2d_stem": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "flk_conv_weights_destroy": (C.c_int, [C.c_void_p]),
     "flk_conv3d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "flk_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolArgs), C.c_int, C.c_void_p]),

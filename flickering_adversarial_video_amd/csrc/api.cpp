@@ -100,6 +100,46 @@ extern "C" int flk_conv_weights_create_split(const float* w, int kt, int kh, int
   return flk_conv_weights_create_impl(w, kt, kh, kw, cin, cout, row_scale, 0, dtype, nf, cin_split, out);
 }
 
+// Folded 7x7x7/2 stem (fold_t = 3 layout, include/flicker_hip.h): a 4x4x4 convolution over 32 channels = 4 chunks of 8,
+// chunk = (qt,qh).  Tap index 3 of an axis only exists for parity 0 (kernel index 2*3+1 = 7 is outside the 7-tap
+// window), so for taps with dt == 3 the chunks qt = 1 are zero, for dh == 3 the chunks qh = 1.  The K steps of mode 4
+// (conv_igemm.hip) are assembled from the non-zero chunks only, 49 steps instead of 64:
+//   class 0 (dt<3, dh<3): one tap, chunks 0..3              class 1 (dt=3): taps (dw, dw+1) x chunks {0,1}
+//   class 2 (dh=3): taps (dw, dw+1) x chunks {0,2}           class 3 (dt=3, dh=3): taps dw..dw+3 x chunk 0
+// in the order dt, dh, dw.  They are packed as a 49-"tap" convolution over 32 channels whose channel (q*8 + j) of
+// step s is (tap, chunk)(s, q) x element j.
+extern "C" int flk_conv_weights_create_s2d_stem(const float* w, int cout, int dtype, int nf, flk_conv_weights** out) {
+  FLK_REQUIRE(w && out && cout > 0, "flk_conv_weights_create_s2d_stem: bad argument");
+  if (dtype != FLK_BF16) return flk_conv_weights_create_impl(w, 4, 4, 4, 32, cout, nullptr, 0, dtype, nf, 0, out);
+  auto at = [&](int dt, int dh, int dw, int ch, int co) { return w[((((size_t)dt * 4 + dh) * 4 + dw) * 32 + ch) * cout + co]; };
+  for (int dt = 0; dt < 4; ++dt) for (int dh = 0; dh < 4; ++dh) for (int dw = 0; dw < 4; ++dw)
+    for (int ch = 0; ch < 32; ++ch) {
+      const int qt = ch >> 4, qh = (ch >> 3) & 1;
+      if (!((dt == 3 && qt == 1) || (dh == 3 && qh == 1))) continue;
+      for (int co = 0; co < cout; ++co)
+        FLK_REQUIRE(at(dt, dh, dw, ch, co) == 0.f, "flk_conv_weights_create_s2d_stem: weight (tap %d,%d,%d, channel %d) must be zero", dt, dh, dw, ch);
+    }
+  std::vector<float> v;
+  v.reserve((size_t)49 * 32 * cout);
+  for (int dt = 0; dt < 4; ++dt)
+    for (int dh = 0; dh < 4; ++dh) {
+      const int cls = (dt == 3) + 2 * (dh == 3), wstride = cls == 0 ? 1 : cls == 3 ? 4 : 2;
+      for (int dw = 0; dw < 4; dw += wstride)
+        for (int q = 0; q < 4; ++q) {
+          const int chunk = cls == 0 ? q : cls == 1 ? (q & 1) : cls == 2 ? (q & 1) * 2 : 0;
+          const int woff = cls == 0 ? 0 : cls == 3 ? q : (q >> 1);
+          for (int j = 0; j < 8; ++j)
+            for (int co = 0; co < cout; ++co) v.push_back(at(dt, dh, dw + woff, chunk * 8 + j, co));
+        }
+    }
+  FLK_REQUIRE(v.size() == (size_t)49 * 32 * cout, "flk_conv_weights_create_s2d_stem: internal step count");
+  int rc = flk_conv_weights_create_impl(v.data(), 49, 1, 1, 32, cout, nullptr, 0, dtype, nf, 0, out);
+  if (rc) return rc;
+  (*out)->stem4 = 1;
+  (*out)->kt = (*out)->kh = (*out)->kw = 4;      // the operator it implements; ntaps stays 49 (K steps per slab)
+  return FLK_OK;
+}
+
 extern "C" int flk_conv_weights_destroy(flk_conv_weights* w) {
   if (!w) return FLK_OK;
   if (w->dev) (void)hipFree(w->dev);

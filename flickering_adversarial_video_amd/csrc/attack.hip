@@ -6,7 +6,20 @@
 // 198-209, 868.  Closed forms: SURVEY Appendix C.
 #include "flk_internal.h"
 
-// FT = 2: fold (t,h,w) parities, 24 used of 32 channels; FT = 1: fold (h,w) only, 12 used of 16 channels
+// Space-to-depth layouts (template FT = flk_apply_args.fold_t, 0 -> 2):
+//   FT = 1: fold (h,w) only,   16 channels: (qh*2+qw)*3 + c, 12..15 zero          (VideoResNet stems)
+//   FT = 2: fold (t,h,w),      32 channels: (qt*4+qh*2+qw)*3 + c, 24..31 zero
+//   FT = 3: fold (t,h,w),      32 channels: (qt*2+qh)*8 + qw*3 + c, 6 and 7 of every 8 zero -- every 16-byte chunk holds
+//           ONE (qt,qh) parity, so the structurally zero (tap, parity) chunks of the folded 7x7x7 stem can be skipped
+//           (conv_igemm.hip mode 4)
+template <int FT> struct S2D {
+  static constexpr int F = FT == 1 ? 1 : 2;                 // frames folded into one position
+  static constexpr int NCH = 16 * F;
+  static constexpr int NUSED = FT == 3 ? 32 : 12 * F;       // leading channels that may be non-zero
+  __device__ static constexpr int ch(int qt, int qh, int k) {   // k = qw*3 + c
+    return FT == 3 ? (qt * 2 + qh) * 8 + k : (qt * 4 + qh * 2) * 3 + k;
+  }
+};
 template <typename TO, int NCH> __device__ static inline void store_ch(char* dst, const float* v) {
   if constexpr (sizeof(TO) == 4) {
 #pragma unroll
@@ -66,9 +79,9 @@ __device__ static inline float pert_at(const flk_apply_args& a, int t, int h, in
 }
 
 // ---- apply: one thread = one space-to-depth output position (FT x 2 x 2 input cells x 3 channels) ----
-template <typename TO, int FT>
+template <typename TO, int FTL>
 __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, char* out) {
-  constexpr int NCH = 16 * FT, NUSED = 12 * FT;
+  constexpr int FT = S2D<FTL>::F, NCH = S2D<FTL>::NCH;
   const int T2 = a.T / FT, H2 = a.H / 2, W2 = a.W / 2;
   const long total = (long)a.B * T2 * H2 * W2;
   for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
@@ -78,6 +91,8 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
     const int t2 = r % T2;
     const int b = r / T2;
     float v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] = 0.f;
 #pragma unroll
     for (int qt = 0; qt < FT; ++qt) {
       const int t = FT * t2 + qt;
@@ -92,12 +107,10 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float pv = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, t, h, 2 * w2 + qw, c) : 0.f;
-            v[(qt * 4 + qh * 2 + qw) * 3 + c] = clipf(x[qw * 3 + c] + pv, a.lo, a.hi);
+            v[S2D<FTL>::ch(qt, qh, qw * 3 + c)] = clipf(x[qw * 3 + c] + pv, a.lo, a.hi);
           }
       }
     }
-#pragma unroll
-    for (int i = NUSED; i < NCH; ++i) v[i] = 0.f;
     store_ch<TO, NCH>(out + (size_t)gid * NCH * sizeof(TO), v);
   }
 }
@@ -106,7 +119,7 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
 // consecutive output positions.  It reads its 24 source bytes of each of the 4 (frame, row) pairs as three aligned
 // 8-byte loads (the generic kernel above issues 2-byte loads), evaluates the 6 perturbation values (2 frames x RGB) once,
 // and decodes its position with 32-bit arithmetic from a 3-D grid.  Same arithmetic per element as the generic kernel.
-template <typename TO>
+template <typename TO, int FTL>
 __global__ __launch_bounds__(256) void apply_s2d_u8_flicker_kernel(const flk_apply_args a, char* out) {
   constexpr int NCH = 32;
   const int H2 = a.H / 2, W2 = a.W / 2, WG = W2 / 4;
@@ -135,6 +148,8 @@ __global__ __launch_bounds__(256) void apply_s2d_u8_flicker_kernel(const flk_app
   for (int j = 0; j < 4; ++j) {                   // output position 4*wg + j: source pixels 2j, 2j+1 of the 8-pixel run
     float v[NCH];
 #pragma unroll
+    for (int k = 0; k < NCH; ++k) v[k] = 0.f;
+#pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
       for (int qh = 0; qh < 2; ++qh) {
@@ -143,18 +158,16 @@ __global__ __launch_bounds__(256) void apply_s2d_u8_flicker_kernel(const flk_app
         for (int e = 0; e < 6; ++e) {              // byte 6j + e of the 24-byte run
           const int bi = 6 * j + e;
           const float x = (float)((w[bi >> 2] >> (8 * (bi & 3))) & 255u) * a.x_scale + a.x_bias;
-          v[(qt * 4 + qh * 2 + e / 3) * 3 + e % 3] = clipf(x + pv[qt][e % 3], a.lo, a.hi);
+          v[S2D<FTL>::ch(qt, qh, e)] = clipf(x + pv[qt][e % 3], a.lo, a.hi);
         }
       }
-#pragma unroll
-    for (int k = 24; k < NCH; ++k) v[k] = 0.f;
     store_ch<TO, NCH>(dst + (size_t)j * NCH * sizeof(TO), v);
   }
 }
 
 static int check_apply(const flk_apply_args* a) {
   FLK_REQUIRE(a && a->x && a->delta, "flk_perturb: null argument");
-  FLK_REQUIRE(a->fold_t == 0 || a->fold_t == 1 || a->fold_t == 2, "flk_perturb: fold_t must be 0, 1 or 2");
+  FLK_REQUIRE(a->fold_t >= 0 && a->fold_t <= 3, "flk_perturb: fold_t must be 0, 1, 2 or 3");
   FLK_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && (a->fold_t == 1 || a->T % 2 == 0) && a->H % 2 == 0 && a->W % 2 == 0,
               "flk_perturb: H,W (and T when folded) must be positive and even (got %d,%d,%d)", a->T, a->H, a->W);
   FLK_REQUIRE(a->lo <= a->hi, "flk_perturb: lo > hi");
@@ -165,23 +178,25 @@ extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dty
   int rc = check_apply(a);
   if (rc) return rc;
   FLK_REQUIRE(out, "flk_perturb_apply_s2d: null out");
-  const int ft = a->fold_t == 1 ? 1 : 2;
+  const int ftl = a->fold_t == 1 ? 1 : a->fold_t == 3 ? 3 : 2, ft = ftl == 1 ? 1 : 2;
   const long total = (long)a->B * (a->T / ft) * (a->H / 2) * (a->W / 2);
   const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
+  FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_perturb_apply_s2d: bad dtype");
+  const bool bf = dtype == FLK_BF16;
   if (ft == 2 && a->x_is_u8 && !a->delta_dense && a->W % 8 == 0 && a->T / 2 < 65536 && a->B < 65536 && !getenv("FLK_APPLY_GENERIC")) {
     const dim3 g3((unsigned)(((a->H / 2) * (a->W / 8) + 255) / 256), (unsigned)(a->T / 2), (unsigned)a->B);
-    if (dtype == FLK_BF16) hipLaunchKernelGGL(apply_s2d_u8_flicker_kernel<bf16_t>, g3, dim3(256), 0, st, *a, (char*)out);
-    else if (dtype == FLK_F32) hipLaunchKernelGGL(apply_s2d_u8_flicker_kernel<float>, g3, dim3(256), 0, st, *a, (char*)out);
-    else { flk_set_error("flk_perturb_apply_s2d: bad dtype"); return FLK_EINVAL; }
+    if (bf && ftl == 2) hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<bf16_t, 2>), g3, dim3(256), 0, st, *a, (char*)out);
+    else if (bf) hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<bf16_t, 3>), g3, dim3(256), 0, st, *a, (char*)out);
+    else if (ftl == 2) hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<float, 2>), g3, dim3(256), 0, st, *a, (char*)out);
+    else hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<float, 3>), g3, dim3(256), 0, st, *a, (char*)out);
     FLK_CHECK_HIP(hipGetLastError());
     return FLK_OK;
   }
-  if (dtype == FLK_BF16 && ft == 2) hipLaunchKernelGGL((apply_s2d_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
-  else if (dtype == FLK_BF16) hipLaunchKernelGGL((apply_s2d_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
-  else if (dtype == FLK_F32 && ft == 2) hipLaunchKernelGGL((apply_s2d_kernel<float, 2>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
-  else if (dtype == FLK_F32) hipLaunchKernelGGL((apply_s2d_kernel<float, 1>), dim3(grid), dim3(256), 0, st, *a, (char*)out);
-  else { flk_set_error("flk_perturb_apply_s2d: bad dtype"); return FLK_EINVAL; }
+#define FLK_APPLY(TT, L) hipLaunchKernelGGL((apply_s2d_kernel<TT, L>), dim3(grid), dim3(256), 0, st, *a, (char*)out)
+  if (bf) { if (ftl == 1) FLK_APPLY(bf16_t, 1); else if (ftl == 2) FLK_APPLY(bf16_t, 2); else FLK_APPLY(bf16_t, 3); }
+  else { if (ftl == 1) FLK_APPLY(float, 1); else if (ftl == 2) FLK_APPLY(float, 2); else FLK_APPLY(float, 3); }
+#undef FLK_APPLY
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -197,9 +212,9 @@ static inline int grad_nchunk(int B, int T, int H) {
   return n;
 }
 
-template <typename TI, int FT>
+template <typename TI, int FTL>
 __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a, const char* gx, int nchunk, float* partials) {
-  constexpr int NCH = 16 * FT, NUSED = 12 * FT;
+  constexpr int FT = S2D<FTL>::F, NCH = S2D<FTL>::NCH, NUSED = S2D<FTL>::NUSED;
   const int T2 = a.T / FT, H2 = a.H / 2, W2 = a.W / 2;
   int bid = blockIdx.x;
   const int chunk = bid % nchunk; bid /= nchunk;
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float u = x[qw * 3 + c] + a.adv_flag * pert_at(a, t, h, 2 * w2 + qw, c);
-            if (u >= a.lo && u <= a.hi) acc[qt * 3 + c] += g[(qt * 4 + qh * 2 + qw) * 3 + c];
+            if (u >= a.lo && u <= a.hi) acc[qt * 3 + c] += g[S2D<FTL>::ch(qt, qh, qw * 3 + c)];
           }
       }
     }
@@ -248,7 +263,7 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a
 __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const float* partials, float* gdelta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.T * 3) return;
-  const int FT = a.fold_t == 1 ? 1 : 2;
+  const int FT = a.fold_t == 1 ? 1 : 2;                 // frames per folded position (fold_t 0, 2, 3: two)
   const int t = i / 3, c = i % 3, t2 = t / FT, qt = t % FT, T2 = a.T / FT;
   float s = 0.f;
   for (int b = 0; b < a.B; ++b)
@@ -260,9 +275,9 @@ __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const flo
 }
 
 // dense delta ("L12" baseline, kinetics_i3d_utils.py:308-521): no spatial reduction, sum over the batch.
-template <typename TI, int FT>
+template <typename TI, int FTL>
 __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a, const char* gx, float* gdelta) {
-  constexpr int NCH = 16 * FT, NUSED = 12 * FT;
+  constexpr int FT = S2D<FTL>::F, NCH = S2D<FTL>::NCH, NUSED = S2D<FTL>::NUSED;
   const int T2 = a.T / FT, H2 = a.H / 2, W2 = a.W / 2;
   const long total = (long)T2 * H2 * W2;
   for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a,
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
             const float u = x[k] + a.adv_flag * pert_at(a, t, 2 * h2 + qh, 2 * w2 + k / 3, k % 3);
-            if (u >= a.lo && u <= a.hi) acc[(qt * 4 + qh * 2) * 3 + k] += g[(qt * 4 + qh * 2) * 3 + k];
+            if (u >= a.lo && u <= a.hi) acc[S2D<FTL>::ch(qt, qh, k)] += g[S2D<FTL>::ch(qt, qh, k)];
           }
         }
       }
@@ -301,7 +316,7 @@ __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a,
           const size_t di = (((size_t)ts * a.H + 2 * h2 + qh) * a.W + 2 * w2 + k / 3) * 3 + c;
           const float d = a.delta[di];
           const bool pass = !(a.dclip > 0.f) || (d >= -a.dclip && d <= a.dclip);
-          gdelta[di] = pass ? acc[(qt * 4 + qh * 2) * 3 + k] * a.adv_flag * a.inv_std[c] : 0.f;
+          gdelta[di] = pass ? acc[S2D<FTL>::ch(qt, qh, k)] * a.adv_flag * a.inv_std[c] : 0.f;
         }
   }
 }
@@ -319,23 +334,23 @@ extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s
   FLK_REQUIRE(gx_s2d && gdelta, "flk_perturb_grad_reduce: null argument");
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_perturb_grad_reduce: bad dtype");
   hipStream_t s = (hipStream_t)stream;
-  const int ft = a->fold_t == 1 ? 1 : 2;
+  const int ftl = a->fold_t == 1 ? 1 : a->fold_t == 3 ? 3 : 2, ft = ftl == 1 ? 1 : 2;
   const bool bf = dtype == FLK_BF16;
   if (a->delta_dense) {
     const long total = (long)(a->T / ft) * (a->H / 2) * (a->W / 2);
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (bf && ft == 2) hipLaunchKernelGGL((grad_dense_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
-    else if (bf) hipLaunchKernelGGL((grad_dense_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
-    else if (ft == 2) hipLaunchKernelGGL((grad_dense_kernel<float, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
-    else hipLaunchKernelGGL((grad_dense_kernel<float, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta);
+#define FLK_GD(TT, L) hipLaunchKernelGGL((grad_dense_kernel<TT, L>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta)
+    if (bf) { if (ftl == 1) FLK_GD(bf16_t, 1); else if (ftl == 2) FLK_GD(bf16_t, 2); else FLK_GD(bf16_t, 3); }
+    else { if (ftl == 1) FLK_GD(float, 1); else if (ftl == 2) FLK_GD(float, 2); else FLK_GD(float, 3); }
+#undef FLK_GD
   } else {
     FLK_REQUIRE(partials, "flk_perturb_grad_reduce: null scratch");
     const int nchunk = grad_nchunk(a->B, a->T, a->H);
     const unsigned grid = (unsigned)(a->B * (a->T / ft) * nchunk);
-    if (bf && ft == 2) hipLaunchKernelGGL((grad_reduce_stage1<bf16_t, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
-    else if (bf) hipLaunchKernelGGL((grad_reduce_stage1<bf16_t, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
-    else if (ft == 2) hipLaunchKernelGGL((grad_reduce_stage1<float, 2>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
-    else hipLaunchKernelGGL((grad_reduce_stage1<float, 1>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials);
+#define FLK_GR(TT, L) hipLaunchKernelGGL((grad_reduce_stage1<TT, L>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials)
+    if (bf) { if (ftl == 1) FLK_GR(bf16_t, 1); else if (ftl == 2) FLK_GR(bf16_t, 2); else FLK_GR(bf16_t, 3); }
+    else { if (ftl == 1) FLK_GR(float, 1); else if (ftl == 2) FLK_GR(float, 2); else FLK_GR(float, 3); }
+#undef FLK_GR
     hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128), dim3(128), 0, s, *a, nchunk, partials, gdelta);
   }
   FLK_CHECK_HIP(hipGetLastError());

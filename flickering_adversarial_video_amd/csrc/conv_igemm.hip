@@ -88,6 +88,7 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // MODE 0: weights through the LDS ring (wide wave tiles).  MODE 1: every wave streams its own fragments into registers
 // ("direct A").  MODE 2: direct A for a 1x1x1 convolution (activation slabs prefetched in depth as well).  MODE 3: LDS ring
 // for a 1x1x1 convolution with wide wave tiles, activations and weights prefetched in depth with hand-counted waits.
+// MODE 4: the folded 7x7x7 stem (4x4x4 taps over ONE 32-channel slab): K steps built from the non-zero 16-byte chunks only.
 template <typename T, int NF, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   constexpr bool K1 = MODE == 2 || MODE == 3;
@@ -272,6 +273,70 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       }
     }
 
+  } else if constexpr (MODE == 4) {
+    // ---- folded stem (flk_conv_weights_create_s2d_stem, api.cpp): chunk c of a position holds ONE (qt,qh) parity and
+    // tap index 3 of an axis exists for parity 0 only, so for dt == 3 / dh == 3 half (or three quarters) of the chunks
+    // of a tap are structurally zero.  A K step (32 K values = 4 chunks, one per lane group q) is assembled from
+    // non-zero chunks only: class 0 one tap x chunks q; class 1 (dt = 3) taps (dw, dw+1) x chunks {0,1}; class 2
+    // (dh = 3) taps (dw, dw+1) x chunks {0,2}; class 3 tap dw + q x chunk 0.  49 steps instead of 64; weights as in
+    // mode 0 (LDS ring, one-step register prefetch), the halo is staged once.
+    static_assert(WN == 1, "mode 4 shares the weights through LDS");
+    const int wchunk = NF >= 4 ? tid : (tid & 127);
+    const char* wsrc = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
+    uint4 wreg0 = *(const uint4*)wsrc, wreg1 = make_uint4(0, 0, 0, 0);
+    if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+    wsrc += wstep;
+    {
+      const char* src; int ld;
+      const bool chvalid = slab_src(0, src, ld);
+#pragma unroll
+      for (int n0 = 0; n0 < NPK; n0 += 4) {
+        if (n0 * 64 >= p.P) break;
+        uint4 v[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
+      }
+    }
+    // per-lane displacement of (chunk, tap) against the class-0 address rowpos[i] = position * 16 + plane_off(q)
+    const int base_q = plane_off(q, p.plane_b);
+    const int lo1 = plane_off(q & 1, p.plane_b) + (q >> 1) * 16 - base_q;
+    const int lo2 = plane_off((q & 1) * 2, p.plane_b) + (q >> 1) * 16 - base_q;
+    const int lo3 = plane_off(0, p.plane_b) + q * 16 - base_q;
+    int it_w = 0;
+    for (int dt = 0; dt < 4; ++dt)
+      for (int dh = 0; dh < 4; ++dh) {
+        const int cls = (dt == 3) + 2 * (dh == 3);
+        const int lo = cls == 0 ? 0 : cls == 1 ? lo1 : cls == 2 ? lo2 : lo3;
+        const int wstride = cls == 0 ? 1 : cls == 3 ? 4 : 2;
+        int tapoff = (dt * p.Hh + dh) * p.Wh * 16 + lo;
+        for (int dw = 0; dw < 4; dw += wstride, tapoff += wstride * 16) {
+          char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
+          *(uint4*)(wcur + wchunk * 16) = wreg0;
+          if (WCH == 2) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
+          ++it_w;
+          if (it_w < nsteps) {
+            wreg0 = *(const uint4*)wsrc;
+            if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+            wsrc += wstep;
+          }
+          __syncthreads();
+          if (wave_active) {
+            frag bf[4], af[NFW];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + rowpos[i] + tapoff);
+#pragma unroll
+            for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < NFW; ++f)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
+          }
+        }
+      }
   } else if constexpr (MODE == 3) {
     // ---- 1x1x1 convolution, wide wave tiles: a GEMM whose K loop is only cin/32 steps long, each step a new slab from
     // HBM.  Activation slabs run D steps ahead and weight chunks 2 steps ahead in register queues, issued from inline
@@ -596,6 +661,8 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   FLK_REQUIRE((a->To - 1) * a->ost + a->oot < a->OT && (a->Ho - 1) * a->osh + a->ooh < a->OH &&
                   (a->Wo - 1) * a->osw + a->oow < a->OW && a->oot >= 0 && a->ooh >= 0 && a->oow >= 0,
               "flk_conv3d: logical output grid exceeds the physical output");
+  FLK_REQUIRE(!w->stem4 || (a->st == 1 && a->sh == 1 && a->sw == 1 && !a->in2 && w->nslab == 1),
+              "flk_conv3d: folded-stem weights need a stride-1, single-segment 4x4x4x32 convolution");
   const size_t esz = flk_esize(dtype);
   FLK_REQUIRE((size_t)a->B * a->Ti * a->Hi * a->Wi * a->in_ld < (1ull << 31) &&
                   (size_t)a->B * a->OT * a->OH * a->OW * a->out_ld < (1ull << 31),
@@ -628,7 +695,7 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
     const char* force = getenv("FLK_CONV_WN");
     while (true) {
       const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * ntile_n;
-      const bool more = force ? wn < atoi(force) : wgs < 256;   // fewer workgroups than CUs
+      const bool more = w->stem4 ? false : force ? wn < atoi(force) : wgs < 256;   // fewer workgroups than CUs (mode 4 is written for wn = 1)
       if (!more || wn * 2 > 4 || wn * 2 > wn_max) break;
       wn *= 2;
       t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS / wn, max_halo);
@@ -676,11 +743,12 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
     static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
     const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);
     const bool k1 = kp.ntaps == 1 && kp.P <= 256;
-    if (wn >= 2 || narrow_small) mode = k1 ? 2 : 1;
+    if (w->stem4) mode = 4;
+    else if (wn >= 2 || narrow_small) mode = k1 ? 2 : 1;
     else if (k1 && kp.nslab >= 4 && !getenv("FLK_CONV_NO_K1")) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
   }
   // two halo images for small halos; the LDS weight ring only in mode 0
-  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3) ? 2 * (size_t)nf * 1024 : 0);
+  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4) ? 2 * (size_t)nf * 1024 : 0);
   {
     static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
     if (dbg)
@@ -695,6 +763,9 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   if (nf == NFv && wn == WNv && mode == 1) return launch<TT, NFv, WNv, 1>(kp, grid, lds, s); \
   if (nf == NFv && wn == WNv && mode == 2) return launch<TT, NFv, WNv, 2>(kp, grid, lds, s)
   if (dtype == FLK_BF16) {
+    if (mode == 4 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 4>(kp, grid, lds, s);
+    if (mode == 4 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 4>(kp, grid, lds, s);
+    if (mode == 4 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 4>(kp, grid, lds, s);
     FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1);
     FLK_LAUNCHD(bf16_t, 2, 1); FLK_LAUNCHD(bf16_t, 4, 1); FLK_LAUNCHD(bf16_t, 4, 2);
     FLK_LAUNCHD(bf16_t, 8, 2); FLK_LAUNCHD(bf16_t, 8, 4);

@@ -46,6 +46,7 @@ struct flk_conv_weights {
   int kt = 0, kh = 0, kw = 0, cin = 0, cout = 0;   // of THIS operator (after optional transpose)
   int dtype = 0, nf = 0, nslab = 0, ntaps = 0, cout_frags = 0;
   int cin_split = 0, nslab1 = 0;   // two-segment K order: slabs [0,nslab1) = channels [0,cin_split)
+  int stem4 = 0;                   // folded-stem K-step packing (49 steps of non-zero chunks; conv_igemm.hip mode 4)
   size_t bytes = 0;
 };
 

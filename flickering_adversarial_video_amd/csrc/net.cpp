@@ -265,7 +265,7 @@ int flk_net::build_i3d() {
   int rc;
   std::vector<std::function<void()>> bwd_emit;   // backward emitters, run in reverse at the end
 
-  // ---- stem: Conv3d_1a_7x7 (7x7x7 / 2, 3->64) as a 4x4x4 / 1 convolution over the space-to-depth clip ----
+  // ---- stem: Conv3d_1a_7x7 (7x7x7 / 2, 3->64) as a 4x4x4 / 1 convolution over the space-to-depth clip (fold_t = 3) ----
   ConvLayer* stem7 = nullptr;
   if ((rc = make_unit3d("Conv3d_1a_7x7", 7, 7, 7, 3, 64, &stem7))) return rc;
   ConvLayer* stem = nullptr;
@@ -276,7 +276,7 @@ int flk_net::build_i3d() {
     for (int kt = 0; kt < 7; ++kt) for (int kh = 0; kh < 7; ++kh) for (int kw = 0; kw < 7; ++kw)
       for (int c = 0; c < 3; ++c) {
         const int jt = kt >> 1, qt = kt & 1, jh = kh >> 1, qh = kh & 1, jw = kw >> 1, qw = kw & 1;
-        const int ch = (qt * 4 + qh * 2 + qw) * 3 + c;
+        const int ch = (qt * 2 + qh) * 8 + qw * 3 + c;      // fold_t = 3 layout: one (qt,qh) parity per 16-byte chunk
         const float* src = &stem7->w[((((size_t)kt * 7 + kh) * 7 + kw) * 3 + c) * 64];
         float* dst = &L->w[((((size_t)jt * 4 + jh) * 4 + jw) * 32 + ch) * 64];
         for (int co = 0; co < 64; ++co) dst[co] = src[co];
@@ -285,7 +285,13 @@ int flk_net::build_i3d() {
     stem = L.get();
     convs.push_back(std::move(L));
   }
-  if ((rc = pack(stem))) return rc;
+  {
+    // forward: K steps assembled from the non-zero chunks of the folded taps (49 instead of 64; bf16); data-gradient: the
+    // generic transposed operator over the same folded tensor
+    if ((rc = flk_conv_weights_create_s2d_stem(stem->w.data(), 64, dtype, choose_nf(64, 64), &stem->wf))) return rc;
+    if ((rc = flk_conv_weights_create_impl(stem->w.data(), 4, 4, 4, 32, 64, stem->scale.data(), 1, dtype, choose_nf(32, 64), 0, &stem->wb))) return rc;
+    if ((rc = upload(&stem->d_scale, stem->scale)) || (rc = upload(&stem->d_bias, stem->bias))) return rc;
+  }
   const int T1 = T / 2, H1 = H / 2, W1 = W / 2;
   Act xin; xin.T = T1; xin.H = H1; xin.W = W1; xin.ld = 32;       // bound per call
   Act a1, G1;

@@ -135,7 +135,7 @@ class FlickerI3D:
         sx = int(self._rng.integers(0, self.T)) if cyclic else 0          # one shift per step for the whole batch
         sp = int(self._rng.integers(0, self.T)) if cyclic_pert else 0     # (kinetics_i3d_utils.py:115,130)
         return ops.make_apply_args(x, self.eps_rgb, dialect="tf", dclip=0.0 if self.dense else 0.4, adv_flag=adv_flag,
-                                   shift_x=sx, shift_p=sp)
+                                   shift_x=sx, shift_p=sp, fold_t=ops.I3D_FOLD)
 
     def _check_x(self, x):
         if tuple(x.shape) != (self.B, self.T, self.H, self.W, 3) or x.dtype not in (torch.uint8, torch.float32) or not x.is_cuda:
@@ -254,6 +254,6 @@ class FlickerI3DInference(FlickerI3D):
         self.last_shift_x = int(self._rng.integers(0, self.T)) if cyclic_input_flag else 0
         self.last_shift_p = int(self._rng.integers(0, self.T)) if cyclic_eps_flag else 0
         a = ops.make_apply_args(x, self.eps_rgb, dialect="tf", dclip=0.0, adv_flag=float(adv_flag), shift_x=self.last_shift_x,
-                                shift_p=self.last_shift_p)
+                                shift_p=self.last_shift_p, fold_t=ops.I3D_FOLD)
         ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
         return torch.softmax(self.net.forward(self._xs2d, self._logits), -1)

@@ -39,6 +39,20 @@ class ConvWeights:
         self.cin_split = cin_split
         self.handle = h
 
+    @classmethod
+    def s2d_stem(cls, w_folded, dtype, nf):
+        """folded 7x7x7/2 stem: [4,4,4,32,cout] in the fold_t = 3 channel order (flk_conv_weights_create_s2d_stem)"""
+        w = np.ascontiguousarray(w_folded, dtype=np.float32)
+        assert w.shape[:4] == (4, 4, 4, 32)
+        self = cls.__new__(cls)
+        self.kt = self.kh = self.kw = 4
+        self.cin, self.cout = 32, w.shape[4]
+        self.dtype, self.nf, self.cin_split = dtype_code(dtype), nf, 0
+        h = C.c_void_p()
+        check(load().flk_conv_weights_create_s2d_stem(ptr(w), self.cout, self.dtype, nf, C.byref(h)))
+        self.handle = h
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
@@ -122,6 +136,9 @@ def maxpool3d_bwd(ctx, gout, mask=None):
     check(load().flk_maxpool3d_bwd(C.byref(a), ptr(gout), gout.shape[4], 0, ptr(gin), C_, 0, ptr(mask),
                                    0 if mask is None else mask.shape[4], 0, dtype_code(x.dtype), stream_ptr()))
     return gin
+
+
+I3D_FOLD = 3   # space-to-depth layout the I3D plan (flk_net, FLK_NET_I3D) expects: chunk-aligned (t,h,w) fold
 
 
 def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=0, shift_p=0, inv_std=(1.0, 1.0, 1.0),

@@ -57,6 +57,12 @@ int flk_conv_weights_create(const float* w_dhwio, int kt, int kh, int kw, int ci
 int flk_conv_weights_create_split(const float* w_dhwio, int kt, int kh, int kw, int cin, int cout,
                                   const float* row_scale, int cin_split, int dtype, int nf,
                                   flk_conv_weights** out);
+/* Weights of the folded 7x7x7 / stride-2 I3D stem (Conv3d_1a_7x7, i3d.py:168-170) as a 4x4x4 convolution over the
+ * fold_t = 3 space-to-depth clip (flk_perturb_apply_s2d): w_folded is [4,4,4,32,cout] with channel
+ * (qt*2+qh)*8 + qw*3 + c.  Tap index 3 of an axis exists for parity 0 only, so whole 8-channel chunks are structurally
+ * zero (checked); in bf16 the K loop is assembled from the non-zero chunks only (49 steps instead of 64).  Use with
+ * flk_conv3d(kt = kh = kw = 4, cin = 32, stride 1). */
+int flk_conv_weights_create_s2d_stem(const float* w_folded, int cout, int dtype, int nf, flk_conv_weights** out);
 int flk_conv_weights_destroy(flk_conv_weights* w);
 
 /* Generic 3-D convolution as implicit GEMM on MFMA, LDS-staged T x H x W halo tiles.
@@ -131,7 +137,10 @@ typedef struct {
   float adv_flag;            /* 0 -> clean input */
   int shift_x, shift_p;      /* cyclic temporal rolls (kinetics_i3d_utils.py:115-137), 0 = off */
   int B, T, H, W;
-  int fold_t;                /* 0/2: fold (t,h,w) parities -> [B,T/2,H/2,W/2,32] (I3D stem, stride 2x2x2);
+  int fold_t;                /* 0/2: fold (t,h,w) parities -> [B,T/2,H/2,W/2,32], channel (qt*4+qh*2+qw)*3+c, 24..31 zero
+                                (I3D stem, stride 2x2x2);
+                                3: the same fold with chunk-aligned channels (qt*2+qh)*8 + qw*3+c, 6 and 7 of every 8
+                                zero (one (qt,qh) parity per 16-byte chunk: flk_conv_weights_create_s2d_stem);
                                 1: fold (h,w) only -> [B,T,H/2,W/2,16], channel (qh*2+qw)*3+c, 12..15 zero
                                 (VideoResNet stems, stride 1x2x2) */
 } flk_apply_args;

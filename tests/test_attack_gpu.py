@@ -25,6 +25,13 @@ def s2d(x):
     return torch.cat([y, torch.zeros(*y.shape[:4], 8)], -1)
 
 
+def s2d_aligned(x):
+    """fold_t = 3: channel (qt*2+qh)*8 + qw*3 + c, 6 and 7 of every 8 zero (one (qt,qh) parity per 16-byte chunk)"""
+    B, T, H, W, _ = x.shape
+    y = x.reshape(B, T // 2, 2, H // 2, 2, W // 2, 2, 3).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B, T // 2, H // 2, W // 2, 4, 6)
+    return torch.cat([y, torch.zeros(*y.shape[:5], 2)], -1).reshape(B, T // 2, H // 2, W // 2, 32)
+
+
 def un_s2d(g):
     B, T2, H2, W2, _ = g.shape
     return g[..., :24].reshape(B, T2, H2, W2, 2, 2, 2, 3).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, T2 * 2, H2 * 2, W2 * 2, 3)
@@ -35,7 +42,7 @@ def un_s2d(g):
 @pytest.mark.parametrize("shifts", [(0, 0), (3, 5)], ids=["plain", "cyclic"])
 def test_apply_and_grad_tf(ops, u8, dense, shifts):
     """kinetics_i3d_utils.py:100-142: clip(x' + a*p', -1, 1) and its gradient w.r.t. delta (both clips inclusive)"""
-    B, T, H, W = 2, 8, 12, 10
+    B, T, H, W = 2, 8, 12, 16       # W % 8 == 0: the uint8 flicker case takes the 8-byte-load fast path
     rng = np.random.default_rng(5)
     xu = torch.from_numpy(rng.integers(0, 256, (B, T, H, W, 3), dtype=np.uint8))
     x = xu.float() / 128 - 1 if u8 else torch.from_numpy(rng.uniform(-1, 1, (B, T, H, W, 3)).astype(np.float32))
@@ -56,6 +63,14 @@ def test_apply_and_grad_tf(ops, u8, dense, shifts):
     # adv_flag = 0 -> clean clip
     args0 = ops.make_apply_args((xu if u8 else x).cuda(), dd.contiguous().cuda(), adv_flag=0.0)
     torch.testing.assert_close(ops.perturb_apply_s2d(args0, torch.float32).cpu(), s2d(x.clamp(-1, 1)), rtol=0, atol=1e-7)
+    # fold_t = 3 (chunk-aligned channels, the I3D plan's layout): same values, other channel order -- apply and gradient
+    args3 = ops.make_apply_args((xu if u8 else x).cuda(), dd.contiguous().cuda(), dclip=0.0 if dense else 0.4, shift_x=sx, shift_p=sp, fold_t=3)
+    torch.testing.assert_close(ops.perturb_apply_s2d(args3, torch.float32).cpu(), s2d_aligned(xa.detach()), rtol=0, atol=1e-7)
+    torch.testing.assert_close(ops.perturb_apply_s2d(args3, torch.bfloat16).float().cpu(), s2d_aligned(xa.detach()).bfloat16().float(), rtol=0, atol=0)
+    g3 = ops.perturb_grad_reduce(args3, s2d_aligned(gw).cuda())
+    torch.testing.assert_close(g3.cpu().reshape(gref.shape), gref, rtol=1e-4, atol=1e-4)
+    g3b = ops.perturb_grad_reduce(args3, s2d_aligned(gw).bfloat16().cuda())
+    torch.testing.assert_close(g3b.cpu().reshape(gref.shape), g.cpu().reshape(gref.shape), rtol=2e-2, atol=2e-2 * float(gref.abs().max()))
 
 
 def test_apply_and_grad_torch_dialect_golden(ops, golden):

@@ -91,7 +91,7 @@ def test_forward_backward_vs_oracle(setup, dtype):
     r32, r64 = ref[torch.float32], ref[torch.float64]
     f32 = dtype == "f32"
     net = ops.Net(FLK_NET_I3D, dtype, 1, T, 224, 224, W)
-    args = ops.make_apply_args(xu.cuda(), delta.reshape(T, 3).contiguous().cuda())
+    args = ops.make_apply_args(xu.cuda(), delta.reshape(T, 3).contiguous().cuda(), fold_t=ops.I3D_FOLD)
     logits = net.forward(ops.perturb_apply_s2d(args, dtype))
     # ---- forward: every endpoint, logits, loss against the fp32 oracle (smooth quantities) ----
     for name in r32["ep"]:

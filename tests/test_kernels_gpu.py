@@ -85,6 +85,46 @@ def test_conv_forward(ops, case, dtype):
     torch.testing.assert_close(out.float().cpu(), ref, rtol=r, atol=a)
 
 
+def fold_stem(w7):
+    """[7,7,7,3,cout] -> [4,4,4,32,cout]: tap 2*j + q of an axis goes to folded tap j, parity q; channel (qt*2+qh)*8 + qw*3 + c"""
+    cout = w7.shape[4]
+    wf = torch.zeros(4, 4, 4, 32, cout)
+    for kt in range(7):
+        for kh in range(7):
+            for kw in range(7):
+                ch = ((kt & 1) * 2 + (kh & 1)) * 8 + (kw & 1) * 3
+                wf[kt >> 1, kh >> 1, kw >> 1, ch:ch + 3] = w7[kt, kh, kw]
+    return wf
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("nf", [4, 8])
+def test_conv_folded_stem(ops, dtype, nf):
+    """Conv3d_1a_7x7 (7x7x7 / 2, SAME) as the 4x4x4 convolution over the fold_t = 3 clip with K steps assembled from the
+    non-zero chunks (mode 4, bf16) -- against the strided 7x7x7 oracle convolution on the unfolded clip."""
+    B, T, H, W, cout = 1, 8, 32, 48, 64
+    x = q(rnd((B, T, H, W, 3), 3), dtype)
+    w7 = q(rnd((7, 7, 7, 3, cout), 4, (2.0 / 1029) ** 0.5), dtype)
+    og, pad = zip(*(ops.same_pad(n, 7, 2) for n in (T, H, W)))
+    ref = ref_conv(x, w7, (2, 2, 2), pad, og)
+    xs = x.reshape(B, T // 2, 2, H // 2, 2, W // 2, 2, 3).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B, T // 2, H // 2, W // 2, 4, 6)
+    xs = torch.cat([xs, torch.zeros(*xs.shape[:5], 2)], -1).reshape(B, T // 2, H // 2, W // 2, 32)
+    pw = ops.ConvWeights.s2d_stem(fold_stem(w7).numpy(), dtype, nf)
+    out = ops.conv3d(xs.to(dtype).cuda(), pw, pad=(1, 1, 1), out_grid=og)
+    r, a = tol(dtype, ref)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=r, atol=a)
+    # the generic dense packing of the same folded tensor gives the same result
+    pg = ops.ConvWeights(fold_stem(w7).numpy(), dtype, nf)
+    out_g = ops.conv3d(xs.to(dtype).cuda(), pg, pad=(1, 1, 1), out_grid=og)
+    torch.testing.assert_close(out.float().cpu(), out_g.float().cpu(), rtol=r, atol=a)
+    # a folded tensor with a non-zero weight in a structurally zero chunk is refused (bf16 packs K steps from the others)
+    bad = fold_stem(w7).clone()
+    bad[3, 0, 0, 16] = 1.0
+    if dtype == torch.bfloat16:
+        with pytest.raises(RuntimeError, match="must be zero"):
+            ops.ConvWeights.s2d_stem(bad.numpy(), dtype, nf)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_epilogue_slices(ops, dtype):
     """channel slices of wider buffers (concat elimination) + scale/bias/add/relu/mask epilogue"""
