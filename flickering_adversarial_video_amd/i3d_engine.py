@@ -29,15 +29,19 @@ class StepResult(dict):
     the stored ones (``is_adversarial``, ``argmax``, ``total_loss``, the ``*_relative`` percentages) are computed on
     first access -- an iteration that nobody inspects launches no bookkeeping kernels."""
 
-    _DERIVED = ("argmax", "is_adversarial", "total_loss", "thickness_relative", "roughness_relative")
+    _DERIVED = ("argmax", "is_adversarial", "total_loss", "loss", "thickness_relative", "roughness_relative", "thickness", "roughness")
 
     def __missing__(self, key):
         if key == "argmax":
             v = self["_argmax_f"].to(torch.int64)
         elif key == "is_adversarial":
             v = (self["argmax"] == self["_labels"]).all() if self["_targeted"] else (self["argmax"] != self["_labels"]).all()
-        elif key == "total_loss" and "reg_loss" in self:
+        elif key in ("total_loss", "loss") and "reg_loss" in self:      # "loss": the torch engine's name (model.py:1079)
             v = self["adv_loss"] + self["_reg_weight"] * self["reg_loss"]
+        elif key == "thickness" and "_thickness" in self:                # torch engine: percentages (model.py:326-329)
+            v = self["_thickness"] * 100
+        elif key == "roughness" and "_roughness" in self:
+            v = self["_roughness"] * 100
         elif key == "thickness_relative" and "thickness" in self:
             v = self["thickness"] / 2 * 100
         elif key == "roughness_relative" and "roughness" in self:

@@ -78,10 +78,10 @@ class Losses:
         self.margin, self.improve_loss, self.logits, self.attack_type = margin, improve_loss, logits, attack_type
         self.label_prob = None
 
-    def adv(self, labels, model_logits, global_batch):
+    def adv(self, labels, model_logits, global_batch, out=None):
         lab = labels if not self.targeted else torch.full_like(labels, self.target_class)
         sm, dl, pc = ops.softmax_adv_loss(model_logits, lab, dialect="torch", improve_loss=self.improve_loss, use_logits=self.logits,
-                                          targeted=self.targeted, margin=self.margin, mean_scale=1.0 / global_batch)
+                                          targeted=self.targeted, margin=self.margin, mean_scale=1.0 / global_batch, out=out)
         self.label_prob = pc[:, 1]
         return sm, dl, pc
 
@@ -151,29 +151,42 @@ class FlickerVideoResNet:
         return self.net.forward(self._xs, self._logits)
 
     def step(self, x, labels, criterion, lr=1e-3, update=True):
-        """one iteration of fit_single_video_attack (model.py:1073-1101): forward, Losses, backward, torch-Adam step."""
+        """one iteration of fit_single_video_attack (model.py:1073-1101): forward, Losses, backward, torch-Adam step.
+        The kernels write into one of ``RESULT_SLOTS`` result slots (valid for the next RESULT_SLOTS - 1 iterations);
+        ``loss`` / ``argmax`` are derived on first access (i3d_engine.StepResult)."""
+        from .i3d_engine import RESULT_SLOTS, StepResult
         a = self.pert_model.apply_args(self._check_x(x), True)
+        if not hasattr(self, "_slots"):
+            dev = self._logits.device
+            self._slots = [dict(payload=torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev),
+                                sm=torch.empty_like(self._logits), pc=torch.empty((self.B, 4), dtype=torch.float32, device=dev),
+                                scalars=torch.zeros(8, dtype=torch.float32, device=dev)) for _ in range(RESULT_SLOTS)]
+            self._dl = torch.empty_like(self._logits)
+            self._it = 0
+        slot = self._slots[self._it % RESULT_SLOTS]
+        self._it += 1
+        red, sm, pc = slot["payload"], slot["sm"], slot["pc"]
+        self._red = red
         ops.perturb_apply_s2d(a, self.dtype, self._xs)
         self.net.forward(self._xs, self._logits)
         gbatch = self.B * self.world
-        sm, dl, pc = criterion.adv(labels, self._logits, gbatch)
-        self.net.backward(dl, self._gx)
+        criterion.adv(labels, self._logits, gbatch, out=(sm, self._dl, pc))
+        self.net.backward(self._dl, self._gx)
         n = 3 * self.T
-        ops.perturb_grad_reduce(a, self._gx, self._red[:n].view(self.T, 3), self._scratch)
-        parallel.pack_scalars(self._red, self.T, pc)
-        parallel.allreduce_sum_(self._red, self.pg)
-        res = dict(adv_loss=self._red[n].clone(), softmax=sm, label_prob=pc[:, 1], argmax=pc[:, 3].to(torch.int64))
+        ops.perturb_grad_reduce(a, self._gx, red[:n].view(self.T, 3), self._scratch)
+        ops.pack_batch_sums(pc, 1.0 / gbatch, red[n:])
+        parallel.allreduce_sum_(red, self.pg)
+        res = StepResult(adv_loss=red[n], softmax=sm, label_prob=pc[:, 1], _argmax_f=pc[:, 3], _labels=labels, _targeted=bool(criterion.targeted))
         if update:
             self.adam_t += 1
             b1 = criterion.beta_1
-            ops.perturb_reg_adam(self._red[:n], self.pert_model.perturbation, self.adam_m, self.adam_v, self.adam_t, dialect="torch",
+            sc = slot["scalars"]
+            ops.perturb_reg_adam(red[:n], self.pert_model.perturbation, self.adam_m, self.adam_v, self.adam_t, dialect="torch",
                                  beta0=criterion.lambda_, beta1=b1, beta2=1 - b1, beta3=1 - b1,
-                                 dyn_max_norm=self.pert_model.dynamic_max_norm, lr=lr, scalars=self._scalars)
-            sc = self._scalars.clone()
-            res.update(reg_loss=sc[0], loss=res["adv_loss"] + criterion.lambda_ * sc[0], thickness=sc[4] * 100, roughness=sc[5] * 100)
+                                 dyn_max_norm=self.pert_model.dynamic_max_norm, lr=lr, scalars=sc)
+            res.update(reg_loss=sc[0], _reg_weight=criterion.lambda_, _thickness=sc[4], _roughness=sc[5])
         else:
-            reg = criterion.flickering_regularization_loss(self.pert_model.get_perturbation()[0])
-            res.update(reg_loss=reg, loss=res["adv_loss"] + criterion.lambda_ * reg)
+            res.update(reg_loss=criterion.flickering_regularization_loss(self.pert_model.get_perturbation()[0]), _reg_weight=criterion.lambda_)
         return res
 
     # ---- drivers around step(): VideoLearnerAdversarial's loops without the plotting ------------------------------------
@@ -235,7 +248,7 @@ class FlickerVideoResNet:
                 else:                                           # targeted: a percentage (model.py:300-302)
                     miss += float(m) / 100.0 * target.numel(); valid += target.numel()
                 bs = inputs.shape[0]
-                loss_sum += float(r["loss"] if "loss" in r else r["adv_loss"]) * bs
+                loss_sum += float(r["loss"]) * bs
                 n += bs
             p = self.pert_model.get_perturbation()[0].cpu().numpy()
             result[f"{phase}/time"] = time.time() - t0
