@@ -12,8 +12,16 @@
 //   * LDS halo image = 4 planes [16-byte channel chunk][halo position]: the 16 positions x 4 chunks
 //     one ds_read_b128 wave-instruction touches are bank-conflict-free for consecutive positions
 //     (planes 0/1 and 2/3 aligned mod 256 B, the pairs 32 B apart so the staging writes are 2-way);
-//   * weights arrive pre-packed in MFMA A-fragment order (flk_internal.h), staged per (slab, tap)
-//     through a double-buffered LDS tile with a register prefetch one step ahead;
+//   * weights arrive pre-packed in MFMA A-fragment order (flk_internal.h); how they reach the MFMAs depends on the
+//     launch (template MODE, chosen in flk_conv3d):
+//       0  wide wave tiles: per (slab, tap) through a double-buffered LDS tile shared by the 4 waves, register prefetch
+//          one step ahead, one barrier per step;
+//       1  narrow wave tiles / small grids ("direct A"): every wave streams its own fragments into a register queue
+//          4-8 steps deep (inline-asm loads, hand-counted vmcnt), no per-step barrier;
+//       2  mode 1 for 1x1x1 convolutions, activation slabs prefetched in depth as well;
+//       3  1x1x1 convolutions with wide wave tiles: LDS ring as in 0, activations and weights in register queues with
+//          ONE counted vmcnt per step;
+//       4  the folded 7x7x7 stem: K steps assembled from the structurally non-zero 16-byte chunks only;
 //   * MFMA orientation: A = weights (rows = output channels), B = activations (cols = positions),
 //     so an accumulator lane owns ONE position and 4*NF consecutive channels -> 16-byte epilogue
 //     accesses for scale/bias/add/mask and stores.
