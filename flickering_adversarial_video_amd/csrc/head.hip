@@ -30,8 +30,15 @@ __global__ __launch_bounds__(256) void head_pool_kernel(const char* y, int ld, i
   float acc = 0.f;
   if (c < C) {
     const int npos = Tn * HW;
-    for (int i = grp; i < npos; i += 4)
-      acc += wt[i / HW] * ldf<T>(y, ((size_t)b * npos + i) * ld + coff + c);
+    int i = grp;
+    for (; i + 28 < npos; i += 32) {          // 8 independent loads in flight (the loop is latency-bound)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ldf<T>(y, ((size_t)b * npos + i + 4 * u) * ld + coff + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += wt[(i + 4 * u) / HW] * v[u];
+    }
+    for (; i < npos; i += 4) acc += wt[i / HW] * ldf<T>(y, ((size_t)b * npos + i) * ld + coff + c);
   }
   part[grp][cl] = acc;
   __syncthreads();
