@@ -101,6 +101,8 @@ _SIGS = {
     "flk_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "flk_net_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_conv_set_autotune": (C.c_int, [C.c_int]),
     "flk_net_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "flk_net_input_numel": (C.c_int64, [C.c_void_p]),
     "flk_net_num_classes": (C.c_int, [C.c_void_p]),

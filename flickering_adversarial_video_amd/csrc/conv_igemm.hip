@@ -652,7 +652,8 @@ static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
   return FLK_OK;
 }
 
-extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream) {
+// force_wn: 0 = heuristic, else 1 / 2 / 4.  force_da: -1 = heuristic, 0 = LDS weight ring, 1 = direct A.
+static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream, int force_wn, int force_da) {
   FLK_REQUIRE(a && w && w->dev, "flk_conv3d: null argument");
   FLK_REQUIRE(dtype == w->dtype, "flk_conv3d: dtype %d != packed weight dtype %d", dtype, w->dtype);
   FLK_REQUIRE(a->kt == w->kt && a->kh == w->kh && a->kw == w->kw && a->cin == w->cin && a->cout == w->cout,
@@ -700,10 +701,11 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS, max_halo);
   {
     const int wn_max = dtype == FLK_BF16 ? nf / 2 : nf;      // NFW >= 2 (bf16) / 1 (fp32)
-    const char* force = getenv("FLK_CONV_WN");
+    static const char* force_env = getenv("FLK_CONV_WN");
+    const int force = force_wn > 0 ? force_wn : force_env ? atoi(force_env) : 0;
     while (true) {
       const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * ntile_n;
-      const bool more = w->stem4 ? false : force ? wn < atoi(force) : wgs < 256;   // fewer workgroups than CUs (mode 4 is written for wn = 1)
+      const bool more = w->stem4 ? false : force ? wn < force : wgs < 256;   // fewer workgroups than CUs (mode 4 is written for wn = 1)
       if (!more || wn * 2 > 4 || wn * 2 > wn_max) break;
       wn *= 2;
       t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS / wn, max_halo);
@@ -751,8 +753,14 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
     static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
     const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);
     const bool k1 = kp.ntaps == 1 && kp.P <= 256;
+    // direct A needs <= 4 fragments per wave (and >= 2 in bf16); the ring kernels are instantiated for wn == 1 only
+    const int nfw = nf / wn;
+    const bool da_ok = nfw <= 4 && (dtype != FLK_BF16 || nfw >= 2), ring_ok = wn == 1;
+    bool da = wn >= 2 || narrow_small;
+    if (force_da == 0 && ring_ok) da = false;
+    if (force_da == 1 && da_ok) da = true;
     if (w->stem4) mode = 4;
-    else if (wn >= 2 || narrow_small) mode = k1 ? 2 : 1;
+    else if (da) mode = k1 ? 2 : 1;
     else if (k1 && kp.nslab >= 4 && !getenv("FLK_CONV_NO_K1")) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
   }
   // two halo images for small halos; the LDS weight ring only in mode 0
@@ -786,4 +794,52 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
 #undef FLK_LAUNCHD
   flk_set_error("flk_conv3d: unsupported dtype %d / nf %d / wn %d", dtype, nf, wn);
   return FLK_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Autotuning.  The layout heuristics above (rows per workgroup, weight path) are good for the big layers and mediocre for
+// the many mid-sized ones, whose best layout depends on how their grid lands on 256 CUs.  In tuning mode every
+// flk_conv3d call times its candidate layouts on its own operands (3 runs each after a warm-up, HIP events on the
+// caller's stream), remembers the winner in the weights object under the call's geometry and runs it; later calls with
+// the same geometry reuse it.  The arithmetic does not depend on the layout (same K order per output), so tuning
+// changes speed only.
+static thread_local int g_tuning = 0;
+extern "C" int flk_conv_set_autotune(int on) { g_tuning = on != 0; return FLK_OK; }
+
+extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream) {
+  if (!a || !w) return conv3d_impl(a, w, dtype, stream, 0, -1);
+  flk_conv_weights* wm = const_cast<flk_conv_weights*>(w);
+  for (const flk_conv_weights::Tuned& tn : wm->tuned)
+    if (tn.B == a->B && tn.To == a->To && tn.Ho == a->Ho && tn.Wo == a->Wo) return conv3d_impl(a, w, dtype, stream, tn.wn, tn.da);
+  if (!g_tuning || w->stem4) return conv3d_impl(a, w, dtype, stream, 0, -1);
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  FLK_CHECK_HIP(hipEventCreate(&e0));
+  FLK_CHECK_HIP(hipEventCreate(&e1));
+  const int nf = w->nf, wn_max = dtype == FLK_BF16 ? nf / 2 : nf;
+  struct Cand { int wn, da; };
+  std::vector<Cand> cands;
+  cands.push_back({0, -1});                                       // the heuristic's choice
+  for (int wn = 1; wn <= 4 && wn <= (wn_max < 1 ? 1 : wn_max); wn *= 2) {
+    const int nfw = nf / wn;
+    if (wn == 1) cands.push_back({1, 0});
+    if (nfw <= 4 && (dtype != FLK_BF16 || nfw >= 2)) cands.push_back({wn, 1});
+  }
+  float best_ms = 1e30f;
+  Cand best = cands[0];
+  for (const Cand& c : cands) {
+    int rc = conv3d_impl(a, w, dtype, stream, c.wn, c.da);        // warm-up (also validates the candidate)
+    if (rc) continue;
+    FLK_CHECK_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < 3; ++r) (void)conv3d_impl(a, w, dtype, stream, c.wn, c.da);
+    FLK_CHECK_HIP(hipEventRecord(e1, s));
+    FLK_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FLK_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best_ms * 0.97f) { best_ms = ms; best = c; }         // candidates are listed heuristic-first: keep it on ties
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  wm->tuned.push_back({a->B, a->To, a->Ho, a->Wo, best.wn, best.da});
+  return conv3d_impl(a, w, dtype, stream, best.wn, best.da);
 }

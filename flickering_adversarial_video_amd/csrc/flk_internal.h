@@ -47,6 +47,8 @@ struct flk_conv_weights {
   int dtype = 0, nf = 0, nslab = 0, ntaps = 0, cout_frags = 0;
   int cin_split = 0, nslab1 = 0;   // two-segment K order: slabs [0,nslab1) = channels [0,cin_split)
   int stem4 = 0;                   // folded-stem K-step packing (49 steps of non-zero chunks; conv_igemm.hip mode 4)
+  struct Tuned { int B, To, Ho, Wo, wn, da; };
+  std::vector<Tuned> tuned;        // autotuned launch layout per call geometry (conv_igemm.hip: flk_conv_set_autotune)
   size_t bytes = 0;
 };
 

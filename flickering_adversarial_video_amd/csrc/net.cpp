@@ -102,6 +102,7 @@ struct flk_net {
   hipStream_t side[kSideStreams] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr};
   bool multi_stream = true;
+  bool tuning = false;
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fwd, ev_bwd;
   bool ev_fwd_valid = false, ev_bwd_valid = false;
@@ -906,9 +907,11 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
   }
   // per-layer profiling runs the plan serially on the caller's stream: durations of co-running kernels would overlap
   const bool ms = n->multi_stream && n->side[0] && !n->profile;
+  bool in_fork = false;
   for (size_t i = 0; i < ops.size(); ++i) {
     Op& op = ops[i];
     if (op.kind == K_FORK) {
+      in_fork = true;
       if (ms) {
         FLK_CHECK_HIP(hipEventRecord(n->ev_fork, s));
         for (int l = 0; l < kSideStreams; ++l) FLK_CHECK_HIP(hipStreamWaitEvent(n->side[l], n->ev_fork, 0));
@@ -916,6 +919,7 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       continue;
     }
     if (op.kind == K_JOIN) {
+      in_fork = false;
       if (ms)
         for (int l = 0; l < kSideStreams; ++l) {
           FLK_CHECK_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
@@ -924,6 +928,9 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       continue;
     }
     hipStream_t st = (ms && op.lane > 0) ? n->side[op.lane - 1] : s;
+    // tuning pass: only the launches that run alone on the device (outside the fork/join regions) are timed in the
+    // conditions they will run in; branch kernels co-run with their siblings, where the isolated optimum is not the best
+    if (n->tuning) flk_conv_set_autotune(!in_fork);
     if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].first, st));
     int rc = op.run(st);
     if (rc) return rc;
@@ -948,6 +955,23 @@ extern "C" int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, v
   if (!n->fwd_done) { flk_set_error("flk_net_backward: no forward pass to differentiate"); return FLK_ESTATE; }
   n->dlogits_in = dlogits; n->gx_in = gx_in;
   return run_ops(n, n->bwd, n->ev_bwd, n->ev_bwd_valid, (hipStream_t)stream);
+}
+
+// one serial forward + backward with conv autotuning switched on (conv_igemm.hip): every convolution of the plan times its
+// candidate launch layouts on its real operands and keeps the fastest for all later calls
+extern "C" int flk_net_autotune(flk_net* n, const void* x_in, float* logits, const float* dlogits, void* gx_in, void* stream) {
+  FLK_REQUIRE(n && n->finalized && x_in && logits && dlogits && gx_in, "flk_net_autotune: bad argument / not finalized");
+  const bool ms = n->multi_stream;
+  n->multi_stream = false;
+  n->tuning = true;
+  int rc = flk_net_forward(n, x_in, logits, 1, stream);
+  if (!rc) rc = flk_net_backward(n, dlogits, gx_in, stream);
+  n->tuning = false;
+  flk_conv_set_autotune(0);
+  n->multi_stream = ms;
+  if (rc) return rc;
+  FLK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return FLK_OK;
 }
 
 extern "C" int flk_net_profile(flk_net* n, int enable) {

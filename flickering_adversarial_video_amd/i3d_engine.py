@@ -147,6 +147,14 @@ class FlickerI3D:
                              f"got {tuple(x.shape)} {x.dtype} {x.device}")
         return x.contiguous()
 
+    def autotune(self, x):
+        """Pick the fastest launch layout for every convolution on this clip's activations (like cudnn.benchmark: speed
+        only -- the arithmetic per output does not depend on the layout).  Takes a fraction of a second; call once."""
+        x = self._check_x(x)
+        ops.perturb_apply_s2d(self._apply_args(x, 0.0, 0, 0), self.dtype, self._xs2d)
+        dl = torch.randn_like(self._logits) * 1e-3
+        self.net.autotune(self._xs2d, self._logits, dl, self._gx)
+
     # ---- inference ---------------------------------------------------------------------------------
     def logits(self, x, adv_flag=None, cyclic=None):
         x = self._check_x(x)

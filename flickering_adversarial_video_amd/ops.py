@@ -272,6 +272,10 @@ class Net:
         check(load().flk_net_backward(self.handle, ptr(dlogits), ptr(gx), stream_ptr()))
         return gx
 
+    def autotune(self, x, logits, dlogits, gx):
+        """tune the launch layout of every convolution of the plan on these operands (one serial forward + backward)"""
+        check(load().flk_net_autotune(self.handle, ptr(x), ptr(logits), ptr(dlogits), ptr(gx), stream_ptr()))
+
     def profile(self, enable):
         check(load().flk_net_profile(self.handle, int(enable)))
 

@@ -57,6 +57,12 @@ int flk_conv_weights_create(const float* w_dhwio, int kt, int kh, int kw, int ci
 int flk_conv_weights_create_split(const float* w_dhwio, int kt, int kh, int kw, int cin, int cout,
                                   const float* row_scale, int cin_split, int dtype, int nf,
                                   flk_conv_weights** out);
+/* Launch-layout autotuning (speed only: the arithmetic per output does not depend on the layout).  While switched on
+ * (per host thread), every flk_conv3d call with a geometry not seen before times its candidate layouts on its own
+ * operands, SYNCHRONISING the stream, and remembers the fastest in the weights object; later calls reuse it.
+ * flk_net_autotune runs one forward + backward of a finalized network in that mode. */
+int flk_conv_set_autotune(int on);
+
 /* Weights of the folded 7x7x7 / stride-2 I3D stem (Conv3d_1a_7x7, i3d.py:168-170) as a 4x4x4 convolution over the
  * fold_t = 3 space-to-depth clip (flk_perturb_apply_s2d): w_folded is [4,4,4,32,cout] with channel
  * (qt*2+qh)*8 + qw*3 + c.  Tap index 3 of an axis exists for parity 0 only, so whole 8-channel chunks are structurally
@@ -234,6 +240,9 @@ int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream
 /* per-layer HIP-event timing of the next forward/backward (bench.py roofline leg).  While enabled the plan runs serially on
  * the caller's stream (normally independent Inception branches run on parallel streams; FLK_SINGLE_STREAM=1 disables that). */
 int flk_net_profile(flk_net* n, int enable);
+/* one serial forward + backward with flk_conv_set_autotune(1): tunes the launch layout of every convolution of the plan on
+ * its real operands (x_in / dlogits as for forward / backward; synchronises the stream) */
+int flk_net_autotune(flk_net* n, const void* x_in, float* logits, const float* dlogits, void* gx_in, void* stream);
 int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap);
 int64_t flk_net_input_numel(const flk_net* n);
 int flk_net_num_classes(const flk_net* n);

@@ -222,3 +222,20 @@ def test_inference_engine_cyclic_flags():
     p_cyc = eng(x, adv_flag=1, cyclic_input_flag=1).clone()
     assert eng.last_shift_p == 0
     assert torch.allclose(eng(torch.roll(x, eng.last_shift_x, dims=1), adv_flag=1), p_cyc, atol=2e-6)
+
+
+def test_autotune_changes_speed_only():
+    """flk_net_autotune picks launch layouts per convolution; results must stay bitwise identical (same K order per output)."""
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W = i3d_spec.synthetic_i3d_weights(42)
+    x = torch.from_numpy(i3d_spec.synthetic_clip_u8(2, T, seed=4)).cuda()
+    eng = FlickerI3D(W, batch_size=2, frames=T, dtype="bf16")
+    labels = eng.logits(x, adv_flag=0.0).argmax(-1).clone()
+    l0 = eng.logits(x, adv_flag=0.0).clone()
+    r0 = eng.step(x, labels, update=False)
+    g0 = eng.delta_gradient().clone()
+    eng.autotune(x)
+    torch.testing.assert_close(eng.logits(x, adv_flag=0.0), l0, rtol=0, atol=0)
+    eng.step(x, labels, update=False)
+    torch.testing.assert_close(eng.delta_gradient(), g0, rtol=0, atol=0)
