@@ -270,7 +270,7 @@ class FlickerVideoResNet:
             lr_step_size = int(np.ceil(2 / 3 * epochs))
         results = []
         for e in range(start_epoch, epochs + 1):
-            lr_e = lr * lr_gamma ** ((e - start_epoch) // max(int(lr_step_size), 1))
+            lr_e = lr * lr_gamma ** ((e - start_epoch) // max(int(lr_step_size), 1))   # a fresh StepLR on every (re)start, like the reference
             res = self.train_an_epoch(data_loaders, criterion, metric, lr_e)
             res["lr"] = lr_e
             results.append(res)

@@ -88,3 +88,31 @@ def test_universal_script_on_tfrecords(tmp_path):
     assert [s_ for s_, _ in ev] == [2] and set(tb_events.SCALAR_TAGS) <= set(ev[0][1]) and np.isfinite(list(ev[0][1].values())).all()
     r = subprocess.run(cmd + ["--max-steps", "5"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "resumed from" in r.stdout and os.path.exists(tmp_path / "out" / "model_step_00005.npz")
+
+
+def test_r2plus1d_universal_script(tmp_path):
+    """pre-decoded clips -> VideoResNet universal attack epochs: result files named like the reference's, resume from the last"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet
+    T, N = 8, 4
+    u8 = np.random.default_rng(3).integers(0, 256, (N, T, 112, 112, 3), dtype=np.uint8)
+    eng = FlickerVideoResNet("r3d_18", vs.synthetic_weights("r3d_18", 42), batch_size=2, sample_length=T, dtype="f32")
+    norm = ((u8.astype(np.float32) / 255.0 - np.array(vs.DEFAULT_MEAN, np.float32)) / np.array(vs.DEFAULT_STD, np.float32)).astype(np.float32)
+    labels = np.concatenate([eng.logits(torch.from_numpy(norm[i:i + 2]).cuda(), False).argmax(1).cpu().numpy() for i in (0, 2)])
+    del eng
+    np.savez(tmp_path / "train.npz", clips=u8, labels=labels)
+    np.savez(tmp_path / "val.npz", clips=norm[:2], labels=labels[:2])            # float32 clips are taken as normalised
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "r2plus1d_main_universal_attack.py"), "--train-npz", str(tmp_path / "train.npz"),
+           "--val-npz", str(tmp_path / "val.npz"), "--results-root", str(tmp_path / "results"), "--base-model", "r3d_18", "--batch-size", "2",
+           "--dtype", "f32"]
+    r = subprocess.run(cmd + ["--epochs", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    dest = glob.glob(str(tmp_path / "results" / "r3d_18" / "generalization" / "universal" / "val_test" / "all_cls_shuffle_flickering" / "t_4_v_2_*"))
+    assert len(dest) == 1 and sorted(os.path.basename(f) for f in glob.glob(dest[0] + "/*.npy")) == ["r3d_18_001.npy", "r3d_18_002.npy"]
+    res = np.load(os.path.join(dest[0], "r3d_18_002.npy"), allow_pickle=True)
+    assert len(res) == 2 and res[-1]["valid/perturbation"].shape == (3, T, 1, 1) and 0.0 <= res[-1]["valid/fooling_ratio"] <= 1.0
+    r = subprocess.run(cmd + ["--epochs", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "init from last ckpt" in r.stdout and "continue from last epoch. init with 3" in r.stdout
+    assert os.path.exists(os.path.join(dest[0], "r3d_18_003.npy"))
