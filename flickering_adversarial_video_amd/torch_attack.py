@@ -279,3 +279,32 @@ class FlickerVideoResNet:
                 np.save(os.path.join(model_dir, f"{model_name or self.model_name}_{str(e).zfill(3)}.npy"), np.array(results, dtype=object),
                         allow_pickle=True)
         return results
+
+    def fit_many_videos(self, videos, criterion, lr=1e-3, model_dir=None, label_id_to_text=None, save_model=True, n_iter=3000,
+                        targeted_attack=False, target_class_id=None, **kw):
+        """``VideoLearnerAdversarial.fit_many_videos`` (model.py:791-982): one single-video attack per (inputs, target, name);
+        a video whose result file already shows a success is skipped, a placeholder (None) is written before the attack, the
+        perturbation restarts from U(-1,1) * 0.005 and the clamp norm from ``max_norm`` (model.py:938-947).  Result files are
+        ``<name>_@<class>.npy`` (model.py:917-921).  Returns {name: result dict or None}."""
+        import os
+        out = {}
+        rng = np.random.default_rng(0)
+        for inputs, target, name in videos:
+            cls = (label_id_to_text[int(target[0])] if label_id_to_text is not None else str(int(target[0]))).replace(" ", "_")
+            dest = os.path.join(model_dir, f"{os.path.basename(str(name))}_@{cls}.npy") if model_dir else None
+            if dest and os.path.exists(dest):
+                prev = np.load(dest, allow_pickle=True).tolist()
+                if prev is None or np.array(prev["is_adversarial"]).any():
+                    continue                                  # attacked before (None: the clean clip was misclassified / aborted run)
+            elif dest and save_model:
+                os.makedirs(model_dir, exist_ok=True)
+                np.save(dest, None)
+            self.pert_model.init_perturbation(((rng.random((3, self.T, 1, 1), dtype=np.float32) * 2 - 1) * 0.005))
+            self.pert_model.dynamic_max_norm = self.pert_model.max_norm
+            res = self.fit_single_video_attack(inputs, target, criterion, lr=lr, n_iter=n_iter, targeted_attack=targeted_attack,
+                                               target_class_id=target_class_id, **kw)
+            out[str(name)] = res
+            if res is not None and dest and save_model:
+                res = dict(res, prob_clean_input=res["prob_clean_input"].cpu().numpy())
+                np.save(dest, res, allow_pickle=True)
+        return out

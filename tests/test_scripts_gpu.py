@@ -116,3 +116,29 @@ def test_r2plus1d_universal_script(tmp_path):
     r = subprocess.run(cmd + ["--epochs", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "init from last ckpt" in r.stdout and "continue from last epoch. init with 3" in r.stdout
     assert os.path.exists(os.path.join(dest[0], "r3d_18_003.npy"))
+
+
+def test_r2plus1d_single_video_statistics_script(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet
+    T = 8
+    norm = vs.synthetic_clip(2, T, seed=6)
+    eng = FlickerVideoResNet("r3d_18", vs.synthetic_weights("r3d_18", 42), batch_size=1, sample_length=T, dtype="f32")
+    lab = [int(eng.logits(torch.from_numpy(norm[i:i + 1]).cuda(), False).argmax()) for i in range(2)]
+    del eng
+    lab[1] = (lab[1] + 1) % 400                                               # second clip "misclassified": no attack, None result
+    np.savez(tmp_path / "v.npz", clips=norm, labels=np.array(lab), names=np.array(["clipA", "clipB"]))
+    (tmp_path / "labels.txt").write_text("\n".join(f"class {i}" for i in range(400)))
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "r2plus1d_main_statistics_single_video_attack.py"), "--videos-npz", str(tmp_path / "v.npz"),
+           "--label-map", str(tmp_path / "labels.txt"), "--results-root", str(tmp_path / "res"), "--base-model", "r3d_18", "--dtype", "f32",
+           "--n-iter", "3", "--restart-after", "40"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "clipA:" in r.stdout and "clipB: clean clip misclassified" in r.stdout
+    files = sorted(glob.glob(str(tmp_path / "res" / "r3d_18" / "single_video_attack" / "flickering" / "*" / "*.npy")))
+    assert [os.path.basename(f) for f in files] == [f"clipA_@class_{lab[0]}.npy", f"clipB_@class_{lab[1]}.npy"]
+    ra = np.load(files[0], allow_pickle=True).tolist()
+    assert len(ra["loss/total"]) >= 3 and ra["perturbation"][0].shape == (3, T, 1, 1) and ra["prob_clean_input"].shape == (1, 400)
+    assert np.load(files[1], allow_pickle=True).tolist() is None
