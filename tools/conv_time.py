@@ -1,0 +1,26 @@
+"""Time ONE convolution geometry in isolation (20 launches x 5 repetitions after a 20-launch warm-up; min / median).
+A/B different builds or env knobs by alternating processes -- single measurements inside a long run drift with the clock state.
+
+usage: conv_time.py k cin cout nf B T H W [T]      (k x k x k taps, stride 1 SAME; a trailing argument = data-gradient)"""
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flickering_adversarial_video_amd import ops
+# usage: conv_time.py kt cin cout nf B T H W [transpose]
+kt, cin, cout, nf, B, T, H, W = (int(v) for v in sys.argv[1:9])
+tr = len(sys.argv) > 9
+torch.manual_seed(0)
+x = torch.randn(B, T, H, W, cout if tr else cin, device="cuda").to(torch.bfloat16)
+w = (np.random.default_rng(0).standard_normal((kt, kt, kt, cin, cout)) * 0.05).astype(np.float32)
+pw = ops.ConvWeights(w, torch.bfloat16, nf, transpose=tr)
+out = torch.empty(B, T, H, W, cin if tr else cout, device="cuda", dtype=torch.bfloat16)
+pad = tuple([kt - 1 - (kt - 1) // 2] * 3) if tr else None
+f = lambda: ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W), out=out)
+for _ in range(20): f()
+torch.cuda.synchronize()
+ts = []
+for rep in range(5):
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): f()
+    e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) / 20)
+print(sys.argv[1:], "ms min %.4f med %.4f" % (min(ts), sorted(ts)[2]), flush=True)
