@@ -239,3 +239,35 @@ def test_autotune_changes_speed_only():
     torch.testing.assert_close(eng.logits(x, adv_flag=0.0), l0, rtol=0, atol=0)
     eng.step(x, labels, update=False)
     torch.testing.assert_close(eng.delta_gradient(), g0, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("frames", [90, 18])
+def test_reference_default_clip_length(frames):
+    """The reference runs on 90-frame clips (_SAMPLE_VIDEO_FRAMES, kinetics_i3d_utils.py): T/2 = 45, 23, 12 are odd, so
+    the temporal SAME paddings have a pad-before and the strided pools take their fallback kernels.  Logits, loss and
+    d(loss)/d(delta) of the fp32 mode against the fp32 CPU oracle (18 frames: the same odd-size paths, small)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    Tn = frames
+    W = i3d_spec.synthetic_i3d_weights(42)
+    Wt = {torch.float32: {k: torch.from_numpy(v) for k, v in W.items()}}
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(1, Tn, seed=90))
+    delta = torch.from_numpy(np.random.default_rng(9).uniform(-0.05, 0.05, (Tn, 1, 1, 3)).astype(np.float32))
+    x = xu.float() / 128 - 1
+    d = delta.clone().requires_grad_(True)
+    logits = i3d_ref.i3d_logits(am.tf_apply(x, d), Wt[torch.float32])
+    label = logits.argmax(-1)
+    loss, _, _ = am.tf_improve_adversarial_loss(logits, label, 0.05, False, False)
+    (g,) = torch.autograd.grad(loss, d)
+    eng = FlickerI3D(W, batch_size=1, frames=Tn, dtype="f32")
+    eng.reset_perturbation(delta.numpy())
+    got = eng.logits(xu.cuda(), adv_flag=1.0).cpu()
+    assert rel_err(got, logits.detach()) < 1e-3
+    r = eng.step(xu.cuda(), label.cuda(), update=False, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05)
+    assert float(r["adv_loss"]) == pytest.approx(loss.item(), rel=1e-3, abs=1e-6)
+    gg = eng.delta_gradient().cpu().reshape(g.shape)
+    cos = float(torch.nn.functional.cosine_similarity(gg.double().flatten(), g.double().flatten(), 0))
+    print(f"T={Tn}: logits rel err {rel_err(got, logits.detach()):.2e}, d(loss)/d(delta) cosine {cos:.6f}, max-rel {rel_err(gg, g):.2e}")
+    assert cos > 0.999 and rel_err(gg, g) < 3e-2
