@@ -271,3 +271,14 @@ def test_reference_default_clip_length(frames):
     cos = float(torch.nn.functional.cosine_similarity(gg.double().flatten(), g.double().flatten(), 0))
     print(f"T={Tn}: logits rel err {rel_err(got, logits.detach()):.2e}, d(loss)/d(delta) cosine {cos:.6f}, max-rel {rel_err(gg, g):.2e}")
     assert cos > 0.999 and rel_err(gg, g) < 3e-2
+    # the bf16 mode on the same odd sizes (fixed-point pool accumulation, fallback kernels), two clips per batch
+    e16 = FlickerI3D(W, batch_size=2, frames=Tn, dtype="bf16")
+    e16.reset_perturbation(delta.numpy())
+    xu2 = torch.cat([xu, xu]).cuda()
+    got16 = e16.logits(xu2, adv_flag=1.0).cpu()
+    assert torch.equal(got16[0], got16[1]) and rel_err(got16[:1], logits.detach()) < 5e-2
+    e16.step(xu2, torch.cat([label, label]).cuda(), update=False, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05)
+    g16 = e16.delta_gradient().cpu().reshape(g.shape) / 2          # the margin loss is a SUM over the (identical) clips
+    cos16 = float(torch.nn.functional.cosine_similarity(g16.double().flatten(), g.double().flatten(), 0))
+    print(f"T={Tn} bf16: logits rel err {rel_err(got16[:1], logits.detach()):.2e}, gradient cosine {cos16:.4f}")
+    assert cos16 > 0.85
