@@ -200,9 +200,11 @@ def main():
         "adv_loss_last": float(last["adv_loss"]), "workspace_GiB": eng.net.workspace_bytes / 2**30,
     }
 
-    if rank == 0 and not a.no_roofline:
+    if not a.no_roofline:
         # dominant kernel = conv_igemm (all convolutions, forward and data-gradient): HIP events around every launch,
-        # on the stream the kernels run on, over 3 extra (untimed) steps
+        # on the stream the kernels run on, over 3 extra (untimed) steps.  EVERY rank runs these steps (each step ends in
+        # the delta-gradient all-reduce: a rank that skipped them would leave rank 0 waiting in a collective nobody joins);
+        # only rank 0 reports.
         eng.net.profile(True)
         per_kind = {}
         reps = 3

@@ -63,7 +63,8 @@ class AdamArgs(C.Structure):
 
 class DenseAdamArgs(C.Structure):
     _fields_ = [("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("torch_dialect", C.c_int), ("beta", C.c_float), ("g_scale", C.c_float),
-                ("lr", C.c_float), ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("step", C.c_int)]
+                ("lr", C.c_float), ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("step", C.c_int),
+                ("dyn_max_norm", C.c_float)]
 
 
 class LossArgs(C.Structure):

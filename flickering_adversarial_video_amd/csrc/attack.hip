@@ -461,8 +461,9 @@ extern "C" int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, 
 // d/d(delta_t) sqrt(mean_{hwc} delta_t^2) = delta_t / (N_f * sqrt(mean_t)),  N_f = H*W*3.
 constexpr int DENSE_CHUNKS = 64;     // workgroups per frame in the reduction pass
 
-__global__ __launch_bounds__(256) void dense_frame_stats(const float* delta, int frame_elems, float* part) {
-  // part[(t*DENSE_CHUNKS + c)*4 + {0,1,2,3}] = {sum d^2, sum |d|, sum |d - d_prev_frame|, max |d|} over this chunk
+__global__ __launch_bounds__(256) void dense_frame_stats(const float* delta, int frame_elems, float* part, float clampv) {
+  // part[(t*DENSE_CHUNKS + c)*4 + {0,1,2,3}] = {sum clamp(d)^2, sum |d|, sum |d - d_prev_frame|, max |d|} over this chunk
+  // (clampv > 0: the regulariser sees the clamped perturbation; the metrics are taken on the raw one, model.py:113-118)
   const int t = blockIdx.y, c = blockIdx.x, T = gridDim.y;
   const float4* d4 = (const float4*)(delta + (size_t)t * frame_elems);
   const float4* p4 = (const float4*)(delta + (size_t)((t + T - 1) % T) * frame_elems);
@@ -470,7 +471,11 @@ __global__ __launch_bounds__(256) void dense_frame_stats(const float* delta, int
   float sq = 0.f, ab = 0.f, ro = 0.f, mx = 0.f;
   for (int i = c * 256 + threadIdx.x; i < n4; i += DENSE_CHUNKS * 256) {
     const float4 a = d4[i], b = p4[i];
-    sq += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    {
+      const float cx = fminf(fmaxf(a.x, -clampv), clampv), cy = fminf(fmaxf(a.y, -clampv), clampv);
+      const float cz = fminf(fmaxf(a.z, -clampv), clampv), cw = fminf(fmaxf(a.w, -clampv), clampv);
+      sq += cx * cx + cy * cy + cz * cz + cw * cw;
+    }
     ab += fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w);
     ro += fabsf(a.x - b.x) + fabsf(a.y - b.y) + fabsf(a.z - b.z) + fabsf(a.w - b.w);
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
@@ -523,7 +528,8 @@ __global__ __launch_bounds__(256) void dense_adam_kernel(const flk_dense_adam_ar
     float mv[4] = {mm.x, mm.y, mm.z, mm.w}, vvv[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float g = a.g_scale * gg[k] + rcoef * dd[k];
+      // d(L12)/d(delta) through the clamp: passes where |delta| <= dyn_max_norm (torch.clamp gradient, bounds inclusive)
+      const float g = a.g_scale * gg[k] + ((a.dyn_max_norm > 0.f && fabsf(dd[k]) > a.dyn_max_norm) ? 0.f : rcoef * dd[k]);
       mv[k] = a.adam_b1 * mv[k] + (1.f - a.adam_b1) * g;
       vvv[k] = a.adam_b2 * vvv[k] + (1.f - a.adam_b2) * g * g;
       dd[k] = a.torch_dialect ? dd[k] - (a.lr / bc1) * mv[k] / (sqrtf(vvv[k]) / bc2s + a.adam_eps)
@@ -549,7 +555,8 @@ extern "C" int flk_perturb_dense_l12_adam(const flk_dense_adam_args* a, const fl
   float* part = scratch;
   float* frame_rms = scratch + (size_t)a->T * DENSE_CHUNKS * 4;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(dense_frame_stats, dim3(DENSE_CHUNKS, a->T), dim3(256), 0, s, delta, fe, part);
+  hipLaunchKernelGGL(dense_frame_stats, dim3(DENSE_CHUNKS, a->T), dim3(256), 0, s, delta, fe, part,
+                     a->dyn_max_norm > 0.f ? a->dyn_max_norm : INFINITY);
   hipLaunchKernelGGL(dense_frame_finish, dim3(1), dim3(1024), 0, s, part, a->T, fe, frame_rms, scalars);
   hipLaunchKernelGGL(dense_adam_kernel, dim3(64, a->T), dim3(256), 0, s, *a, fe, frame_rms, g_adv, delta, m, v);
   FLK_CHECK_HIP(hipGetLastError());

@@ -158,7 +158,11 @@ __global__ __launch_bounds__(256) void softmax_adv_loss_kernel(const flk_loss_ar
   __shared__ float coef[8];
   const int b = blockIdx.x, tid = threadIdx.x, C = a.C;
   const float* z = logits + (size_t)b * C;
-  const int y = (int)labels[b];
+  // a label outside [0, C) must not index z[]: clamp it for the reads and poison this clip's outputs with NaN so that the
+  // error is visible in the loss instead of being a silent out-of-bounds read (the host wrapper validates the range too)
+  const int64_t y_raw = labels[b];
+  const bool y_bad = y_raw < 0 || y_raw >= (int64_t)C;
+  const int y = y_bad ? 0 : (int)y_raw;
   constexpr int PER = 4;  // C <= 1024
   float zl[PER], pl[PER];
   float mx = -INFINITY; int mxi = 0x7fffffff;
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(256) void softmax_adv_loss_kernel(const flk_loss_ar
       else if (a.torch_dialect) { loss = -logf(py + 1e-6f) * ms; gy = -ms / (py + 1e-6f); }
       else { loss = -(zy - zmax - logf(1.f / inv)) * ms; gy = -ms / py; }
     }
+    if (y_bad) { loss = NAN; alpha = NAN; gy = NAN; }
     coef[0] = alpha; coef[1] = beta; coef[2] = gy * py; coef[3] = gP * Pm;
     per_clip[b * 4 + 0] = loss; per_clip[b * 4 + 1] = py; per_clip[b * 4 + 2] = Pm; per_clip[b * 4 + 3] = (float)amax;
   }

@@ -162,9 +162,9 @@ class FlickerI3D:
         ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
         return self.net.forward(self._xs2d, self._logits)
 
-    def __call__(self, inputs, adv_flag=0):
+    def __call__(self, inputs, adv_flag=0, cyclic=None):
         """softmax of the (clean by default) clip: kinetics_i3d.__call__ (kinetics_i3d_utils.py:210-212)"""
-        return torch.softmax(self.logits(inputs, adv_flag), -1)
+        return torch.softmax(self.logits(inputs, adv_flag, cyclic), -1)
 
     # ---- one attack iteration ----------------------------------------------------------------------
     def step(self, x, labels, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05, targeted=False,
@@ -175,7 +175,7 @@ class FlickerI3D:
         labels = true labels (untargeted) or the target class per clip (targeted).  Returned scalars are the
         PRE-update values, as the reference fetches them together with train_op."""
         if self.dense:
-            return self._step_dense(x, labels, lr, beta1, margin, targeted, use_logits, improve_loss, cyclic, update)
+            return self._step_dense(x, labels, lr, beta0, beta1, margin, targeted, use_logits, improve_loss, cyclic, update)
         x = self._check_x(x)
         cyclic = self.cyclic_flag if cyclic is None else cyclic
         cyclic_pert = self.cyclic_pert_flag if cyclic_pert is None else cyclic_pert
@@ -207,9 +207,9 @@ class FlickerI3D:
                        roughness=sc[5], pert_max=sc[6], pert_min=sc[7], _reg_weight=beta0)
         return res
 
-    def _step_dense(self, x, labels, lr, beta1, margin, targeted, use_logits, improve_loss, cyclic, update):
-        """kinetics_i3d_L12 (kinetics_i3d_utils.py:308-521) with loss = adv + beta1 * L12 (i3d_adversarial_main_universal.py:129-133):
-        dense delta [T,224,224,3]; the all-reduce payload is the full dense gradient (38.5 MB at T=64: bandwidth-bound)."""
+    def _step_dense(self, x, labels, lr, beta0, beta1, margin, targeted, use_logits, improve_loss, cyclic, update):
+        """kinetics_i3d_L12 (kinetics_i3d_utils.py:308-521) with loss = adv + beta0 * (beta1 * L12) (i3d_adversarial_main_universal.py:
+        129-133): dense delta [T,224,224,3]; the all-reduce payload is the full dense gradient (38.5 MB at T=64: bandwidth-bound)."""
         x = self._check_x(x)
         a = self._apply_args(x, 1.0, self.cyclic_flag if cyclic is None else cyclic, 0)
         ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
@@ -222,17 +222,17 @@ class FlickerI3D:
             self._gdense = torch.empty_like(self.eps_rgb)
         ops.perturb_grad_reduce(a, self._gx, self._gdense)
         tail = pc[:, :3].sum(0)
-        if self.world > 1:
-            torch.distributed.all_reduce(self._gdense, group=self.pg)
-            torch.distributed.all_reduce(tail, group=self.pg)
+        parallel.allreduce_sum_(self._gdense, self.pg)            # RCCL over xGMI: the dense gradient (38.5 MB at 64 x 224 x 224)
+        parallel.allreduce_sum_(tail, self.pg)
         res = StepResult(adv_loss=tail[0].clone(), softmax=sm, label_prob=pc[:, 1], argmax=pc[:, 3].to(torch.int64),
                          prob_to_min=(tail[2] if targeted else tail[1]) / gbatch, prob_to_max=(tail[1] if targeted else tail[2]) / gbatch)
         res["is_adversarial"] = (res["argmax"] == labels).all() if targeted else (res["argmax"] != labels).all()
         if update:
             self.adam_t += 1
-            sc = ops.perturb_dense_l12_adam(self._gdense, self.eps_rgb, self.adam_m, self.adam_v, self.adam_t, dialect="tf", beta=beta1, lr=lr).clone()
-            res.update(reg_loss=sc[0], L12=sc[0], thickness=sc[1], roughness=sc[2], pert_max=sc[3], total_loss=res["adv_loss"] + beta1 * sc[0],
-                       thickness_relative=sc[1] / 2 * 100, roughness_relative=sc[2] / 2 * 100)
+            sc = ops.perturb_dense_l12_adam(self._gdense, self.eps_rgb, self.adam_m, self.adam_v, self.adam_t, dialect="tf", beta=beta0 * beta1,
+                                            lr=lr).clone()
+            res.update(reg_loss=beta1 * sc[0], L12=sc[0], thickness=sc[1], roughness=sc[2], pert_max=sc[3],
+                       total_loss=res["adv_loss"] + beta0 * beta1 * sc[0], thickness_relative=sc[1] / 2 * 100, roughness_relative=sc[2] / 2 * 100)
         return res
 
     def delta_gradient(self):

@@ -200,14 +200,16 @@ def perturb_reg_adam(g_adv, delta, m, v, step, *, dialect="tf", beta0=1.0, beta1
 
 
 def perturb_dense_l12_adam(g_adv, delta, m, v, step, *, dialect="tf", beta=1.0, g_scale=1.0, lr=1e-3, adam=(0.9, 0.999, 1e-8),
-                           scalars=None, scratch=None):
-    """dense delta [T,H,W,3]: L12 regulariser gradient + Adam (kinetics_i3d_L12); returns scalars {L12, thickness, roughness, max}"""
+                           scalars=None, scratch=None, dyn_max_norm=0.0):
+    """dense delta [T,H,W,3]: L12 regulariser gradient + Adam (kinetics_i3d_L12); returns scalars {L12, thickness, roughness, max}.
+    dyn_max_norm > 0 (torch dialect): L12 of the clamped perturbation, as Losses receives it (model.py:1078)"""
     T, H, W, _ = delta.shape
     a = DenseAdamArgs()
     a.T, a.H, a.W, a.torch_dialect = T, H, W, int(dialect == "torch")
     a.beta, a.g_scale, a.lr = beta, g_scale, lr
     a.adam_b1, a.adam_b2, a.adam_eps = adam
     a.step = int(step)
+    a.dyn_max_norm = float(dyn_max_norm)
     if scalars is None:
         scalars = torch.empty(4, dtype=torch.float32, device="cuda")
     if scratch is None:
@@ -221,6 +223,30 @@ def pack_batch_sums(per_clip, prob_scale, out3):
     assert per_clip.dtype == torch.float32 and per_clip.is_contiguous() and per_clip.shape[1] == 4 and out3.dtype == torch.float32
     check(load().flk_pack_batch_sums(ptr(per_clip), per_clip.shape[0], float(prob_scale), ptr(out3), stream_ptr()))
     return out3
+
+
+_labels_ok = {}      # (data_ptr, _version, numel) -> number of classes the tensor was range-checked against
+
+
+def check_labels(labels, batch, num_classes):
+    """labels must be a CUDA int64 tensor of shape (batch,) with 0 <= label < num_classes: anything else would hand the loss
+    kernel a host pointer (GPU memory fault) or an out-of-range class index.  Device / dtype / shape are checked on every call
+    (free); the range check costs one device read-back and is cached per (storage, version), so a loop that reuses its label
+    tensor pays it once.  (The kernel itself clamps a bad index and poisons that clip's outputs with NaN.)"""
+    if not torch.is_tensor(labels) or not labels.is_cuda or labels.dtype != torch.int64 or tuple(labels.shape) != (batch,):
+        desc = f"{tuple(labels.shape)} {labels.dtype} {labels.device}" if torch.is_tensor(labels) else type(labels).__name__
+        raise ValueError(f"labels must be a CUDA int64 tensor of shape ({batch},), got {desc}")
+    if not labels.is_contiguous():
+        raise ValueError("labels must be contiguous")
+    key = (labels.data_ptr(), labels._version, labels.numel())
+    if _labels_ok.get(key) != num_classes:
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= num_classes:
+            raise ValueError(f"labels must lie in [0, {num_classes}), got [{lo}, {hi}]")
+        if len(_labels_ok) > 64:
+            _labels_ok.clear()
+        _labels_ok[key] = num_classes
+    return labels
 
 
 def softmax_adv_loss(logits, labels, *, dialect="tf", improve_loss=True, use_logits=False, targeted=False, margin=0.05,
@@ -237,7 +263,8 @@ def softmax_adv_loss(logits, labels, *, dialect="tf", improve_loss=True, use_log
         pc = torch.empty((B, 4), dtype=torch.float32, device=logits.device)
     else:
         sm, dl, pc = out
-    assert logits.dtype == torch.float32 and labels.dtype == torch.int64 and logits.is_contiguous()
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    check_labels(labels, B, Cn)
     check(load().flk_softmax_adv_loss(C.byref(a), ptr(logits), ptr(labels), ptr(sm), ptr(dl), ptr(pc), stream_ptr()))
     return sm, dl, pc
 

@@ -35,9 +35,16 @@ def pack_scalars(payload, T, per_clip):
     return payload
 
 
+def force_collective():
+    """FLK_FORCE_COLLECTIVE=1: issue the collectives even in a 1-rank process group (they are the identity there) -- lets a
+    one-GPU box execute the real RCCL all-reduce calls of the data-parallel path"""
+    import os
+    return os.environ.get("FLK_FORCE_COLLECTIVE", "0") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def allreduce_sum_(payload, group=None):
-    """in-place sum over ranks (no-op for a single process)"""
-    if world_size(group) > 1:
+    """in-place sum over ranks (no-op for a single process unless FLK_FORCE_COLLECTIVE=1)"""
+    if world_size(group) > 1 or force_collective():
         dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group)
     return payload
 
@@ -72,7 +79,6 @@ class FoolingCounter:
 
     def result(self, group=None):
         c = self.cnt.clone()
-        if world_size(group) > 1:
-            dist.all_reduce(c, group=group)
+        allreduce_sum_(c, group)
         miss, total = c.tolist()
         return (miss / total if total else float("nan")), int(total)

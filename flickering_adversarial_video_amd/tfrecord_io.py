@@ -160,21 +160,64 @@ def list_tfrecords(paths, limit=None):
     return files[:limit] if limit else files
 
 
+def record_spans(path):
+    """yield (payload offset, payload length) of every record of one .tfrecords file WITHOUT reading the payloads
+    (a 90-frame clip is 13.5 MB: a rank only reads the records it owns)"""
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        pos = 0
+        while pos < size:
+            f.seek(pos)
+            head = f.read(12)
+            if len(head) < 12:
+                raise ValueError(f"{path}: truncated record header")
+            (length,), (lcrc,) = struct.unpack("<Q", head[:8]), struct.unpack("<I", head[8:])
+            if masked_crc(head[:8]) != lcrc:
+                raise ValueError(f"{path}: corrupt record length")
+            if pos + 12 + length + 4 > size:
+                raise ValueError(f"{path}: truncated record")
+            yield pos + 12, length
+            pos += 12 + length + 4
+
+
+def _read_span(path, off, length):
+    with open(path, "rb") as f:
+        f.seek(off)
+        return f.read(length)
+
+
 def batches(files, batch_size, frames=90, rank=0, world=1, drop_remainder=True):
-    """uint8 batches [B,T,224,224,3] + labels; records are dealt round-robin to ranks (every rank sees the same number of
-    batches when drop_remainder)"""
-    clips, labels, k = [], [], 0
+    """uint8 batches [B,T,224,224,3] + labels.
+
+    Data-parallel sharding: the record stream is cut into GLOBAL batches of ``world * batch_size`` consecutive records and
+    rank r takes records [r*B, (r+1)*B) of each; the global remainder is dropped.  Every rank therefore yields the SAME number
+    of batches by construction (each step is followed by a collective: unequal counts would dead-lock the all-reduce), and
+    reads only the payloads it owns."""
+    if world > 1 and not drop_remainder:
+        raise ValueError("drop_remainder=False is only meaningful for a single rank (ranks must see equal batch counts)")
+    per_global = world * batch_size
+    spans = []
+
+    def load(span_list):
+        clips, labels = [], []
+        for path, off, ln in span_list:
+            v, l = parse_example_uint8(_read_span(path, off, ln), frames)
+            clips.append(v); labels.append(l)
+        return np.stack(clips), np.array(labels, dtype=np.int64)
+
     for path in files:
-        for payload in read_records(path):
-            if k % world == rank:
-                v, l = parse_example_uint8(payload, frames)
-                clips.append(v); labels.append(l)
-                if len(clips) == batch_size:
-                    yield np.stack(clips), np.array(labels, dtype=np.int64)
-                    clips, labels = [], []
-            k += 1
-    if clips and not drop_remainder:
-        yield np.stack(clips), np.array(labels, dtype=np.int64)
+        for off, ln in record_spans(path):
+            spans.append((path, off, ln))
+            if len(spans) == per_global:
+                yield load(spans[rank * batch_size:(rank + 1) * batch_size])
+                spans = []
+    if spans and not drop_remainder:
+        yield load(spans)
+
+
+def count_batches(files, batch_size, world=1):
+    """number of batches every rank gets from ``batches`` (headers only)"""
+    return sum(1 for path in files for _ in record_spans(path)) // (world * batch_size)
 
 
 # ---- writer (tests / dataset preparation) -----------------------------------------------------------------------------

@@ -16,13 +16,15 @@ ARCH_CODES = {"r2plus1d_18": FLK_NET_R2PLUS1D_18, "r3d_18": FLK_NET_R3D_18, "mc3
 
 
 class Perturbation:
-    """model.py:58-129.  size = [3,T,1,1] (flickering); the parameter is stored time-major [T,3] on the device."""
+    """model.py:58-129.  size = [3,T,1,1] (flickering) or [3,T,H,W] (the dense "L12" attack, model.py:380-384); the parameter
+    is stored time-major / channels-last on the device: [T,3] or [T,H,W,3]."""
 
     def __init__(self, size, requires_grad=True, device="cuda", max_value=None, min_value=None, max_norm=1.0, cyclic_pert=False):
-        if len(size) != 4 or size[0] != 3 or size[2] != 1 or size[3] != 1:
-            raise NotImplementedError("only the flickering perturbation [3,T,1,1] is built (dense L12: apply/gradient kernels only)")
+        if len(size) != 4 or size[0] != 3:
+            raise ValueError(f"perturbation size must be [3,T,1,1] or [3,T,H,W], got {tuple(size)}")
         self.size, self.device, self.requires_grad = tuple(size), device, requires_grad
         self.T = size[1]
+        self.dense = not (size[2] == 1 and size[3] == 1)
         # model.py:72-75: attributes are only set when the argument is None (SURVEY D.6) -- reproduced
         if max_value is None:
             self.max_value = float(np.min((1 - np.array(DEFAULT_MEAN)) / DEFAULT_STD))
@@ -34,13 +36,26 @@ class Perturbation:
         self.perturbation = None
         self.init_perturbation()
 
+    @property
+    def _dev_shape(self):
+        return (self.T, self.size[2], self.size[3], 3) if self.dense else (self.T, 3)
+
+    def _to_dev(self, p_cthw):
+        """[3,T,H,W] (reference layout) -> device layout"""
+        p = np.asarray(p_cthw, dtype=np.float32).reshape(self.size)
+        return np.ascontiguousarray(np.transpose(p, (1, 2, 3, 0)).reshape(self._dev_shape))
+
+    def _to_ref(self, t):
+        """device layout -> [3,T,H,W] like the reference tensors"""
+        return t.reshape(self.T, self.size[2], self.size[3], 3).permute(3, 0, 1, 2)
+
     def init_perturbation(self, perturbation=(), requires_grad=True, device="cuda"):
-        """model.py:121-126: U(-1,1)*1e-6 or the given numpy array [3,T,1,1]"""
+        """model.py:121-126: U(-1,1)*1e-6 or the given numpy array [3,T,1,1] / [3,T,H,W]"""
         if len(perturbation) == 0:
-            p = (self._rng.random((self.T, 3), dtype=np.float32) * 2 - 1) * 1e-6
+            p = (self._rng.random(self.size, dtype=np.float32) * 2 - 1) * 1e-6
         else:
-            p = np.asarray(perturbation, dtype=np.float32).reshape(3, self.T).T
-        self.perturbation = torch.from_numpy(np.ascontiguousarray(p)).cuda()
+            p = perturbation
+        self.perturbation = torch.from_numpy(self._to_dev(p)).cuda()
 
     def apply_args(self, x, adversarial=True):
         shift = int(self._rng.integers(0, self.T)) if (self.cyclic_pert and adversarial) else 0   # model.py:91-92
@@ -54,11 +69,11 @@ class Perturbation:
         return self.perturbation.clamp(-self.dynamic_max_norm, self.dynamic_max_norm)
 
     def get_perturbation(self):
-        """(clamped, raw) as [3,T,1,1] like the reference (model.py:128-129)"""
-        f = lambda t: t.t().reshape(3, self.T, 1, 1)
-        return f(self.clamp_perturbation()), f(self.perturbation)
+        """(clamped, raw) as [3,T,1,1] / [3,T,H,W] like the reference (model.py:128-129)"""
+        return self._to_ref(self.clamp_perturbation()), self._to_ref(self.perturbation)
 
     def metric_calc(self):
+        """model.py:113-118 on the raw parameter: roll over the time axis"""
         p = self.perturbation
         return p.abs().mean() * 100.0, (torch.roll(p, 1, 0) - p).abs().mean() * 100.0
 
@@ -69,8 +84,8 @@ class Losses:
 
     def __init__(self, beta_1=0.5, lambda_=1.0, targeted=False, target_class=None, margin=0.05, improve_loss=False, logits=False,
                  attack_type="flickering"):
-        if attack_type != "flickering":
-            raise NotImplementedError("L12 regulariser kernel is not built yet")
+        if attack_type not in ("flickering", "L12"):
+            raise ValueError(f"attack_type must be 'flickering' or 'L12' (model.py:165-168), got {attack_type!r}")
         if targeted and improve_loss:
             # model.py:223-225 references undefined names: the reference crashes here; refuse instead of guessing
             raise NotImplementedError("the reference's targeted improve-loss is non-functional (model.py:223-225)")
@@ -95,6 +110,13 @@ class Losses:
         laplacian_norm_reg = torch.mean((-2 * p + right + left) ** 2) + 1e-12
         return self.beta_1 * norm_reg + (1 - self.beta_1) * (diff_norm_reg + laplacian_norm_reg)
 
+    def L12_regularization_loss(self, perturbation):
+        """model.py:211-214 on the clamped perturbation [3,T,H,W]: value only (update passes take it from flk_perturb_dense_l12_adam)"""
+        return torch.sum(torch.sqrt(torch.mean(perturbation ** 2, [0, 2, 3]))) + 1e-12
+
+    def regularization_loss(self, perturbation):
+        return self.L12_regularization_loss(perturbation) if self.attack_type == "L12" else self.flickering_regularization_loss(perturbation)
+
 
 class Adversarial_metrics:
     """model.py:253-330"""
@@ -117,7 +139,7 @@ class FlickerVideoResNet:
     """Attack engine for torchvision-0.5.0 r2plus1d_18 / r3d_18 / mc3_18 (model.py:337-399,984-1205)."""
 
     def __init__(self, base_model, weights, batch_size=1, sample_length=16, image_size=112, dtype="bf16", device=0, l_inf_pert_norm=0.2,
-                 cyclic_pert=False, num_classes=400, process_group=None):
+                 cyclic_pert=False, num_classes=400, process_group=None, attack_type="flickering"):
         if base_model not in ARCH_CODES:
             raise ValueError(f"base_model must be one of {sorted(ARCH_CODES)} (model.py:47-56), got {base_model!r}")
         if not torch.cuda.is_available():
@@ -126,7 +148,12 @@ class FlickerVideoResNet:
         self.model_name, self.B, self.T, self.H, self.W, self.dtype = base_model, batch_size, sample_length, image_size, image_size, dtype
         self.pg, self.world = process_group, parallel.world_size(process_group)
         self.net = ops.Net(ARCH_CODES[base_model], dtype, self.B, self.T, self.H, self.W, weights, device)
-        self.pert_model = Perturbation((3, self.T, 1, 1), max_norm=l_inf_pert_norm, cyclic_pert=cyclic_pert)
+        if attack_type not in ("flickering", "L12"):
+            raise ValueError(f"attack_type must be 'flickering' or 'L12', got {attack_type!r}")
+        self.attack_type = attack_type
+        # model.py:380-384: [3,T,1,1] for the flickering attack, a dense [3,T,H,W] perturbation otherwise
+        self.pert_model = Perturbation((3, self.T, 1, 1) if attack_type == "flickering" else (3, self.T, self.H, self.W),
+                                       max_norm=l_inf_pert_norm, cyclic_pert=cyclic_pert)
         dev = torch.device("cuda", device)
         tdt = torch.bfloat16 if dtype in ("bf16", torch.bfloat16) else torch.float32
         self._xs = torch.empty((self.B, self.T, self.H // 2, self.W // 2, 16), dtype=tdt, device=dev)
@@ -135,8 +162,8 @@ class FlickerVideoResNet:
         self._red = torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev)
         self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4), dtype=torch.float32, device=dev)
         self._scalars = torch.empty(8, dtype=torch.float32, device=dev)
-        self.adam_m = torch.zeros(self.T, 3, device=dev)
-        self.adam_v = torch.zeros(self.T, 3, device=dev)
+        self.adam_m = torch.zeros(self.pert_model._dev_shape, device=dev)
+        self.adam_v = torch.zeros(self.pert_model._dev_shape, device=dev)
         self.adam_t = 0      # the reference keeps ONE Adam instance across videos: not reset by init_perturbation
 
     def _check_x(self, x):
@@ -155,6 +182,10 @@ class FlickerVideoResNet:
         The kernels write into one of ``RESULT_SLOTS`` result slots (valid for the next RESULT_SLOTS - 1 iterations);
         ``loss`` / ``argmax`` are derived on first access (i3d_engine.StepResult)."""
         from .i3d_engine import RESULT_SLOTS, StepResult
+        if criterion.attack_type != self.attack_type:
+            raise ValueError(f"criterion.attack_type {criterion.attack_type!r} != engine attack_type {self.attack_type!r}")
+        if self.attack_type == "L12":
+            return self._step_dense(x, labels, criterion, lr, update)
         a = self.pert_model.apply_args(self._check_x(x), True)
         if not hasattr(self, "_slots"):
             dev = self._logits.device
@@ -186,7 +217,35 @@ class FlickerVideoResNet:
                                  dyn_max_norm=self.pert_model.dynamic_max_norm, lr=lr, scalars=sc)
             res.update(reg_loss=sc[0], _reg_weight=criterion.lambda_, _thickness=sc[4], _roughness=sc[5])
         else:
-            res.update(reg_loss=criterion.flickering_regularization_loss(self.pert_model.get_perturbation()[0]), _reg_weight=criterion.lambda_)
+            res.update(reg_loss=criterion.regularization_loss(self.pert_model.get_perturbation()[0]), _reg_weight=criterion.lambda_)
+        return res
+
+    def _step_dense(self, x, labels, criterion, lr, update):
+        """the dense "L12" attack (model.py:211-214,380-384): loss = adv + lambda * L12(clamped delta); the data-parallel payload
+        is the dense gradient [T,H,W,3] (2.4 MB at 16 x 112 x 112)"""
+        from .i3d_engine import StepResult
+        a = self.pert_model.apply_args(self._check_x(x), True)
+        ops.perturb_apply_s2d(a, self.dtype, self._xs)
+        self.net.forward(self._xs, self._logits)
+        gbatch = self.B * self.world
+        sm, dl, pc = criterion.adv(labels, self._logits, gbatch)
+        self._dl = dl
+        self.net.backward(dl, self._gx)
+        if not hasattr(self, "_gdense"):
+            self._gdense = torch.empty_like(self.pert_model.perturbation)
+        ops.perturb_grad_reduce(a, self._gx, self._gdense)
+        tail = pc[:, :3].sum(0)
+        parallel.allreduce_sum_(self._gdense, self.pg)            # RCCL over xGMI: the dense gradient (2.4 MB at 16 x 112 x 112)
+        parallel.allreduce_sum_(tail, self.pg)
+        res = StepResult(adv_loss=tail[0].clone(), softmax=sm, label_prob=pc[:, 1], _argmax_f=pc[:, 3], _labels=labels,
+                         _targeted=bool(criterion.targeted), _reg_weight=criterion.lambda_)
+        if update:
+            self.adam_t += 1
+            sc = ops.perturb_dense_l12_adam(self._gdense, self.pert_model.perturbation, self.adam_m, self.adam_v, self.adam_t, dialect="torch",
+                                            beta=criterion.lambda_, lr=lr, dyn_max_norm=self.pert_model.dynamic_max_norm).clone()
+            res.update(reg_loss=sc[0], _thickness=sc[1], _roughness=sc[2])
+        else:
+            res.update(reg_loss=criterion.L12_regularization_loss(self.pert_model.get_perturbation()[0]))
         return res
 
     # ---- drivers around step(): VideoLearnerAdversarial's loops without the plotting ------------------------------------
@@ -299,7 +358,7 @@ class FlickerVideoResNet:
             elif dest and save_model:
                 os.makedirs(model_dir, exist_ok=True)
                 np.save(dest, None)
-            self.pert_model.init_perturbation(((rng.random((3, self.T, 1, 1), dtype=np.float32) * 2 - 1) * 0.005))
+            self.pert_model.init_perturbation(((rng.random(self.pert_model.size, dtype=np.float32) * 2 - 1) * 0.005))
             self.pert_model.dynamic_max_norm = self.pert_model.max_norm
             res = self.fit_single_video_attack(inputs, target, criterion, lr=lr, n_iter=n_iter, targeted_attack=targeted_attack,
                                                target_class_id=target_class_id, **kw)

@@ -65,3 +65,40 @@ def synthetic_clip(B, T=16, H=112, W=112, seed=1234):
     """normalised fp32 clip [B,T,H,W,3] channels-last ((u8/255 - mean)/std, dataset.py transforms)"""
     u8 = np.random.default_rng(seed).integers(0, 256, (B, T, H, W, 3)).astype(np.float32)
     return ((u8 / 255.0 - np.array(DEFAULT_MEAN, np.float32)) / np.array(DEFAULT_STD, np.float32)).astype(np.float32)
+
+
+def load_weights(path, arch=None):
+    """Victim weights for FlickerVideoResNet as ``{state_dict name: float32 ndarray}``.
+
+    ``.pth`` / ``.pt``: a torchvision ``state_dict`` as ``torch.save`` writes it -- what the reference obtains through
+    ``torchvision.models.video.<arch>(pretrained=True)`` (utils_cv/action_recognition/model.py:421; torchvision 0.5.0 files such as
+    ``r2plus1d_18-91a641e6.pth``) -- or a checkpoint dict holding one under ``state_dict`` / ``model``; a ``module.`` prefix
+    (``nn.DataParallel``, model.py:576-578) is stripped and ``num_batches_tracked`` counters are dropped.  ``.npz``: the same names.
+    With ``arch`` the names and shapes are checked against that architecture's layer table."""
+    if str(path).endswith(".npz"):
+        W = {k: np.asarray(v, dtype=np.float32) for k, v in np.load(path).items()}
+    else:
+        import torch
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        for key in ("state_dict", "model"):
+            if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict):
+                sd = sd[key]
+        W = {}
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked") or not hasattr(v, "numpy"):
+                continue
+            W[k[len("module."):] if k.startswith("module.") else k] = v.detach().to(torch.float32).numpy()
+    if arch is not None:
+        want = {}
+        for pre, co, ci, k, bnp in conv_table(arch):
+            want[pre + ".weight"] = (co, ci, *k)
+            for s in (".weight", ".bias", ".running_mean", ".running_var"):
+                want[bnp + s] = (co,)
+        want["fc.weight"], want["fc.bias"] = (W.get("fc.bias", np.zeros(400)).shape[0], 512), W.get("fc.bias", np.zeros(400)).shape
+        missing = sorted(set(want) - set(W))
+        if missing:
+            raise KeyError(f"{path}: not a {arch} state_dict, missing {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+        bad = [k for k, shp in want.items() if tuple(W[k].shape) != tuple(shp)]
+        if bad:
+            raise ValueError(f"{path}: shape mismatch for {arch}: {bad[0]} is {W[bad[0]].shape}, expected {want[bad[0]]}")
+    return W

@@ -198,6 +198,8 @@ typedef struct {
   float g_scale;
   float lr, adam_b1, adam_b2, adam_eps;
   int step;
+  float dyn_max_norm;        /* > 0 (torch dialect): L12 is taken on clamp(delta, +-dyn_max_norm), as Losses receives the CLAMPED
+                              * perturbation (model.py:1078,211-214); its gradient vanishes where |delta| > dyn_max_norm.  0: raw delta */
 } flk_dense_adam_args;
 int64_t flk_dense_adam_scratch_bytes(int T, int H, int W);
 int flk_perturb_dense_l12_adam(const flk_dense_adam_args* a, const float* g_adv, float* delta, float* m, float* v,

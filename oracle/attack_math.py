@@ -158,11 +158,13 @@ def is_adversarial(softmax, labels, targeted=False):
     return bool((am == labels).all()) if targeted else bool((am != labels).all())
 
 
-def fooling_counts(adv_logits, clean_logits, labels, targeted=False, target=None):
+def fooling_counts(adv_logits, clean_logits, labels, targeted=False, target=None, exclude_misclassify=True):
     """kinetics_i3d_utils.py:217-250 / model.py:293-323 -> (miss, valid)."""
     a, c = adv_logits.argmax(-1), clean_logits.argmax(-1)
-    valid = c == labels
     miss_cond = (a == target) if targeted else (a != labels)
+    if not exclude_misclassify:                                  # kinetics_i3d_utils.py:244-246
+        return int(miss_cond.sum()), int(miss_cond.numel())
+    valid = c == labels
     return int((miss_cond & valid).sum()), int(valid.sum())
 
 

@@ -51,13 +51,35 @@ def conv_unit(x, W, pre, kind, stride):
     return F.conv3d(y, W[pre + ".3.weight"], None, (stride, 1, 1), (1, 0, 0))
 
 
-def basic_block(x, W, pre, kind, stride, has_ds):
+def basic_block(x, W, pre, kind, stride, has_ds, final_relu=True):
+    """final_relu=False returns the pre-ReLU sum (where a d(loss)/d(pre-activation) gradient buffer lives; used by the link tests)"""
     out = F.relu(bn(conv_unit(x, W, pre + ".conv1.0", kind, stride), W, pre + ".conv1.1"))
     out = bn(conv_unit(out, W, pre + ".conv2.0", kind, 1), W, pre + ".conv2.1")
     res = x
     if has_ds:
         res = bn(F.conv3d(x, W[pre + ".downsample.0.weight"], None, ds_stride(kind, stride)), W, pre + ".downsample.1")
-    return F.relu(out + res)
+    return F.relu(out + res) if final_relu else out + res
+
+
+def stem(x, W, arch, final_relu=True):
+    """torchvision R2Plus1dStem / BasicStem"""
+    act = F.relu if final_relu else (lambda t: t)
+    if arch == "r2plus1d_18":
+        y = F.relu(bn(F.conv3d(x, W["stem.0.weight"], None, (1, 2, 2), (0, 3, 3)), W, "stem.1"))
+        return act(bn(F.conv3d(y, W["stem.3.weight"], None, 1, (1, 0, 0)), W, "stem.4"))
+    return act(bn(F.conv3d(x, W["stem.0.weight"], None, (1, 2, 2), (1, 3, 3)), W, "stem.1"))
+
+
+def blocks(arch):
+    """[(endpoint name, kind, stride, has_downsample)] in forward order"""
+    out, inpl = [], 64
+    for li, planes in enumerate(PLANES, start=1):
+        kind = conv_builder(arch, li)
+        for bi in range(2):
+            stride = 2 if (li > 1 and bi == 0) else 1
+            out.append((f"layer{li}.{bi}", kind, stride, stride != 1 or inpl != planes))
+            inpl = planes
+    return out
 
 
 def videoresnet_logits(x, W, arch="r2plus1d_18", return_endpoints=False):

@@ -6,7 +6,8 @@ i3d_adversarial_main_single_video_npy.py (same run_config.yml section, same resu
 
 Per clip (reference :115-337): clean prediction (skip if misclassified) -> delta, Adam re-initialised -> iterate until
 step > MAX_NUM_STEP and the clip is adversarial -> pickle {keys of config.RESULT_KEYS}.  One device pass per iteration
-(FlickerI3D.step) replaces the reference's four sess.run calls.  Weights: MODEL.WEIGHTS_NPZ ({variable name: array}); without
+(FlickerI3D.step) replaces the reference's four sess.run calls; past MAX_NUM_STEP the updated perturbation is verified with one extra
+forward before the loop stops, so the saved perturbation / adv_video / last softmax describe the same, checked-adversarial state.  Weights: MODEL.WEIGHTS_NPZ ({variable name: array}); without
 it seeded synthetic weights are used (the checkpoint is not distributed with the reference).
 """
 import argparse
@@ -33,28 +34,48 @@ def attack_clip(eng, x, label_id, c, max_steps, target_id=None, log_every=100):
     eng.reset_perturbation()
     beta3 = c.BETA_2                       # reference :98: beta_3 := BETA_2
     res = {k: [] for k in ("total_loss_l", "adv_loss_l", "reg_loss_l", "norm_reg_loss_l", "diff_norm_reg_loss_l", "perturbation", "softmax")}
-    step, last = 0, None
+    cyc = float(bool(c.CYCLIC_ATTACK))
+
+    def is_adv(sm):
+        am = int(sm.argmax())
+        return am == target_id if targeted else am != label_id
+
+    step, last, pending = 0, None, False
     while True:
+        # one device pass: scalars of the CURRENT delta (what the reference fetches together with train_op, :213-215), then the update
         r = eng.step(x, lab, lr=1e-3, beta0=c.LAMBDA, beta1=c.BETA_1, beta2=c.BETA_2, beta3=beta3, margin=c.PROB_MARGIN,
-                     targeted=targeted, use_logits=bool(c.USE_LOGITS), improve_loss=bool(c.IMPROVE_ADV_LOSS), cyclic=float(bool(c.CYCLIC_ATTACK)))
+                     targeted=targeted, use_logits=bool(c.USE_LOGITS), improve_loss=bool(c.IMPROVE_ADV_LOSS), cyclic=cyc)
         h = r.host()                       # one host sync per step, like the reference's fetches
+        # the reference's second sess.run (:217) evaluates is_adversarial / softmax AFTER the update: the forward of step k+1 is
+        # that evaluation for step k (same delta), so the softmax list is filled with one step of lag ...
+        if pending:
+            res["softmax"].append(h["softmax"].copy())
+        pending = True
         for k, src in (("total_loss_l", "total_loss"), ("adv_loss_l", "adv_loss"), ("reg_loss_l", "reg_loss"),
                        ("norm_reg_loss_l", "norm_reg"), ("diff_norm_reg_loss_l", "diff_norm_reg")):
             res[k].append(float(h[src]))
-        res["perturbation"].append(eng.perturbation.cpu().numpy().copy())
-        res["softmax"].append(h["softmax"].copy())
+        res["perturbation"].append(eng.perturbation.cpu().numpy().copy())      # sess.run(perturbation) after the update, :305
         last = h
         step += 1
         if log_every and step % log_every == 0:
             print(f"  step {step}: total {h['total_loss']:.5f} adv {h['adv_loss']:.5f} thick {h['thickness_relative']:.3f}% "
-                  f"rough {h['roughness_relative']:.3f}% adversarial {bool(h['is_adversarial'])}", flush=True)
-        if step > max_steps and bool(h["is_adversarial"]):
-            break
-        if step > 20 * max_steps + 100:     # the reference loops forever on a robust clip; bound it
-            print("  giving up: not adversarial", flush=True)
-            break
+                  f"rough {h['roughness_relative']:.3f}% adversarial (before this update) {bool(h['is_adversarial'])}", flush=True)
+        give_up = step > 20 * max_steps + 100       # the reference loops forever on a robust clip; bound it
+        if step > max_steps or give_up:
+            # ... and past MAX_NUM_STEP the updated delta is verified with its own forward before the loop may stop (:313): the
+            # perturbation that is saved is the one that was checked
+            sm = eng(x, adv_flag=1, cyclic=cyc)[0].cpu().numpy()
+            res["softmax"].append(sm)
+            pending = False
+            if is_adv(sm):
+                break
+            if give_up:
+                print("  giving up: not adversarial", flush=True)
+                break
+    # thickness / roughness of the SAVED (verified) perturbation, kinetics_i3d_utils.py:196-200 on the raw variable
+    d = res["perturbation"][-1].astype(np.float64)
     res.update(correct_cls_prob=float(clean[label_id]), softmax_init=clean.cpu().numpy(), total_steps=step,
-               fatness=float(last["thickness_relative"]), smoothness=float(last["roughness_relative"]),
+               fatness=float(np.abs(d).mean() / 2 * 100), smoothness=float(np.abs(d - np.roll(d, 1, 0)).mean() / 2 * 100),
                adv_video=None, beta_0=c.LAMBDA, beta_1=c.BETA_1, beta_2=c.BETA_2, beta_3=beta3)
     return res
 

@@ -31,7 +31,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--videos-npz", required=True)
     ap.add_argument("--label-map", default="")
-    ap.add_argument("--weights-npz", default="")
+    ap.add_argument("--weights-npz", "--weights", dest="weights_npz", default="",
+                    help="victim weights: a torchvision state_dict (.pth / .pt, what model.py:421 downloads) or an .npz of the same names; "
+                         "'' = seeded synthetic weights")
+    ap.add_argument("--attack-type", default=ATTACK_TYPE, choices=["flickering", "L12"], help="L12: dense [3,T,H,W] perturbation (model.py:380-384)")
     ap.add_argument("--results-root", default=os.path.join(os.getcwd(), "results"))
     ap.add_argument("--base-model", default=BASE_MODEL)
     ap.add_argument("--n-iter", type=int, default=N_ITER)
@@ -45,12 +48,12 @@ def main():
         clips = (clips.astype(np.float32) / 255.0 - np.array(vs.DEFAULT_MEAN, np.float32)) / np.array(vs.DEFAULT_STD, np.float32)
     clips = np.ascontiguousarray(clips, dtype=np.float32)
     classes = [l.strip() for l in open(a.label_map)] if a.label_map else None
-    W = dict(np.load(a.weights_npz)) if a.weights_npz else vs.synthetic_weights(a.base_model, 42)
+    W = vs.load_weights(a.weights_npz) if a.weights_npz else vs.synthetic_weights(a.base_model, 42)
     learner = FlickerVideoResNet(a.base_model, W, batch_size=1, sample_length=clips.shape[1], image_size=clips.shape[2], dtype=a.dtype,
-                                 l_inf_pert_norm=L_INF_PERT_NORM, cyclic_pert=CYCLIC_PERT)
-    dest = os.path.join(a.results_root, learner.model_name, "single_video_attack", ATTACK_TYPE,
+                                 l_inf_pert_norm=L_INF_PERT_NORM, cyclic_pert=CYCLIC_PERT, attack_type=a.attack_type)
+    dest = os.path.join(a.results_root, learner.model_name, "single_video_attack", a.attack_type,
                         f"linf_{L_INF_PERT_NORM}_lambda_{LAMBDA}_beta1_{BETA_1}_")
-    crit = Losses(beta_1=BETA_1, lambda_=LAMBDA, targeted=TARGETED_ATTACK, improve_loss=IMPROVE_LOSS, logits=USE_LOGITS, attack_type=ATTACK_TYPE)
+    crit = Losses(beta_1=BETA_1, lambda_=LAMBDA, targeted=TARGETED_ATTACK, improve_loss=IMPROVE_LOSS, logits=USE_LOGITS, attack_type=a.attack_type)
     videos = ((torch.from_numpy(clips[i:i + 1]).cuda(), torch.from_numpy(labels[i:i + 1]).cuda(), names[i]) for i in range(len(clips)))
     out = learner.fit_many_videos(videos, crit, lr=LR, model_dir=dest, label_id_to_text=classes, n_iter=a.n_iter, restart_after=a.restart_after)
     for name, r in out.items():

@@ -58,7 +58,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--train-npz", required=True)
     ap.add_argument("--val-npz", required=True)
-    ap.add_argument("--weights-npz", default="")
+    ap.add_argument("--weights-npz", "--weights", dest="weights_npz", default="",
+                    help="victim weights: a torchvision state_dict (.pth / .pt, what model.py:421 downloads) or an .npz of the same names; "
+                         "'' = seeded synthetic weights")
+    ap.add_argument("--attack-type", default=ATTACK_TYPE, choices=["flickering", "L12"], help="L12: dense [3,T,H,W] perturbation (model.py:380-384)")
     ap.add_argument("--results-root", default=os.path.join(os.getcwd(), "results"))
     ap.add_argument("--base-model", default=BASE_MODEL)
     ap.add_argument("--epochs", type=int, default=EPOCHS)
@@ -76,10 +79,10 @@ def main():
     xtr, ytr = load_clips(a.train_npz)
     xva, yva = load_clips(a.val_npz)
     T, HW = xtr.shape[1], xtr.shape[2]
-    W = dict(np.load(a.weights_npz)) if a.weights_npz else vs.synthetic_weights(a.base_model, 42)
+    W = vs.load_weights(a.weights_npz) if a.weights_npz else vs.synthetic_weights(a.base_model, 42)
     learner = FlickerVideoResNet(a.base_model, W, batch_size=a.batch_size, sample_length=T, image_size=HW, dtype=a.dtype,
-                                 device=local_rank, l_inf_pert_norm=L_INF_PERT_NORM, cyclic_pert=CYCLIC_PERT)
-    dest = os.path.join(a.results_root, learner.model_name, "generalization", "universal", "val_test", f"all_cls_shuffle_{ATTACK_TYPE}",
+                                 device=local_rank, l_inf_pert_norm=L_INF_PERT_NORM, cyclic_pert=CYCLIC_PERT, attack_type=a.attack_type)
+    dest = os.path.join(a.results_root, learner.model_name, "generalization", "universal", "val_test", f"all_cls_shuffle_{a.attack_type}",
                         f"t_{len(xtr)}_v_{len(xva)}_linf_{L_INF_PERT_NORM}_lambda_{LAMBDA}_beta1_{BETA_1}_")
     start_epoch = 1
     ckpts = sorted(glob.glob(os.path.join(dest, "*.npy")), key=os.path.getmtime)
@@ -89,7 +92,7 @@ def main():
     if CONTINUE_TRAIN and ckpts:                  # :210-219
         start_epoch = int(ckpts[-1].split("_")[-1].split(".")[0]) + 1
         print(f"Success! to continue from last epoch. init with {start_epoch}")
-    crit = Losses(beta_1=BETA_1, lambda_=LAMBDA, targeted=TARGETED_ATTACK, improve_loss=IMPROVE_LOSS, logits=USE_LOGITS, attack_type=ATTACK_TYPE)
+    crit = Losses(beta_1=BETA_1, lambda_=LAMBDA, targeted=TARGETED_ATTACK, improve_loss=IMPROVE_LOSS, logits=USE_LOGITS, attack_type=a.attack_type)
 
     class Loaders(dict):                          # fresh iterators every epoch
         def __getitem__(self, phase):

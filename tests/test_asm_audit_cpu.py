@@ -1,6 +1,11 @@
 """The conv kernel issues asynchronous loads from inline asm (direct-A / mode-3 K loops).  hipcc does not know those loads
 are in flight; tools/audit_asm_loads.py proves on the compiled assembly that no compiler-generated instruction touches
-a destination register between the load and the hand-counted wait that releases it."""
+a destination register between the load and the hand-counted wait that releases it.
+
+Three checks: the product kernels pass; the audit FLAGS a minimal hazard fixture; and it FLAGS the pre-fix form of the product
+K loops that is consistent with the round-1 GPU faults (fault post-mortem): without the `s_waitcnt vmcnt(0)` drain behind
+the K loop the last queue refills are still in flight when the epilogue starts, hipcc considers their destination registers dead
+and builds the epilogue's store addresses in them -- a late-landing load then overwrites a pointer (memory access fault)."""
 import os
 import shutil
 import subprocess
@@ -9,11 +14,42 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AUDIT = os.path.join(ROOT, "tools", "audit_asm_loads.py")
+SRC = os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_igemm.hip")
+pytestmark = pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="hipcc not available")
+
+
+def _audit(path):
+    return subprocess.run([sys.executable, AUDIT, path], capture_output=True, text=True, timeout=900)
 
 
 def test_no_compiler_access_to_in_flight_registers():
-    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
-        pytest.skip("hipcc not available")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "audit_asm_loads.py")], capture_output=True, text=True, timeout=900)
+    r = _audit(SRC)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "kernels with asm loads audited, 0 with violations" in r.stdout and " 0 kernels" not in r.stdout
+
+
+def test_audit_flags_a_minimal_hazard():
+    """tests/fixtures/asm_inflight_fixture.hip: one kernel that touches the destination only behind its wait (must pass), one that
+    lets hipcc copy the register while the load is in flight (must be flagged) -- the audit is not vacuous"""
+    r = _audit(os.path.join(ROOT, "tests", "fixtures", "asm_inflight_fixture.hip"))
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "conv_igemm_kernel_fixture_ok: 1 asm loads, 0 violation(s)" in r.stdout
+    assert "conv_igemm_kernel_fixture_bad: 1 asm loads, 2 violation(s)" in r.stdout and "touches in-flight" in r.stdout
+    assert "2 kernels with asm loads audited, 1 with violations" in r.stdout
+
+
+def test_audit_flags_the_pre_fix_k_loops(tmp_path):
+    """the product source with the two post-loop drains removed (the state the faulting development builds were in)"""
+    s = open(SRC).read()
+    drains = ['    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the queue\'s tail before the wave may end\n',
+              '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n  } else {']
+    assert all(s.count(d) == 1 for d in drains), "conv_igemm.hip changed: update the fixture's patch"
+    s = s.replace(drains[0], "").replace(drains[1], "  } else {")
+    p = tmp_path / "conv_igemm_nodrain.hip"
+    p.write_text(s)
+    r = _audit(str(p))
+    assert r.returncode == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    # the violations are epilogue address arithmetic built in queue registers whose tail loads have not landed
+    assert "touches in-flight" in r.stdout and "v_lshl_add_u64" in r.stdout
+    assert "30 kernels with asm loads audited, 30 with violations" in r.stdout or "with violations" in r.stdout

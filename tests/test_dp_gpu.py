@@ -81,3 +81,137 @@ def test_two_ranks_equal_one_process_with_the_global_batch():
         np.testing.assert_allclose(deltas[-1], ref_delta[-1], rtol=0, atol=0.15 * np.abs(ref_delta[-1]).max())
     for d0, d1 in zip(got[0][1], got[1][1]):
         np.testing.assert_array_equal(d0, d1)                          # replicas stay bitwise identical
+
+
+def _rccl_worker(port, q):
+    """one rank, backend "nccl" (= RCCL): with FLK_FORCE_COLLECTIVE=1 the engine issues its real all-reduce calls (identity in a
+    1-rank group) -- the flicker payload (T*3+3 floats), the dense gradient (38.5 MB at T = 64) and the fooling counters"""
+    import torch.distributed as dist
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    W = i3d_spec.synthetic_i3d_weights(42)
+    out = {}
+
+    def run(tag):
+        x = torch.from_numpy(i3d_spec.synthetic_clip_u8(1, 64, seed=5)).cuda()
+        eng = FlickerI3D(W, batch_size=1, frames=64, dtype="bf16")
+        labels = eng.logits(x, adv_flag=0.0).argmax(-1).clone()
+        for _ in range(2):
+            r = eng.step(x, labels, **HP)
+        out[tag + "flicker"] = (eng.perturbation.cpu().numpy().copy(), float(r["adv_loss"]))
+        out[tag + "eval"] = eng.evaluate([(x, labels)])
+        del eng
+        eng = FlickerI3D(W, batch_size=1, frames=64, dtype="bf16", dense_delta=True)
+        for _ in range(2):
+            r = eng.step(x, labels, lr=1e-3, beta1=0.5)
+        out[tag + "dense"] = (eng.perturbation[::16, ::37, ::41].cpu().numpy().copy(), float(r["adv_loss"]), float(eng._gdense.numel() * 4 / 1e6))
+        del eng
+        torch.cuda.empty_cache()
+
+    try:
+        run("plain:")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        os.environ["FLK_FORCE_COLLECTIVE"] = "1"
+        try:
+            run("rccl:")
+            out["backend"] = dist.get_backend()
+        finally:
+            dist.destroy_process_group()
+        q.put(out)
+    except Exception as e:      # noqa: BLE001 -- report instead of hanging the parent on q.get
+        q.put({"error": repr(e)})
+
+
+def test_rccl_collectives_execute_world_size_one():
+    """RCCL had never run (SCALE / MULTICHIP of round 1 were skipped): execute the engine's collectives through backend "nccl" on the
+    test GPU.  A 1-rank all-reduce is the identity, so results must be bitwise those of the run without a process group."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    out = q.get(timeout=900)
+    p.join(timeout=120)
+    assert "error" not in out, out["error"]
+    assert p.exitcode == 0 and out["backend"] == "nccl"
+    for k in ("flicker", "dense"):
+        np.testing.assert_array_equal(out["plain:" + k][0], out["rccl:" + k][0])
+        assert out["plain:" + k][1] == out["rccl:" + k][1]
+    assert out["rccl:dense"][2] == pytest.approx(38.535168)                # the dense all-reduce payload in MB (SURVEY 8(d))
+    assert out["plain:eval"] == out["rccl:eval"]
+
+
+def _dense_worker(rk, world, port, labels, q):
+    import torch.distributed as dist
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rk, world_size=world)
+    try:
+        W, x = _data()
+        eng = FlickerI3D(W, batch_size=1, frames=T, dtype="f32", device=0, dense_delta=True)
+        r = eng.step(x[rk:rk + 1].cuda(), labels[rk:rk + 1].cuda(), lr=1e-3, beta0=1.0, beta1=0.5)
+        q.put((rk, eng._gdense.cpu().numpy().copy(), eng.perturbation.cpu().numpy().copy(), float(r["adv_loss"]), float(r["L12"])))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dense_delta_two_ranks_equal_one_process():
+    """_step_dense data-parallel: the all-reduce payload is the dense gradient [T,224,224,3]; two ranks x one clip must equal one
+    process x two clips (first step: the same delta everywhere, so the comparison sits above the ReLU-flip noise floor)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, x = _data()
+    eng = FlickerI3D(W, batch_size=2, frames=T, dtype="f32", device=0, dense_delta=True)
+    labels = eng.logits(x.cuda(), adv_flag=0.0).argmax(-1).cpu()
+    r = eng.step(x.cuda(), labels.cuda(), lr=1e-3, beta0=1.0, beta1=0.5)
+    ref = (eng._gdense.cpu().numpy().copy(), eng.perturbation.cpu().numpy().copy(), float(r["adv_loss"]), float(r["L12"]))
+    del eng
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dense_worker, args=(rk, 2, port, labels, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    got = {rk: rest for rk, *rest in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rk in range(2):
+        g, d, adv, l12 = got[rk]
+        np.testing.assert_allclose(g, ref[0], rtol=1e-4, atol=1e-5 * np.abs(ref[0]).max())
+        assert adv == pytest.approx(ref[2], rel=1e-5) and l12 == pytest.approx(ref[3], rel=1e-6)
+        # first Adam step = lr * sign(g): identical wherever the gradient is not within rounding of zero
+        big = np.abs(ref[0]) > 1e-3 * np.abs(ref[0]).max()
+        np.testing.assert_allclose(d[big], ref[1][big], rtol=1e-4, atol=1e-9)
+    np.testing.assert_array_equal(got[0][1], got[1][1])                    # replicas stay bitwise identical
+
+
+def test_bench_two_ranks_rehearsal():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the one test GPU
+    with FLK_DIST_BACKEND=gloo: the roofline leg runs on EVERY rank (its steps end in the all-reduce), rank 0 prints one JSON line."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, FLK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+           "--frames", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 2 and out["value"] > 0
+    assert out["roofline"]["frac"] > 0 and out["config"]["parallelism"] == "dp2"

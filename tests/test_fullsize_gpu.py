@@ -105,3 +105,46 @@ def test_bf16_iteration_is_bitwise_reproducible(env):
         del e
     for a_, b_ in zip(*outs):
         assert torch.equal(a_, b_)
+
+
+def test_bf16_attack_level_equivalence(env):
+    """The benchmarked dtype against the parity dtype AS AN ATTACK, at the benchmark size (bs 8, 64 x 224 x 224, one shared delta,
+    run_config.yml hyper-parameters): the same 8 clips through the fp32 and the bf16 engine for 450 iterations.  On the random-sign
+    synthetic network individual trajectories decorrelate (tests/test_i3d_gpu.py docstring), so what is compared is what an attack
+    delivers: the iteration at which every clip is fooled, the adversarial-loss curve and the final thickness / roughness.
+    Stated bands: iterations-to-fool within 15 %, loss curve within 20 % (+0.05 absolute) at every 25th iteration, final
+    thickness / roughness within 10 % relative."""
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, x = env
+    N, every = 450, 25
+    curves = {}
+    for dt in ("f32", "bf16"):
+        eng = FlickerI3D(W, batch_size=B, frames=T, dtype=dt)
+        labels = eng.logits(x, adv_flag=0.0).argmax(-1).clone()
+        if dt == "f32":
+            labels32 = labels.clone()
+        else:
+            assert torch.equal(labels, labels32), "clean predictions differ between fp32 and bf16"
+        rows, fooled_all_at, kept = [], None, []
+        for it in range(1, N + 1):
+            r = eng.step(x, labels, **HP)
+            if it % every == 0 or it == N:
+                kept.append((it, r["adv_loss"].clone(), r["thickness_relative"].clone(), r["roughness_relative"].clone(),
+                             (r["argmax"] != labels).clone()))
+        for it, adv, th, ro, fooled in kept:
+            rows.append((it, float(adv), float(th), float(ro), int(fooled.sum())))
+            if fooled_all_at is None and int(fooled.sum()) == B:
+                fooled_all_at = it
+        curves[dt] = (rows, fooled_all_at)
+        del eng
+        torch.cuda.empty_cache()
+    (r32, f32_at), (r16, f16_at) = curves["f32"], curves["bf16"]
+    for a, b in zip(r32, r16):
+        print(f"iter {a[0]:4d}: adv f32 {a[1]:.4f} bf16 {b[1]:.4f} | thickness {a[2]:.3f}% / {b[2]:.3f}% | roughness {a[3]:.3f}% / {b[3]:.3f}% | "
+              f"clips fooled {a[4]} / {b[4]}")
+    print(f"all {B} clips fooled at iteration: f32 {f32_at}, bf16 {f16_at}")
+    assert f32_at is not None and f16_at is not None
+    assert abs(f16_at - f32_at) <= max(every, 0.15 * f32_at)
+    for a, b in zip(r32, r16):
+        assert b[1] == pytest.approx(a[1], rel=0.20, abs=0.05), f"adversarial loss at iteration {a[0]}"
+    assert r16[-1][2] == pytest.approx(r32[-1][2], rel=0.10) and r16[-1][3] == pytest.approx(r32[-1][3], rel=0.10)

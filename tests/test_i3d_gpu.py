@@ -3,17 +3,21 @@
 
 north-star bar: logits, adversarial loss and learned delta within 1e-3 relative (fp32 mode).
 
-How the bar is applied.  Logits, softmax and the adversarial loss are smooth in the inputs and are
-asserted at 1e-3 against the fp32 CPU oracle (measured ~1e-6).  Gradient-derived quantities pass through
-~10^7 ReLU / max-pool decisions: an activation within fp32 rounding of zero takes a different mask under a
-different (equally valid) fp32 summation order, and d(loss)/d(delta) is a random-sign sum in which each
-flipped unit contributes fully.  The torch-CPU fp32 oracle ITSELF therefore reproduces the fp64 oracle's
-delta-gradient only to ~6e-3 on this synthetic noise clip (asserted below), and Adam -- which normalises
-every component by its own magnitude -- amplifies that on the small components of delta.  Ground truth for
-gradients and the delta trajectory is hence the fp64 oracle, and the HIP fp32 path must be as close to it as
-the fp32 CPU oracle is (factor 3 + 5e-3 slack: WHICH units flip differs between any two fp32 implementations,
-e.g. between the oneDNN builds of two hosts).  bf16 mode (performance mode: bf16 storage + bf16
-MFMA, fp32 accumulate) is checked at the looser, stated tolerances and its measured error is printed."""
+How the bar is applied.
+* Smooth quantities (every forward endpoint, logits, softmax, adversarial loss) are asserted at 1e-3 against the fp32 CPU oracle
+  on every fixture (measured ~1e-6).
+* The learned delta is asserted at 1e-3 against the fp64 oracle trajectory on the WELL-CONDITIONED fixture
+  (oracle/fixtures.py: same topology and kernels, non-negative weights -> no cancellation in the gradient sums; the torch-CPU
+  fp32 oracle itself reproduces the fp64 delta to ~3e-6 there): test_attack_trajectory_well_conditioned.
+* On the random-sign ("noise") fixture two fp32 implementations of the same forward pass disagree on ~10-30 of the ~3e7 ReLU /
+  max-pool decisions of a 16-frame clip, and ONE flipped unit in a 4e5-unit layer moves d(loss)/d(delta) by ~1/sqrt(N) = 1e-3
+  (measured: one flip in Mixed_4e between torch-CPU fp32 and fp64 leaves rel-L2 6e-3 in every gradient buffer below it).  The
+  backward pass is therefore checked LINK BY LINK (test_forward_backward_vs_oracle): the HIP gradient of each endpoint is pushed
+  through the oracle's backward of just the next block and compared with the HIP gradient of the endpoint below -- at 1e-3 of
+  the buffer's maximum for all but a counted few elements (the neighbourhoods of flipped decisions).  A wiring / indexing /
+  mask bug in any block shows up as an O(1) error of that link; accumulated flips do not.
+* bf16 mode (bf16 storage + bf16 MFMA, fp32 accumulate) goes through the same links against a like-for-like oracle (weights,
+  activations and gradients rounded to bf16 where the HIP path stores bf16) at the stated bf16 tolerances."""
 import numpy as np
 import pytest
 import torch
@@ -36,6 +40,58 @@ def rel_err(a, b):
 
 def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-300))
+
+
+class _RoundBF16(torch.autograd.Function):
+    """bf16 storage of an activation (forward) and of its gradient buffer (backward), as the HIP bf16 mode does"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def oracle_links(W, bf16):
+    """[(endpoint name, fn(previous endpoint NCDHW fp64, final_relu) -> this endpoint)] following i3d.py:144-455.  With
+    final_relu=False the block's OUTPUT units skip their ReLU: the HIP gradient buffers hold d(loss)/d(pre-ReLU output), so the
+    backward of a link starts exactly there.  In bf16 mode weights are bf16-rounded and every stored activation / gradient is
+    rounded to bf16 (like-for-like with the HIP bf16 path)."""
+    rnd = _RoundBF16.apply if bf16 else (lambda t: t)
+    Wd = {k: (torch.from_numpy(v).to(torch.bfloat16).double() if (bf16 and k.endswith("/w") and "Logits" not in k) else torch.from_numpy(v).double())
+          for k, v in W.items()}
+
+    def u(x, name, k, s=(1, 1, 1), relu=True):
+        y = i3d_ref.unit3d(x, Wd, name, k, s, relu=relu)
+        return rnd(y) if relu else y
+
+    def mixed(x, n, fr):
+        b0 = u(x, n + "/Branch_0/Conv3d_0a_1x1", (1, 1, 1), relu=fr)
+        b1 = u(u(x, n + "/Branch_1/Conv3d_0a_1x1", (1, 1, 1)), n + "/Branch_1/Conv3d_0b_3x3", (3, 3, 3), relu=fr)
+        b2 = u(u(x, n + "/Branch_2/Conv3d_0a_1x1", (1, 1, 1)), n + "/Branch_2/" + i3d_ref.b2_3x3_name(n), (3, 3, 3), relu=fr)
+        b3 = u(rnd(i3d_ref.maxpool_same(x, (3, 3, 3), (1, 1, 1))), n + "/Branch_3/Conv3d_0b_1x1", (1, 1, 1), relu=fr)
+        return torch.cat([b0, b1, b2, b3], 1)
+
+    links = [("Conv3d_1a_7x7", lambda x, fr: u(rnd(x), "Conv3d_1a_7x7", (7, 7, 7), (2, 2, 2), relu=fr)),
+             ("MaxPool3d_2a_3x3", lambda x, fr: i3d_ref.maxpool_same(x, (1, 3, 3), (1, 2, 2))),
+             ("Conv3d_2b_1x1", lambda x, fr: u(x, "Conv3d_2b_1x1", (1, 1, 1), relu=fr)),
+             ("Conv3d_2c_3x3", lambda x, fr: u(x, "Conv3d_2c_3x3", (3, 3, 3), relu=fr)),
+             ("MaxPool3d_3a_3x3", lambda x, fr: i3d_ref.maxpool_same(x, (1, 3, 3), (1, 2, 2)))]
+    for name, spec in i3d_ref.MIXED:
+        links.append((name, (lambda x, fr, sp=spec: i3d_ref.maxpool_same(x, *sp)) if name.startswith("MaxPool") else (lambda x, fr, n=name: mixed(x, n, fr))))
+
+    def head(x, fr):
+        x = torch.nn.functional.avg_pool3d(x, (2, 7, 7), (1, 1, 1))
+        return i3d_ref.unit3d(x, Wd, "Logits/Conv3d_0c_1x1", (1, 1, 1), bn=False, relu=False, bias=True).squeeze(4).squeeze(3).mean(2)
+    links.append(("Logits", head))
+    return links
+
+
+def outlier_frac(got, ref, tol):
+    """fraction of elements further than tol * max|ref| from ref"""
+    return float(((got.double() - ref.double()).abs() > tol * ref.double().abs().max()).double().mean())
 
 
 def oracle_pass(Wt, xu, delta, dt):
@@ -64,7 +120,7 @@ def oracle_trajectory(Wt, xu, dt, steps):
         total, reg = am.tf_total_loss(adv, dv, *BETAS)
         (g,) = torch.autograd.grad(total, dv)
         d, m, v = am.tf_adam_step(d, g, m, v, it)
-        out.append(dict(adv=adv.item(), total=total.item(), to_min=to_min.item(), softmax=torch.softmax(lg.detach(), -1), delta=d.clone()))
+        out.append(dict(adv=adv.item(), total=total.item(), to_min=to_min.item(), softmax=torch.softmax(lg.detach(), -1), logits=lg.detach(), delta=d.clone()))
     return label, out
 
 
@@ -103,28 +159,52 @@ def test_forward_backward_vs_oracle(setup, dtype):
     assert e < (1e-3 if f32 else 5e-2)
     sm, dl, pc = ops.softmax_adv_loss(logits, r32["label"].cuda(), dialect="tf", improve_loss=True, margin=0.05)
     assert pc[0, 0].item() == pytest.approx(r32["loss"], rel=1e-3 if f32 else 5e-2, abs=1e-6)
-    # ---- backward: gradient buffers hold d(loss)/d(pre-ReLU) = d(loss)/d(endpoint) masked by endpoint > 0 ----
+    # ---- backward, link by link.  Gradient buffers hold d(loss)/d(pre-ReLU output) = d(loss)/d(endpoint) masked by endpoint > 0
+    # (max-pool endpoints: unmasked).  For every link the oracle block is evaluated on the HIP path's OWN input endpoint and its
+    # backward is fed the HIP path's OWN output gradient: what is compared is this block's arithmetic alone. ----
     gx = net.backward(dl)
-    for name in reversed(GRAD_ENDPOINTS):
-        def masked(r):
-            g = r["ge"][name].permute(0, 2, 3, 4, 1)
-            return g if name.startswith("MaxPool") else torch.where(r["ep"][name].permute(0, 2, 3, 4, 1) > 0, g, torch.zeros_like(g))
-        got = torch.from_numpy(net.activation("grad:" + name))
-        truth = masked(r64)
-        e_hip, e_cpu = rel_l2(got, truth), rel_l2(masked(r32), truth)
-        print(f"[{dtype}] grad:{name}: rel-L2 vs fp64 oracle: HIP {e_hip:.3e}  (fp32 CPU oracle {e_cpu:.3e})")
-        # isolated ReLU-mask flips (see module docstring) perturb a whole neighbourhood in the small top layers;
-        # a wiring / indexing bug gives O(1).  Exact per-op backward parity is asserted in test_kernels_gpu.py.
-        assert e_hip < (max(3 * e_cpu, 0.1) if f32 else 0.9), "grad:" + name
-    g = ops.perturb_grad_reduce(args, gx.view(1, T // 2, 112, 112, 32)).cpu().reshape(r64["g"].shape)
+    bf = not f32
+    # tolerances: element error relative to the buffer maximum; allowed fraction of elements beyond it (flipped-decision neighbourhoods)
+    FWD_TOL, BWD_TOL, BWD_FRAC, BWD_L2 = (1e-4, 1e-3, 1e-3, 1e-2) if f32 else (1.6e-2, 3e-2, 2e-2, 3e-2)
+    hip_act = lambda n: torch.from_numpy(net.activation(n)).permute(0, 4, 1, 2, 3).contiguous().double()
+    d0 = delta.double().clone().requires_grad_(True)
+    prev_name, prev = "delta", am.tf_apply(xu.double() / 128 - 1, d0).permute(0, 4, 1, 2, 3).contiguous()
+    worst = {}
+    for name, fn in oracle_links(W, bf):
+        with torch.no_grad():
+            out = fn(prev, True)              # forward value of the endpoint (with its ReLU)
+        pre = fn(prev, False)                 # the same block up to the pre-ReLU output: where the HIP gradient buffer lives
+        if name == "Logits":
+            got_f, got_g = logits.cpu().double(), dl.cpu().double()
+        else:
+            got_f, got_g = hip_act(name), hip_act("grad:" + name)
+        e_f = rel_err(out.detach(), got_f)
+        assert e_f < FWD_TOL, f"forward link {prev_name} -> {name}: {e_f:.3e}"
+        if prev_name == "delta":
+            (g_ref,) = torch.autograd.grad(pre, d0, grad_outputs=got_g)
+            g_hip = ops.perturb_grad_reduce(args, gx.view(1, T // 2, 112, 112, 32)).cpu().reshape(g_ref.shape).double()
+            g_link = g_hip
+            e_l2, frac = rel_l2(g_hip, g_ref), outlier_frac(g_hip, g_ref, BWD_TOL)
+            assert rel_err(g_hip, g_ref) < (1e-3 if f32 else 2e-2), f"d(loss)/d(delta) link: {rel_err(g_hip, g_ref):.3e}"
+        else:
+            (g_ref,) = torch.autograd.grad(pre, prev, grad_outputs=got_g)
+            if not prev_name.startswith("MaxPool"):
+                g_ref = torch.where(prev > 0, g_ref, torch.zeros_like(g_ref))
+            g_hip = hip_act("grad:" + prev_name)
+            e_l2, frac = rel_l2(g_hip, g_ref), outlier_frac(g_hip, g_ref, BWD_TOL)
+        worst[name] = (e_f, e_l2, frac)
+        print(f"[{dtype}] link {prev_name:>17s} -> {name:<17s} fwd max-rel {e_f:.2e} | bwd rel-L2 {e_l2:.2e}, elements beyond {BWD_TOL:g} of max: {frac:.2e}")
+        assert frac <= BWD_FRAC and e_l2 < BWD_L2, f"backward link {name} -> {prev_name}: rel-L2 {e_l2:.3e}, outliers {frac:.3e}"
+        # next link starts from the HIP path's own endpoint (like-for-like; an upstream flip cannot leak into the next comparison)
+        prev_name = name
+        if name != "Logits":
+            prev = hip_act(name).requires_grad_(True)
+    # ---- end to end against the fp64 oracle (information + sanity): direction of d(adv)/d(delta), clipped entries ----
+    g = g_link.reshape(r64["g"].shape)
     e_hip, e_cpu = rel_err(g, r64["g"]), rel_err(r32["g"], r64["g"])
     cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), r64["g"].flatten(), 0))
-    print(f"[{dtype}] d(adv)/d(delta) vs fp64 oracle: HIP max-rel {e_hip:.3e} (fp32 CPU oracle {e_cpu:.3e}); cosine {cos:.6f}")
-    assert e_cpu < 2e-2                      # the documented fp32 noise floor of the reference maths itself
-    if f32:
-        assert e_hip < 3 * e_cpu + 5e-3 and cos > 0.999
-    else:
-        assert cos > 0.85
+    print(f"[{dtype}] d(adv)/d(delta) end to end vs fp64 oracle: HIP max-rel {e_hip:.3e} (fp32 CPU oracle {e_cpu:.3e}); cosine {cos:.6f}")
+    assert cos > (0.999 if f32 else 0.85)
     assert g[3].abs().max() == 0             # clipped delta entries get no gradient (kinetics_i3d_utils.py:104)
 
 
@@ -150,6 +230,150 @@ def test_attack_trajectory_vs_oracle(setup):
         assert res["prob_to_min"] == pytest.approx(t64[it]["to_min"], rel=1e-3)
         torch.testing.assert_close(torch.from_numpy(res["softmax"]).double(), t64[it]["softmax"], rtol=2e-3, atol=1e-6)
         assert e_hip < 3 * e_cpu + 5e-3
+
+
+def _coherent_fixture():
+    from flickering_adversarial_video_amd import i3d_spec
+    from oracle import fixtures
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(1, T, seed=1234))
+    W = fixtures.coherent_i3d_weights(xu, seed=5, label=233)
+    Wt = {dt: {k: torch.from_numpy(v).to(dt) for k, v in W.items()} for dt in (torch.float32, torch.float64)}
+    return W, Wt, xu
+
+
+def test_attack_trajectory_well_conditioned():
+    """THE north-star assertion: logits (softmax), adversarial loss and the LEARNED DELTA of the fp32 mode within 1e-3 of the
+    reference maths (fp64 oracle) over 6 iterations of the single-video loop (i3d_adversarial_main_single_video_npy.py:211-217) on the
+    well-conditioned fixture (oracle/fixtures.py).  The fixture is first shown to be well-conditioned: the torch-CPU fp32 oracle
+    reproduces the fp64 trajectory to < 1e-4."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, Wt, xu = _coherent_fixture()
+    steps = 6
+    label, t32 = oracle_trajectory(Wt, xu, torch.float32, steps)
+    label64, t64 = oracle_trajectory(Wt, xu, torch.float64, steps)
+    assert int(label) == int(label64) == 233
+    for it in range(steps):
+        assert rel_err(t32[it]["delta"], t64[it]["delta"]) < 1e-4, "fixture is not well-conditioned"
+    eng = FlickerI3D(W, batch_size=1, frames=T, dtype="f32")
+    clean = eng.logits(xu.cuda(), adv_flag=0.0).cpu()
+    e = rel_err(clean, i3d_ref.i3d_logits(xu.double() / 128 - 1, Wt[torch.float64]))
+    print(f"clean logits max-rel vs fp64 oracle {e:.2e}")
+    assert e < 1e-3
+    fooled_at = {"hip": None, "oracle": None}
+    for it in range(steps):
+        res = eng.step(xu.cuda(), label.cuda(), lr=1e-3, beta0=BETAS[0], beta1=BETAS[1], beta2=BETAS[2], beta3=BETAS[3], margin=0.05).host()
+        e_d = rel_err(eng.perturbation.cpu(), t64[it]["delta"])
+        e_l = rel_err(eng._logits.cpu(), t64[it]["logits"])
+        print(f"iter {it + 1}: adv {res['adv_loss']:.7f} (fp64 oracle {t64[it]['adv']:.7f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e} "
+              f"(torch-CPU fp32 oracle delta {rel_err(t32[it]['delta'], t64[it]['delta']):.2e})")
+        assert e_d < 1e-3, "learned delta"
+        assert res["adv_loss"] == pytest.approx(t64[it]["adv"], rel=1e-3, abs=1e-7)
+        assert res["total_loss"] == pytest.approx(t64[it]["total"], rel=1e-3, abs=1e-7)
+        assert res["prob_to_min"] == pytest.approx(t64[it]["to_min"], rel=1e-3)
+        torch.testing.assert_close(torch.from_numpy(res["softmax"]).double(), t64[it]["softmax"], rtol=1e-3, atol=1e-7)
+        assert e_l < 1e-3
+        for k, sm in (("hip", torch.from_numpy(res["softmax"])), ("oracle", t64[it]["softmax"])):
+            if fooled_at[k] is None and int(sm.argmax()) != int(label):
+                fooled_at[k] = it
+    assert fooled_at["hip"] == fooled_at["oracle"]          # same iteration-to-fool (None: not fooled within the 6 steps)
+
+
+def test_bf16_attack_equivalent_to_fp32_well_conditioned():
+    """bf16 (the benchmarked dtype) on the well-conditioned fixture: the SAME attack as fp32 -- loss curve within 3 %, learned delta
+    within 5 % of its maximum after every one of 12 iterations, identical iteration-to-fool."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, Wt, xu = _coherent_fixture()
+    label = torch.tensor([233]).cuda()
+    out = {}
+    for dt in ("f32", "bf16"):
+        eng = FlickerI3D(W, batch_size=1, frames=T, dtype=dt)
+        rows = []
+        for it in range(12):
+            r = eng.step(xu.cuda(), label).host()
+            rows.append((float(r["adv_loss"]), eng.perturbation.cpu().clone(), bool(r["is_adversarial"])))
+        out[dt] = rows
+        del eng
+    for it, ((l32, d32, a32), (l16, d16, a16)) in enumerate(zip(out["f32"], out["bf16"])):
+        e = rel_err(d16, d32)
+        print(f"iter {it + 1}: adv f32 {l32:.6f} bf16 {l16:.6f}; delta max-rel {e:.3e}; adversarial {a32} / {a16}")
+        assert l16 == pytest.approx(l32, rel=3e-2, abs=2e-3) and e < 5e-2
+    first = lambda rows: next((i for i, r_ in enumerate(rows) if r_[2]), None)
+    assert first(out["f32"]) == first(out["bf16"])
+
+
+def test_evaluate_fooling_rate_vs_oracle():
+    """FlickerI3D.evaluate = kinetics_i3d.evaluate (kinetics_i3d_utils.py:217-250): the integer counts (fooled AND clean-correct,
+    clean-correct) over an iterator of batches must equal the reference formula applied to the ORACLE's predictions, for the
+    untargeted, targeted and exclude_misclassify=False variants.  Fixture: the random-sign weights with the logits bias centred
+    on the four clips (otherwise the random network predicts one class whatever the input), clips of different contrast /
+    brightness, one clip deliberately mislabelled; the oracle's top-2 logit gaps are asserted to be wide (> 1e-3 of the largest
+    logit; the fp32 path reproduces logits to ~1e-6), so no argmax can hinge on rounding."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W = i3d_spec.synthetic_i3d_weights(42)
+    bkey = i3d_ref.PREFIX + "Logits/Conv3d_0c_1x1/conv_3d/b"
+    noise = i3d_spec.synthetic_clip_u8(4, T, seed=314).astype(np.float64)
+    clips = torch.from_numpy(np.stack([np.clip(128 + a * (noise[i] - 128) + b, 0, 255)
+                                       for i, (a, b) in enumerate([(1.0, 0), (0.3, -60), (0.3, 60), (0.6, -30)])]).astype(np.uint8))
+    x = clips.double() / 128 - 1
+    W[bkey] = np.zeros(400, np.float32)
+    W[bkey] = (-i3d_ref.i3d_logits(x, {k: torch.from_numpy(v).double() for k, v in W.items()}).mean(0)).numpy().astype(np.float32)
+    W64 = {k: torch.from_numpy(v).double() for k, v in W.items()}
+    delta = torch.full((T, 1, 1, 3), -0.2, dtype=torch.float32)
+    lg_clean = i3d_ref.i3d_logits(x, W64)
+    lg_adv = i3d_ref.i3d_logits(am.tf_apply(x, delta.double()), W64)
+    for lg in (lg_clean, lg_adv):
+        top = lg.topk(2).values
+        assert float(((top[:, 0] - top[:, 1]) / lg.abs().max(1).values).min()) > 1e-3, "fixture: an argmax hinges on rounding"
+    gt = lg_clean.argmax(1).clone()
+    fooled = lg_adv.argmax(1) != gt
+    assert 0 < int(fooled.sum()) < 4, "fixture: want a mixed outcome"
+    keep = int((~fooled).nonzero()[0])
+    gt[keep] = (gt[keep] + 1) % 400                            # one not-fooled clip is mislabelled: excluded from the valid set
+    target = int(lg_adv.argmax(1)[int(fooled.nonzero()[-1])])
+    print("oracle clean argmax", lg_clean.argmax(1).tolist(), "adv argmax", lg_adv.argmax(1).tolist(), "labels", gt.tolist(), "target", target)
+    eng = FlickerI3D(W, batch_size=2, frames=T, dtype="f32")
+    eng.reset_perturbation(delta.numpy())
+    batches = lambda: ((clips[i:i + 2].cuda(), gt[i:i + 2].cuda()) for i in (0, 2))
+    for kw in (dict(), dict(targeted_attack=True, target_class_id=target), dict(exclude_misclassify=False)):
+        miss, valid = am.fooling_counts(lg_adv, lg_clean, gt, targeted=kw.get("targeted_attack", False), target=kw.get("target_class_id"),
+                                        exclude_misclassify=kw.get("exclude_misclassify", True))
+        rate, total = eng.evaluate(batches(), **kw)
+        print(kw, "-> oracle counts", (miss, valid), "engine", (rate, total))
+        assert total == valid and rate == miss / valid
+    assert am.fooling_counts(lg_adv, lg_clean, gt)[1] == 3
+
+
+def test_step_rejects_bad_labels():
+    """a CPU label tensor would hand the loss kernel a host pointer (GPU memory fault), a class id >= 400 an out-of-range index:
+    both must be refused on the host; the kernel itself turns an out-of-range id into NaN outputs instead of reading out of bounds"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import _lib, i3d_spec, ops
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    eng = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=1, frames=T, dtype="bf16")
+    x = torch.from_numpy(i3d_spec.synthetic_clip_u8(1, T, seed=1)).cuda()
+    for bad in (torch.tensor([5]), torch.tensor([5], dtype=torch.int32).cuda(), torch.tensor([5, 6]).cuda(), torch.tensor([400]).cuda(),
+                torch.tensor([-1]).cuda()):
+        with pytest.raises(ValueError):
+            eng.step(x, bad)
+    assert eng.adam_t == 0
+    eng.step(x, torch.tensor([399]).cuda())
+    # the kernel's own guard (bypassing the host check)
+    lg = torch.randn(2, 400, device="cuda")
+    lab = torch.tensor([3, 400], device="cuda")
+    sm, dl, pc = (torch.empty_like(lg), torch.empty_like(lg), torch.empty(2, 4, device="cuda"))
+    a = _lib.LossArgs()
+    a.B, a.C, a.improve_loss, a.margin, a.mean_scale = 2, 400, 1, 0.05, 1.0
+    import ctypes
+    _lib.check(_lib.load().flk_softmax_adv_loss(ctypes.byref(a), _lib.ptr(lg), _lib.ptr(lab), _lib.ptr(sm), _lib.ptr(dl), _lib.ptr(pc), _lib.stream_ptr()))
+    assert torch.isfinite(pc[0, 0]) and torch.isfinite(dl[0]).all() and torch.isnan(pc[1, 0]) and torch.isnan(dl[1]).all()
 
 
 def test_bf16_step_runs_and_tracks_fp32(setup):

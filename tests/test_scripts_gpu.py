@@ -72,22 +72,90 @@ def test_universal_script_on_tfrecords(tmp_path):
     tfc.write_bundle(str(tmp_path / "ckpt" / "model.ckpt"), i3d_spec.synthetic_i3d_weights(42), with_crc=False)
     cfg = cfg.replace("'data/checkpoints/rgb_imagenet/model.ckpt'", f"'{tmp_path}/ckpt/model.ckpt'")
     (tmp_path / "cfg.yml").write_text(cfg)
-    cmd = [sys.executable, os.path.join(ROOT, "scripts", "i3d_adversarial_main_universal.py"), str(tmp_path / "cfg.yml"), "--section",
-           "CLASS_GEN_ATTACK", "--frames", str(T), "--dtype", "f32"]
-    r = subprocess.run(cmd + ["--max-steps", "3", "--summary-steps", "2"], capture_output=True, text=True, timeout=600)
+    # the class-generalisation entry point (reference i3d_adversarial_main_single_class_gen.py)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "i3d_adversarial_main_single_class_gen.py"), str(tmp_path / "cfg.yml"),
+           "--frames", str(T), "--dtype", "f32", "--no-weights-in-checkpoint"]
+    r = subprocess.run(cmd + ["--max-steps", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "step 3:" in r.stdout and "fooling rate" in r.stdout and "I3D weights: tf-checkpoint" in r.stdout
-    assert os.path.exists(tmp_path / "out" / "model_step_00003.npz") and os.path.exists(tmp_path / "out" / "res.pkl")
-    ck = np.load(tmp_path / "out" / "model_step_00003.npz")
-    assert ck["delta"].shape == (T, 1, 1, 3) and int(ck["t"]) == 3 and np.abs(ck["delta"]).max() > 0
-    # the same state as a TensorFlow bundle, and the TensorBoard scalars of step 2 under <out>/train
-    from flickering_adversarial_video_amd import tb_events, tf_checkpoint
+    assert "Step: 00003" in r.stdout and "fool_rate" in r.stdout and "I3D weights: tf-checkpoint" in r.stdout
+    # TensorFlow Saver checkpoints under the reference's names (variables live in tf.variable_scope('RGB'), kinetics_i3d_utils.py:87,100)
+    from flickering_adversarial_video_amd import tf_checkpoint
+    assert os.path.exists(tmp_path / "out" / "model_step_00000.index")                  # saved before the first step (:214)
     tfck = tf_checkpoint.read_bundle(str(tmp_path / "out" / "model_step_00003"), verify_crc=True)
-    assert np.array_equal(tfck["eps"], ck["delta"]) and int(tfck["global_step"]) == 3
-    ev = tb_events.read_scalars(glob.glob(str(tmp_path / "out" / "train" / "events.out.tfevents.*"))[0])
-    assert [s_ for s_, _ in ev] == [2] and set(tb_events.SCALAR_TAGS) <= set(ev[0][1]) and np.isfinite(list(ev[0][1].values())).all()
+    assert set(tfck) == {"RGB/eps", "RGB/eps/Adam", "RGB/eps/Adam_1", "beta1_power", "beta2_power"}
+    assert tfck["RGB/eps"].shape == (T, 1, 1, 3) and np.abs(tfck["RGB/eps"]).max() > 0 and np.abs(tfck["RGB/eps/Adam_1"]).max() > 0
+    assert float(tfck["beta1_power"]) == pytest.approx(0.9 ** 3, rel=1e-6) and float(tfck["beta2_power"]) == pytest.approx(0.999 ** 3, rel=1e-6)
+    res = pickle.load(open(tmp_path / "out" / "res.pkl", "rb"))
+    assert set(res) == {"total_loss_l", "adv_loss_l", "reg_loss_l", "norm_reg_loss_l", "diff_norm_reg_loss_l", "perturbation", "total_steps",
+                        "beta_1", "beta_2", "fatness", "smoothness", "fool_rate"}      # i3d_adversarial_main_single_class_gen.py:353-367
+    assert res["total_steps"] == 3 and len(res["total_loss_l"]) == 3 and len(res["perturbation"]) == 3 and res["perturbation"][0].shape == (T, 1, 1, 3)
+    assert len(res["fool_rate"]) == 3           # before the first step + after each of the two passes (2 global batches per pass, 3 steps)
+    # resume: delta, Adam m / v and the step count t = log(beta1_power) / log(0.9) come back from the newest bundle
     r = subprocess.run(cmd + ["--max-steps", "5"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "resumed from" in r.stdout and os.path.exists(tmp_path / "out" / "model_step_00005.npz")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "resumed from" in r.stdout and "at step 3" in r.stdout and os.path.exists(tmp_path / "out" / "model_step_00005.index")
+    tf5 = tf_checkpoint.read_bundle(str(tmp_path / "out" / "model_step_00005"))
+    assert float(tf5["beta1_power"]) == pytest.approx(0.9 ** 5, rel=1e-6)
+    # the checkpoint carries the whole optimiser state: write -> restore into a fresh engine -> identical (delta, m, v, t)
+    from flickering_adversarial_video_amd import i3d_dataset_attack as ida
+    e1 = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=1, frames=T, dtype="f32")
+    x1, y1 = torch.from_numpy(u8[:1, -T:]).cuda(), torch.tensor(labels[:1]).cuda()
+    for _ in range(2):
+        e1.step(x1, y1)
+    tf_checkpoint.write_bundle(str(tmp_path / "rt" / "model_step_00002"), ida.checkpoint_tensors(e1, 2))
+    assert ida.latest_checkpoint(str(tmp_path / "rt"), "model_step_") == (2, str(tmp_path / "rt" / "model_step_00002"))
+    e2 = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=1, frames=T, dtype="f32")
+    ida.restore(e2, str(tmp_path / "rt" / "model_step_00002"))
+    assert e2.adam_t == 2 and torch.equal(e2.eps_rgb, e1.eps_rgb) and torch.equal(e2.adam_m, e1.adam_m) and torch.equal(e2.adam_v, e1.adam_v)
+    e1.step(x1, y1); e2.step(x1, y1)
+    torch.testing.assert_close(e2.eps_rgb, e1.eps_rgb, rtol=1e-4, atol=1e-9)      # (fp32 pool backward: float atomics, last-ulp run-to-run)
+
+
+@pytest.mark.parametrize("variant", ["cyclic_pert", "dense"])
+def test_universal_section(tmp_path, variant):
+    """BASELINE config 5's entry: ``UNIVERSAL_ATTACK`` (Estimator layout) with CYCLIC_PERTURBATION_ATTACK: True, and with
+    FLICKERING_ATTACK: False (the dense L12 baseline) -- model_dir naming, model.ckpt-<step> checkpoints with global_step and the
+    frozen weights, TensorBoard train / eval scalars, perturbation.npy."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec, tb_events, tf_checkpoint, tfrecord_io as tio
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    T, B = 16, 2
+    (tmp_path / "all_cls" ).mkdir()
+    u8 = i3d_spec.synthetic_clip_u8(4, T, seed=19)
+    eng = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=1, frames=T, dtype="f32")
+    labels = [int(eng(torch.from_numpy(u8[i:i + 1]).cuda(), adv_flag=0).argmax()) for i in range(4)]
+    del eng
+    tio.write_records(str(tmp_path / "all_cls" / "a.tfrecords"), [tio.make_example(u8[i], labels[i]) for i in range(4)], with_payload_crc=False)
+    (tmp_path / "labels.txt").write_text("\n".join(f"class {i}" for i in range(400)))
+    cfg = open(os.path.join(ROOT, "run_config.yml")).read().replace("'data/label_map.txt'", f"'{tmp_path}/labels.txt'")
+    cfg = cfg.replace("['data/kinetics/database/tfrecord/test_all_cls/']", f"['{tmp_path}/all_cls/']")
+    cfg = cfg.replace("PKL_RESULT_PATH: 'result/generalization/universal_untargeted/'", f"PKL_RESULT_PATH: '{tmp_path}/out/'")
+    cfg = cfg.replace("NUM_OF_VID_EACH_TF_RECORDS: 50\n    BATCH_SIZE: 8", f"NUM_OF_VID_EACH_TF_RECORDS: 50\n    BATCH_SIZE: {B}")
+    if variant == "cyclic_pert":
+        cfg = cfg.replace("CYCLIC_PERTURBATION_ATTACK: False", "CYCLIC_PERTURBATION_ATTACK: True")
+    else:
+        cfg = cfg.replace("FLICKERING_ATTACK: True ", "FLICKERING_ATTACK: False")
+    assert f"BATCH_SIZE: {B}" in cfg
+    (tmp_path / "cfg.yml").write_text(cfg)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "i3d_adversarial_main_universal.py"), str(tmp_path / "cfg.yml"), "--frames", str(T),
+           "--dtype", "f32", "--max-steps", "4", "--summary-steps", "2", "--checkpoint-steps", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    kind = "FLICKERING_ATTACK" if variant == "cyclic_pert" else "SUP_ATTACK"
+    mdir = tmp_path / "out" / kind / "all_cls_t1050_v2000_"                 # <attack type>/<source class>_t<21*50>_v<40*50>_ (universal.py:300-302)
+    assert mdir.is_dir(), os.listdir(tmp_path / "out")
+    ck = tf_checkpoint.read_bundle(str(mdir / "model.ckpt-4"), verify_crc=False)
+    shape = (T, 1, 1, 3) if variant == "cyclic_pert" else (T, 224, 224, 3)
+    assert ck["RGB/eps"].shape == shape and int(ck["global_step"]) == 4 and ck["RGB/eps/Adam"].shape == shape
+    assert "RGB/inception_i3d/Conv3d_1a_7x7/conv_3d/w" in ck           # Saver() of the reference saves every variable, the frozen net included
+    assert os.path.exists(mdir / "model.ckpt-2.index") and np.load(mdir / "perturbation.npy").shape == shape
+    assert np.isfinite(ck["RGB/eps"]).all() and np.abs(ck["RGB/eps"]).max() > 0
+    ev = tb_events.read_scalars(glob.glob(str(mdir / "eval" / "events.out.tfevents.*"))[0])
+    assert ev and "ACC: 1- FOOLING_RATIO" in ev[-1][1] and 0.0 <= ev[-1][1]["ACC: 1- FOOLING_RATIO"] <= 1.0
+    if variant == "cyclic_pert":
+        tr = tb_events.read_scalars(glob.glob(str(mdir / "train" / "events.out.tfevents.*"))[0])
+        assert [s_ for s_, _ in tr] == [2, 4] and set(tb_events.SCALAR_TAGS) <= set(tr[0][1]) and np.isfinite(list(tr[0][1].values())).all()
 
 
 def test_r2plus1d_universal_script(tmp_path):

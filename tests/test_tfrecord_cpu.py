@@ -56,8 +56,26 @@ def test_batches_shard_over_ranks(tmp_path):
     assert len(files) == 2 and tio.list_tfrecords([str(tmp_path)], limit=1) == files[:1]
     single = list(tio.batches(files, 2, frames=2))
     assert len(single) == 5 and single[0][0].shape == (2, 2, 224, 224, 3) and single[0][0].dtype == np.uint8
+    # data-parallel: global batches of world*B consecutive records, rank r takes slice r; the global remainder is dropped,
+    # so every rank sees the SAME number of batches (each step ends in a collective)
     r0, r1 = list(tio.batches(files, 2, frames=2, rank=0, world=2)), list(tio.batches(files, 2, frames=2, rank=1, world=2))
-    assert len(r0) == 3 and len(r1) == 2
-    # round-robin: rank 0 owns records 0,2,..,10 (3 full batches), rank 1 owns 1,3,..,9 (2 full batches, record 9 dropped)
-    assert [int(l) for b in r0 for l in b[1]] == [recs[i][1] for i in (0, 2, 4, 6, 8, 10)]
-    assert [int(l) for b in r1 for l in b[1]] == [recs[i][1] for i in (1, 3, 5, 7)]
+    assert len(r0) == len(r1) == 2 == tio.count_batches(files, 2, world=2)
+    assert [int(l) for b in r0 for l in b[1]] == [recs[i][1] for i in (0, 1, 4, 5)]
+    assert [int(l) for b in r1 for l in b[1]] == [recs[i][1] for i in (2, 3, 6, 7)]
+    np.testing.assert_array_equal(r1[1][0][0], recs[6][0])
+    with pytest.raises(ValueError):
+        list(tio.batches(files, 2, frames=2, rank=0, world=2, drop_remainder=False))
+    assert len(list(tio.batches(files, 2, frames=2, drop_remainder=False))) == 6
+
+
+@pytest.mark.parametrize("n,world,B", [(28, 8, 2), (12, 8, 2), (11, 3, 2), (16, 8, 2), (5, 2, 4)])
+def test_equal_batch_counts_per_rank(tmp_path, n, world, B):
+    """the advisor's cases: N not divisible by world*B must not give ranks different batch counts"""
+    recs = _records(n, T=1, size=224, seed=n)
+    tio.write_records(str(tmp_path / "a.tfrecords"), [tio.make_example(v, l) for v, l in recs], with_payload_crc=False)
+    files = tio.list_tfrecords(str(tmp_path))
+    per_rank = [list(tio.batches(files, B, frames=1, rank=r, world=world)) for r in range(world)]
+    counts = [len(x) for x in per_rank]
+    assert counts == [n // (world * B)] * world == [tio.count_batches(files, B, world)] * world
+    seen = [int(l) for k in range(counts[0]) for r in range(world) for l in per_rank[r][k][1]]
+    assert seen == [recs[i][1] for i in range(counts[0] * world * B)]        # rank-major within a global batch, nothing read twice

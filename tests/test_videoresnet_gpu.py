@@ -1,6 +1,8 @@
 """End-to-end parity of the VideoResNet (r2plus1d_18 / r3d_18 / mc3_18) attack iteration on the GPU against the CPU oracle
-(oracle/videoresnet_ref.py + torch-dialect attack maths), same methodology as tests/test_i3d_gpu.py: smooth quantities
-at 1e-3 against the fp32 oracle; gradients against the fp64 oracle, no worse than the fp32 CPU oracle itself."""
+(oracle/videoresnet_ref.py + torch-dialect attack maths) at BASELINE config 3's size (16 x 112 x 112), same methodology as
+tests/test_i3d_gpu.py: smooth quantities at 1e-3 against the fp32 oracle; the backward pass LINK BY LINK (each residual block's
+backward fed with the HIP path's own output gradient and evaluated on its own input endpoint) at 1e-3 of the buffer maximum for
+all but a counted few elements (neighbourhoods of ReLU decisions that differ between two fp32 implementations)."""
 import numpy as np
 import pytest
 import torch
@@ -9,7 +11,7 @@ from oracle import attack_math as am
 from oracle import videoresnet_ref as vr
 
 pytestmark = pytest.mark.gpu
-T, HW = 8, 112
+T, HW = 16, 112
 
 
 def rel_err(a, b):
@@ -61,23 +63,43 @@ def test_videoresnet_forward_backward(arch):
         print(f"[{arch} {dtype}] logits: max rel err {e:.3e}")
         assert e < (1e-3 if f32 else 5e-2)
         assert float(res["adv_loss"]) == pytest.approx(r32["adv"], rel=1e-3 if f32 else 1e-1, abs=1e-5)
-        for name in reversed(list(r64["ge"])):
-            def masked(r):
-                g = r["ge"][name].permute(0, 2, 3, 4, 1)
-                return torch.where(r["ep"][name].permute(0, 2, 3, 4, 1) > 0, g, torch.zeros_like(g))
-            e_hip = rel_l2(torch.from_numpy(eng.net.activation("grad:" + name)), masked(r64))
-            e_cpu = rel_l2(masked(r32), masked(r64))
-            print(f"[{arch} {dtype}] grad:{name}: rel-L2 vs fp64: HIP {e_hip:.3e} (fp32 CPU oracle {e_cpu:.3e})")
-            assert e_hip < (max(3 * e_cpu, 0.1) if f32 else 0.9), name
+        # ---- backward, link by link (see tests/test_i3d_gpu.py): stem <- layer1.0 <- ... <- layer4.1 <- logits ----
+        Wd = {k: (torch.from_numpy(v).to(torch.bfloat16).double() if (not f32 and v.ndim == 5) else torch.from_numpy(v).double()) for k, v in W.items()}
+        FWD_TOL, BWD_TOL, BWD_FRAC, BWD_L2 = (1e-4, 1e-3, 1e-3, 1e-2) if f32 else (3e-2, 5e-2, 2e-2, 5e-2)
+        hip_act = lambda n: torch.from_numpy(eng.net.activation(n)).permute(0, 4, 1, 2, 3).contiguous().double()
+        links = [("stem", lambda x, fr: vr.stem(x, Wd, arch, fr))]
+        links += [(n, lambda x, fr, a=(n, kind, st, ds): vr.basic_block(x, Wd, a[0], a[1], a[2], a[3], fr)) for n, kind, st, ds in vr.blocks(arch)]
+        links.append(("logits", lambda x, fr: torch.nn.functional.linear(x.mean(dim=(2, 3, 4)), Wd["fc.weight"], Wd["fc.bias"])))
+        d0 = delta.double().clone().requires_grad_(True)
+        xa = am.torch_apply(x_cl.double().permute(0, 4, 1, 2, 3).contiguous(), d0, 0.2)
+        prev_name, prev = "delta", (xa.to(torch.bfloat16).double() + (xa - xa.detach())) if not f32 else xa     # bf16: stored input, straight-through
+        for name, fn in links:
+            with torch.no_grad():
+                out = fn(prev, True)
+            pre = fn(prev, False)
+            got_f, got_g = (eng._logits.cpu().double(), eng._dl.cpu().double()) if name == "logits" else (hip_act(name), hip_act("grad:" + name))
+            e_f = rel_err(out, got_f)
+            assert e_f < FWD_TOL, f"forward link {prev_name} -> {name}: {e_f:.3e}"
+            if prev_name == "delta":
+                (g_ref,) = torch.autograd.grad(pre, d0, grad_outputs=got_g)
+                g_hip = eng._red[:3 * T].view(T, 3).cpu().t().reshape(3, T, 1, 1).double()
+                assert rel_err(g_hip, g_ref) < (1e-3 if f32 else 3e-2), f"d(adv)/d(delta) link: {rel_err(g_hip, g_ref):.3e}"
+            else:
+                (g_ref,) = torch.autograd.grad(pre, prev, grad_outputs=got_g)
+                g_ref = torch.where(prev > 0, g_ref, torch.zeros_like(g_ref))
+                g_hip = hip_act("grad:" + prev_name)
+            e_l2, frac = rel_l2(g_hip, g_ref), float(((g_hip - g_ref).abs() > BWD_TOL * g_ref.abs().max()).double().mean())
+            print(f"[{arch} {dtype}] link {prev_name:>9s} -> {name:<9s} fwd max-rel {e_f:.2e} | bwd rel-L2 {e_l2:.2e}, elements beyond {BWD_TOL:g} of max: {frac:.2e}")
+            assert frac <= BWD_FRAC and e_l2 < BWD_L2, f"backward link {name} -> {prev_name}"
+            prev_name = name
+            if name != "logits":
+                prev = hip_act(name).requires_grad_(True)
         g = eng._red[:3 * T].view(T, 3).cpu().t().reshape(3, T, 1, 1)
         e_hip, e_cpu = rel_err(g, r64["g"]), rel_err(r32["g"], r64["g"])
         cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), r64["g"].flatten(), 0))
-        print(f"[{arch} {dtype}] d(adv)/d(delta) vs fp64: HIP {e_hip:.3e} (fp32 CPU {e_cpu:.3e}) cosine {cos:.6f}")
+        print(f"[{arch} {dtype}] d(adv)/d(delta) end to end vs fp64: HIP {e_hip:.3e} (fp32 CPU {e_cpu:.3e}) cosine {cos:.6f}")
         assert g[:, 2].abs().max() == 0
-        if f32:
-            assert e_hip < 3 * e_cpu + 5e-3 and cos > 0.999
-        else:
-            assert cos > 0.8
+        assert cos > (0.999 if f32 else 0.8)
         # one real update: torch-Adam on (adv + lambda*reg) -- first step is a pure sign step of the total gradient
         before = eng.pert_model.perturbation.clone()
         eng.step(x_cl.cuda(), r32["label"].cuda(), crit)
@@ -131,3 +153,54 @@ def test_videoresnet_drivers():
     for r in out:
         for ph in ("train", "valid"):
             assert 0.0 <= r[f"{ph}/fooling_ratio"] <= 1.0 and np.isfinite(r[f"{ph}/loss"]) and r[f"{ph}/perturbation"].shape == (3, T, 1, 1)
+
+
+@pytest.mark.gpu
+def test_videoresnet_dense_l12_attack():
+    """the dense "L12" attack of the torch learner (attack_type != 'flickering': perturbation [3,T,H,W], model.py:380-384;
+    loss = adv + lambda * L12(clamped delta), model.py:169-175,211-214) through FlickerVideoResNet: losses against the oracle,
+    the dense adversarial gradient via the link from the stem (like-for-like), and one torch-Adam update of every pixel."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet, Losses
+    arch, Tn = "r3d_18", 8
+    W = vs.synthetic_weights(arch, 42)
+    Wd = {k: torch.from_numpy(v).double() for k, v in W.items()}
+    x_cl = torch.from_numpy(vs.synthetic_clip(1, Tn, HW, HW, seed=5))
+    rng = np.random.default_rng(12)
+    delta = torch.from_numpy(rng.uniform(-0.05, 0.05, (3, Tn, HW, HW)).astype(np.float32))
+    delta[:, 1, :4] = 0.3                                   # beyond dynamic_max_norm = 0.2
+    eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=Tn, image_size=HW, dtype="f32", l_inf_pert_norm=0.2, attack_type="L12")
+    assert eng.pert_model.size == (3, Tn, HW, HW) and eng.pert_model.perturbation.shape == (Tn, HW, HW, 3)
+    eng.pert_model.init_perturbation(delta.numpy())
+    crit = Losses(lambda_=0.7, margin=0.05, improve_loss=True, logits=True, attack_type="L12")
+    with pytest.raises(ValueError):
+        eng.step(x_cl.cuda(), torch.zeros(1, dtype=torch.int64).cuda(), Losses(attack_type="flickering"))
+    # oracle
+    d0 = delta.double().clone().requires_grad_(True)
+    xa = am.torch_apply(x_cl.double().permute(0, 4, 1, 2, 3).contiguous(), d0, 0.2)
+    logits = vr.videoresnet_logits(xa, Wd, arch)
+    label = logits.argmax(-1)
+    loss, adv, reg = am.torch_losses(label, logits, torch.softmax(logits, 1), d0.clamp(-0.2, 0.2), 0.5, 0.7, 0.05, True, True, "L12")
+    (gtot,) = torch.autograd.grad(loss, d0)
+    r = eng.step(x_cl.cuda(), label.cuda(), crit, lr=1e-3)
+    assert float(r["adv_loss"]) == pytest.approx(adv.item(), rel=1e-3, abs=1e-6)
+    assert float(r["reg_loss"]) == pytest.approx(reg.item(), rel=1e-4)
+    assert float(r["loss"]) == pytest.approx(loss.item(), rel=1e-3)
+    # dense d(adv)/d(delta): the stem link on the HIP path's own stem gradient (like-for-like, no ReLU decisions in between)
+    hip_act = lambda n: torch.from_numpy(eng.net.activation(n)).permute(0, 4, 1, 2, 3).contiguous().double()
+    pre = vr.stem(xa, Wd, arch, False)
+    (g_ref,) = torch.autograd.grad(pre, d0, grad_outputs=hip_act("grad:stem"))
+    g_hip = eng._gdense.cpu().permute(3, 0, 1, 2).double()
+    print(f"dense d(adv)/d(delta): max-rel {rel_err(g_hip, g_ref):.2e}")
+    assert rel_err(g_hip, g_ref) < 1e-3 and float(g_hip[:, 1, :4].abs().max()) == 0
+    # the update: first torch-Adam step = lr * sign of the total gradient wherever it is not tiny
+    moved = eng.pert_model.get_perturbation()[1].cpu().double() - delta.double()
+    big = gtot.abs() > 0.05 * gtot.abs().max()
+    assert (torch.sign(moved[big]) == -torch.sign(gtot[big])).double().mean() > 0.995
+    assert float(moved.abs().max()) == pytest.approx(1e-3, rel=1e-2)
+    # an evaluation pass reports the same regulariser for the same delta
+    r_eval = eng.step(x_cl.cuda(), label.cuda(), crit, update=False)
+    r_upd = eng.step(x_cl.cuda(), label.cuda(), crit, lr=0.0)
+    assert float(r_eval["reg_loss"]) == pytest.approx(float(r_upd["reg_loss"]), rel=1e-4)

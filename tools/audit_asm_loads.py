@@ -32,8 +32,9 @@ def regs_of(text):
 def compile_asm(src):
     hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc") if c and (os.path.exists(c) or c == "hipcc")), "hipcc")
     out = os.path.join(tempfile.mkdtemp(prefix="flk_audit_"), "k.s")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src], check=True,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    inc = [os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc"), os.path.join(ROOT, "include")]
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *(f"-I{d}" for d in inc), "-o", out, src],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return open(out).read()
 
 
@@ -61,7 +62,8 @@ def audit_kernel(name, lines):
             if "global_load_dwordx4" in st:
                 ins.append(("gen", regs_of(st.split(",")[0]), raw))
             elif "s_waitcnt" in st and "vmcnt" in st:
-                ins.append(("kill", regs_of(st.split("release", 1)[1]) if "release" in st else (None if "vmcnt(0)" in st else set()), raw))
+                # vmcnt(0) retires every load; a counted wait retires the registers its "; release ..." comment names
+                ins.append(("kill", None if "vmcnt(0)" in st else (regs_of(st.split("release", 1)[1]) if "release" in st else set()), raw))
             continue
         if not code or code.startswith(".") or code.endswith(":"):
             continue
@@ -106,7 +108,7 @@ def audit_kernel(name, lines):
                 cur |= p
             elif k == "kill":
                 cur = set() if p is None else cur - p
-            elif k == "op" and check and cur & p:
+            elif k == "op" and check is not None and cur & p:
                 check.append((i, sorted(cur & p), raw.strip()))
         return cur
 
@@ -135,7 +137,7 @@ def main():
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_igemm.hip")
     text = compile_asm(src)
     bad = total = 0
-    for m in re.finditer(r"^(_Z\S*conv_igemm_kernel\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(\S*conv_igemm_kernel\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
         nloads, viol = audit_kernel(name, body)
         if nloads:
