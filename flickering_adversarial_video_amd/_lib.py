@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libflicker_hip.so")
+LIB_PATH = os.environ.get("FLK_LIB_PATH") or os.path.join(HERE, "libflicker_hip.so")     # FLK_LIB_PATH: A/B a second build of the library
 
 FLK_F32, FLK_BF16 = 0, 1
 FLK_NET_I3D, FLK_NET_R2PLUS1D_18, FLK_NET_R3D_18, FLK_NET_MC3_18 = 0, 1, 2, 3
@@ -101,6 +101,13 @@ _SIGS = {
     "flk_net_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "flk_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_net_has_backward_delta": (C.c_int, [C.c_void_p]),
+    "flk_net_backward_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_stem_delta_grad_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "flk_stem_delta_grad_weights_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "flk_stem_delta_grad_weights_destroy": (C.c_int, [C.c_void_p]),
+    "flk_stem_delta_grad_mask": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p]),
+    "flk_stem_delta_grad": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "flk_net_autotune": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_conv_set_autotune": (C.c_int, [C.c_int]),

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflicker_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "pool.hip", "head.hip", "attack.hip", "net.cpp"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "pool.hip", "head.hip", "attack.hip", "stem_grad.hip", "net.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-x", "hip"]
 

@@ -274,6 +274,13 @@ __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const flo
   gdelta[ts * 3 + c] = pass ? s * a.adv_flag * a.inv_std[c] : 0.f;
 }
 
+// stage 2 alone, for producers of stage-1 partials outside this file (stem_grad.hip)
+int flk_grad_reduce_stage2_launch(const flk_apply_args* a, int nchunk, const float* partials, float* gdelta, hipStream_t s) {
+  hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128), dim3(128), 0, s, *a, nchunk, partials, gdelta);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
 // dense delta ("L12" baseline, kinetics_i3d_utils.py:308-521): no spatial reduction, sum over the batch.
 template <typename TI, int FTL>
 __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a, const char* gx, float* gdelta) {

@@ -96,11 +96,16 @@ struct flk_net {
   void* gx_in = nullptr;
   float* logits_out = nullptr;
   const float* dlogits_in = nullptr;
+  // fused stem delta-gradient (stem_grad.hip): fp32 weights, index of the stem data-gradient op it replaces, the stem's gradient buffer
+  float* d_stem_wf = nullptr;
+  int stem_dgrad_op = -1;
+  Act stem_G;
   // head
   float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
   // profiling
   hipStream_t side[kSideStreams] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kSideStreams] = {nullptr, nullptr};
+  hipEvent_t ev_mask_fork = nullptr, ev_mask_done = nullptr;     // the stem clip-mask pre-pass runs beside the backward pass
   bool multi_stream = true;
   bool tuning = false;
   bool profile = false;
@@ -293,12 +298,14 @@ int flk_net::build_i3d() {
     if ((rc = flk_conv_weights_create_impl(stem->w.data(), 4, 4, 4, 32, 64, stem->scale.data(), 1, dtype, choose_nf(32, 64), 0, &stem->wb))) return rc;
     if ((rc = upload(&stem->d_scale, stem->scale)) || (rc = upload(&stem->d_bias, stem->bias))) return rc;
   }
+  if (dtype == FLK_BF16 && (rc = flk_stem_delta_grad_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_wf))) return rc;
   const int T1 = T / 2, H1 = H / 2, W1 = W / 2;
   Act xin; xin.T = T1; xin.H = H1; xin.W = W1; xin.ld = 32;       // bound per call
   Act a1, G1;
   if ((rc = new_act(a1, T1, H1, W1, 64)) || (rc = new_act(G1, T1, H1, W1, 64))) return rc;
   named["Conv3d_1a_7x7"] = {a1, 64};
   named["grad:Conv3d_1a_7x7"] = {G1, 64};
+  stem_G = G1;
   {
     // SAME padding of the 7/2 conv on an even size is (2,3) -> in s2d space taps j=0..3 read o-1+j: pad-before 1
     flk_conv_args a{};
@@ -526,6 +533,8 @@ int flk_net::build_i3d() {
   }
   for (auto it = bwd_emit.rbegin(); it != bwd_emit.rend(); ++it) (*it)();
   (void)xin;
+  for (size_t i = 0; i < bwd.size(); ++i)
+    if (bwd[i].name == "Conv3d_1a_7x7/dgrad") stem_dgrad_op = (int)i;
   return FLK_OK;
 }
 
@@ -852,6 +861,9 @@ extern "C" int flk_net_destroy(flk_net* n) {
     if (n->ev_join[l]) (void)hipEventDestroy(n->ev_join[l]);
   }
   if (n->ev_fork) (void)hipEventDestroy(n->ev_fork);
+  if (n->ev_mask_fork) (void)hipEventDestroy(n->ev_mask_fork);
+  if (n->ev_mask_done) (void)hipEventDestroy(n->ev_mask_done);
+  flk_stem_delta_grad_weights_destroy(n->d_stem_wf);
   for (void* p : n->allocs) (void)hipFree(p);
   for (auto& L : n->convs) {
     flk_conv_weights_destroy(L->wf); flk_conv_weights_destroy(L->wb);
@@ -882,6 +894,8 @@ extern "C" int flk_net_finalize(flk_net* n) {
     FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_join[l], hipEventDisableTiming));
   }
   FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+  FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_fork, hipEventDisableTiming));
+  FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_done, hipEventDisableTiming));
   n->multi_stream = !getenv("FLK_SINGLE_STREAM");
   FLK_CHECK_HIP(hipDeviceSynchronize());
   n->finalized = true;
@@ -896,7 +910,8 @@ extern "C" int64_t flk_net_input_numel(const flk_net* n) {
 }
 extern "C" int flk_net_num_classes(const flk_net* n) { return n ? n->num_classes : 0; }
 
-static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool& ev_valid, hipStream_t s) {
+static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool& ev_valid, hipStream_t s,
+                   int replace_op = -1, const std::function<int(hipStream_t)>* replacement = nullptr) {
   if (n->profile && ev.size() != ops.size()) {
     for (size_t i = ev.size(); i < ops.size(); ++i) {
       hipEvent_t a, b;
@@ -932,7 +947,7 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
     // conditions they will run in; branch kernels co-run with their siblings, where the isolated optimum is not the best
     if (n->tuning) flk_conv_set_autotune(!in_fork);
     if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].first, st));
-    int rc = op.run(st);
+    int rc = ((int)i == replace_op && replacement) ? (*replacement)(st) : op.run(st);
     if (rc) return rc;
     if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].second, st));
   }
@@ -955,6 +970,39 @@ extern "C" int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, v
   if (!n->fwd_done) { flk_set_error("flk_net_backward: no forward pass to differentiate"); return FLK_ESTATE; }
   n->dlogits_in = dlogits; n->gx_in = gx_in;
   return run_ops(n, n->bwd, n->ev_bwd, n->ev_bwd_valid, (hipStream_t)stream);
+}
+
+extern "C" int flk_net_has_backward_delta(const flk_net* n) {
+  static const bool off = getenv("FLK_STEM_FUSED") && atoi(getenv("FLK_STEM_FUSED")) == 0;
+  return n && n->finalized && n->d_stem_wf && n->stem_dgrad_op >= 0 && !off;
+}
+
+// backward to the flickering perturbation: the stem's data-gradient op is replaced by the fused delta-gradient kernel
+// (stem_grad.hip), which runs in its place in the plan (same stream, same profile slot "Conv3d_1a_7x7/dgrad")
+extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const flk_apply_args* a, float* gdelta, float* partials, void* stream) {
+  FLK_REQUIRE(n && n->finalized && dlogits && a && gdelta && partials, "flk_net_backward_delta: bad argument / not finalized");
+  FLK_REQUIRE(n->d_stem_wf && n->stem_dgrad_op >= 0, "flk_net_backward_delta: only the I3D plan in bf16 has the fused stem delta-gradient");
+  FLK_REQUIRE(a->B == n->B && a->T == n->T && a->H == n->H && a->W == n->W, "flk_net_backward_delta: apply args (%d,%d,%d,%d) do not match the "
+              "net (%d,%d,%d,%d)", a->B, a->T, a->H, a->W, n->B, n->T, n->H, n->W);
+  if (!n->fwd_done) { flk_set_error("flk_net_backward_delta: no forward pass to differentiate"); return FLK_ESTATE; }
+  n->dlogits_in = dlogits; n->gx_in = nullptr;
+  const flk_apply_args ac = *a;
+  hipStream_t s = (hipStream_t)stream;
+  // the clip mask depends on the clip and on delta only: it runs on a side stream beside the whole backward pass and is joined
+  // right in front of the GEMM that consumes it (serial mode: inline)
+  const bool beside = n->multi_stream && n->side[0];
+  if (beside) {
+    FLK_CHECK_HIP(hipEventRecord(n->ev_mask_fork, s));
+    FLK_CHECK_HIP(hipStreamWaitEvent(n->side[0], n->ev_mask_fork, 0));
+    int rc = flk_stem_delta_grad_mask(&ac, partials, n->side[0]);
+    if (rc) return rc;
+    FLK_CHECK_HIP(hipEventRecord(n->ev_mask_done, n->side[0]));
+  }
+  const std::function<int(hipStream_t)> fused = [n, ac, gdelta, partials, beside](hipStream_t st) {
+    if (beside) FLK_CHECK_HIP(hipStreamWaitEvent(st, n->ev_mask_done, 0));
+    return flk_stem_delta_grad(&ac, n->stem_G.p, n->stem_G.ld, n->d_stem_wf, gdelta, partials, beside ? 1 : 0, st);
+  };
+  return run_ops(n, n->bwd, n->ev_bwd, n->ev_bwd_valid, s, n->stem_dgrad_op, &fused);
 }
 
 // one serial forward + backward with conv autotuning switched on (conv_igemm.hip): every convolution of the plan times its

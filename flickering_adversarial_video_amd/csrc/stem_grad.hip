@@ -1,0 +1,459 @@
+// Fused delta-gradient of the I3D stem: d(loss)/d(delta[t,c]) straight from the stem's output gradient, on MFMA.
+//
+// Replaces, for the flickering attack (delta is [T,3]), the stem's data-gradient convolution + the masked reduction over
+// (b,h,w) (Conv3DBackpropInputV2 of i3d.py:169 + the clip_by_value / reduce_sum gradients of kinetics_i3d_utils.py:100-142):
+//
+//   g[t,c] = sum_b sum_{h,w} m[b,t,h,w,c] * gx[b,t,h,w,c],   gx = transposed 7x7x7/2 convolution of G (64 channels),
+//   m = 1[lo <= x' + a p' <= hi]   (the clip mask of the perturbed clip)
+//
+// The data-gradient gx has only 3 output channels per pixel: as an implicit GEMM its N dimension is 3 (24 of 32 after the
+// space-to-depth fold, half of the folded taps structurally zero) -- 50 % of the MFMA work is padding and the narrow tile is
+// LDS-read-bound (384 TFLOP/s algorithmic in round 1).  But gx is only ever needed SUMMED against the mask, and that sum
+// regroups into the weight-gradient form of the same convolution with the MASK as its input:
+//
+//   g[t,c] = sum_{(ot,kt): 2ot+kt-2=t} sum_{kh,kw,co} Wa[kt,kh,kw,c,co] * C[ot,kt; co; c,kh,kw]
+//   C[..]  = sum_{b,oh,ow} G[b,ot,oh,ow,co] * m[b,t,2oh+kh-2,2ow+kw-2,c]
+//
+// i.e. a GEMM with M = 64 channels x (3-4 output frames), N = 147 = 3*7*7 (padded to 160: 92 % useful), K = output positions:
+// no structural zeros, 40 MFMAs per 9 operand reads.  The mask operand is generated on the fly from the resident uint8 / fp32
+// clip (never materialised in HBM), the weights enter in fp32 in the epilogue (the bf16 data-gradient rounded them to bf16),
+// and neither gx (205 MB at bs 8) nor the space-to-depth clip is read or written.
+//
+// Two launches:
+//  1. stem_mask_kernel (HBM-bound, 0.27 GB written at bs 8): the clip mask in the GEMM's B-operand order -- per (clip, frame, input row h)
+//     21 = 3 x 7 byte rows E[c*7+kw][ow] = m[h, 2*ow+kw-2, c] (0x40 = pass, 0x00 = clipped / outside the frame): the stride-2 tap shift
+//     is resolved here, so every B fragment of the GEMM is 8 CONSECUTIVE bytes.
+//  2. stem_delta_grad_kernel: workgroup = (clip b, frame pair t2, chunk of output rows), 8 waves.  Waves 0..6 only run MFMAs: wave (p, q) owns
+//     C for output frame ot = t2+1-p and clip frame t = 2*t2+q (tap kt = 2p+q), 64 x 160 accumulators; the odd frame has three taps, so
+//     wave 7 has no MFMA work: it is the PRODUCER.  It feeds the G tiles (two K steps ahead, three LDS buffers) and the mask rows (ring of
+//     16 input rows per frame) by LDS-DMA (global_load_lds: no VGPR round trip), issued from inline asm so that hipcc inserts no wait
+//     of its own, and retires them with ONE counted s_waitcnt vmcnt(N) per step (N = what this step issued: everything older has landed).
+//     K step = 32 output positions = 4 runs of 8 consecutive ow:
+//       A (G^T): the [32 positions][4 planes][64 ch] tile sits row-major in LDS (128-byte rows; the XOR swizzle of the 16-byte slots is
+//                applied on the DMA's SOURCE address) and is read with ds_read_b64_tr_b16 (hardware transpose: lane = channel, 8 positions);
+//       B (mask): 8 bytes per lane; a byte is 0x00 / 0x40, so two v_perm_b32 turn 4 bytes into 4 bf16 values 0.0 / 2.0 (bf16 2.0 =
+//                0x4000: its low byte is zero); the factor 2 is undone in the epilogue.
+// Partials are written in the layout of attack.hip's grad_reduce_stage1, so its deterministic stage 2 (batch / chunk sum in a
+// fixed order, roll, 1/std, delta-clip mask) is reused unchanged.
+#include <stdlib.h>
+#include "flk_internal.h"
+
+namespace {
+
+constexpr int SG_THREADS = 512;
+constexpr int SG_CO = 64;              // stem output channels
+constexpr int SG_NCOL = 147;           // 3 * 7 * 7 columns (c, kh, kw)
+constexpr int SG_NPAD = 160;           // padded to 10 fragments of 16
+constexpr int SG_NF = SG_NPAD / 16;
+constexpr int SG_WO = 112;             // output width (the I3D stem on 224 x 224 frames)
+constexpr int SG_MROW = SG_WO;         // bytes per (c, kw) mask row: 112 B = 28 banks -> the 16 rows of a fragment read hit distinct banks
+constexpr int SG_ROWSET = 21 * SG_MROW;   // one input row of one frame: 3 channels x 7 kw = 2352 bytes = 147 x 16
+constexpr int SG_RING = 16;            // input rows kept per frame (9 live + 4 in flight)
+constexpr int SG_GTILE = 4 * 32 * 128;    // bytes of one K step's G tile: 4 planes x 32 positions x 64 bf16
+constexpr int SG_GBUFS = 3;            // G tiles: two K steps of DMA look-ahead
+constexpr int SG_OFF_MRING = SG_GBUFS * SG_GTILE;
+constexpr int SG_OFF_RED = SG_OFF_MRING + 2 * SG_RING * SG_ROWSET;
+constexpr int SG_LDS = SG_OFF_RED + 8 * 3 * 4;
+
+struct StemGradKP {
+  const char* G; int g_ld;             // bf16 [B][To][Ho][Wo][g_ld], channels [0,64)
+  const float* Wf;                     // fp32 [7][160][64]: Wf[kt][c*49+kh*7+kw][co] = W[kt,kh,kw,c,co] * bn_scale[co]; then 1 KiB of zeros
+  const char* mask;                    // bytes [B][T][H][21][112] from stem_mask_kernel
+  float* partials;
+  int B, T, H, To, Ho, Wo;
+  int nchunk, rows_per_chunk;
+  int dbg;                             // timing experiments only (FLK_SG_DBG): 1 = no mask stream, 2 = no MFMA phase, 4 = no G stream
+};
+
+__device__ inline int sg_wrap(int t, int T) { t %= T; return t < 0 ? t + T : t; }
+__device__ inline float sg_clip(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// perturbation added at frame t (flicker delta only) -- the same expression as attack.hip: pert_at
+__device__ inline float sg_pert(const flk_apply_args& a, int t, int c) {
+  float d = a.delta[sg_wrap(t - a.shift_p, a.T) * 3 + c];
+  if (a.dclip > 0.f) d = sg_clip(d, -a.dclip, a.dclip);
+  return d * a.inv_std[c];
+}
+
+// ---- 1. the clip mask in B-operand order ----
+// One workgroup walks over (clip, frame, row) triples.  Per row: the 672 interleaved RGB values are read once (coalesced) and their pass
+// bits written into 6 byte sequences S[c][w parity][w/2] in LDS; the 21 (c, kw) rows of E are byte-shifted windows of those sequences
+// (row kw = sequence kw&1 shifted by (kw>>1)-1, zero beyond the frame): two aligned LDS dwords + v_alignbyte_b32 per 4 mask bytes,
+// stored as 147 coalesced 16-byte pieces.  HBM-bound: 1 read of the clip, 3.5x that written.
+constexpr int SM_SEQ = 120;            // bytes per sequence: 4 zeros | 112 mask bytes | 4 zeros
+__global__ __launch_bounds__(256) void stem_mask_kernel(const flk_apply_args a, char* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char S[2][6 * SM_SEQ];
+  const int tid = threadIdx.x;
+  if (tid < 2 * 6 * 2) {                                           // the zero sentinels of both buffers
+    const int bsel = tid / 12, r = tid % 12;
+    *(unsigned*)&S[bsel][(r >> 1) * SM_SEQ + (r & 1) * (SM_SEQ - 4)] = 0u;
+  }
+  // this thread's 4 output dwords d = 4 tid + e of a row (d < 588): sequence window and shift -- functions of d only
+  int o_src[4], o_sh[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int d = 4 * tid + e, cw = d / 28, ow4 = d - cw * 28, c = cw / 7, kw = cw - c * 7;
+    const int qb = 4 * ow4 + (kw >> 1) - 1 + 4;                    // byte offset into the sequence incl. its leading zeros
+    o_src[e] = (c * 2 + (kw & 1)) * SM_SEQ + (qb & ~3);
+    o_sh[e] = qb & 3;
+  }
+  const int nrows = a.B * a.T * a.H;
+  const bool loader = 4 * tid < a.W * 3;                           // W*3 = 672 interleaved values per row: 168 threads x 4
+  auto row_src = [&](int row) -> size_t {
+    const int h = row % a.H, bt = row / a.H, t = bt % a.T, b = bt / a.T;
+    return ((((size_t)b * a.T + sg_wrap(t - a.shift_x, a.T)) * a.H + h) * a.W) * 3 + 4 * tid;   // x'[t] = x[(t - shift_x) mod T]
+  };
+  unsigned nu = 0; float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);   // the NEXT row's values: loaded one row ahead (latency hidden)
+  if (loader && (int)blockIdx.x < nrows) {
+    if (a.x_is_u8) nu = *(const unsigned*)((const unsigned char*)a.x + row_src(blockIdx.x));
+    else nf = *(const float4*)((const float*)a.x + row_src(blockIdx.x));
+  }
+  int buf = 0;
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x, buf ^= 1) {
+    const int t = (row / a.H) % a.T;
+    const unsigned cu = nu; const float4 cf = nf;
+    if (loader && row + (int)gridDim.x < nrows) {
+      if (a.x_is_u8) nu = *(const unsigned*)((const unsigned char*)a.x + row_src(row + gridDim.x));
+      else nf = *(const float4*)((const float*)a.x + row_src(row + gridDim.x));
+    }
+    if (loader) {
+      float pv[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) pv[c] = a.adv_flag * sg_pert(a, t, c);
+      float xv[4];
+      if (a.x_is_u8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = (float)((cu >> (8 * e)) & 255u) * a.x_scale + a.x_bias;
+      } else {
+        xv[0] = cf.x; xv[1] = cf.y; xv[2] = cf.z; xv[3] = cf.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * tid + e, w = i / 3, c = i - 3 * w;
+        const float u = xv[e] + (c == 0 ? pv[0] : c == 1 ? pv[1] : pv[2]);   // both clip gradients are inclusive at the bounds
+        S[buf][(c * 2 + (w & 1)) * SM_SEQ + 4 + (w >> 1)] = (u >= a.lo && u <= a.hi) ? 0x40 : 0x00;
+      }
+    }
+    __syncthreads();     // (also orders this row's writes to S[buf] behind the reads of two rows ago: every thread passed the barrier in between)
+    if (tid < SG_ROWSET / 16) {
+      uint4 o;
+      unsigned* ow = (unsigned*)&o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned* sp = (const unsigned*)&S[buf][o_src[e]];
+        ow[e] = __builtin_amdgcn_alignbyte(sp[1], sp[0], (unsigned)o_sh[e]);
+      }
+      *(uint4*)(out + (size_t)row * SG_ROWSET + tid * 16) = o;
+    }
+  }
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+// one LDS-DMA wave instruction: lane l moves 16 bytes from gsrc (per lane) to LDS byte address lds_base + 16 l (lds_base wave-uniform)
+__device__ inline void glds16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
+// ---- 2. the GEMM ----
+__global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const StemGradKP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const gbuf = smem;
+  char* const mring = smem + SG_OFF_MRING;
+  float* const red = (float*)(smem + SG_OFF_RED);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pl = wave & 3, q = wave >> 2;            // output-frame plane, clip frame of the pair
+  const int g = lane >> 4, i16 = lane & 15;
+  const int T2 = p.T / 2;
+  int id = blockIdx.x;
+  const int b = id % p.B; id /= p.B;                 // clips fastest: with 8 clips the planes of one clip stay on one XCD's L2
+  const int t2 = id % T2;
+  const int chunk = id / T2;
+  const int oh_lo = chunk * p.rows_per_chunk;
+  const int oh_hi = min(p.Ho, oh_lo + p.rows_per_chunk);
+  constexpr int gpr = SG_WO / 8;                     // 8-position groups per output row (14; the host checks Wo = 112)
+  const int ngroups = (oh_hi - oh_lo) * gpr;
+  const int nsteps = (ngroups + 3) >> 2;
+  const bool producer = wave == 7;                   // (p = 3, q = 1): the odd frame has three taps kt = 1, 3, 5
+
+  // highest input row K step s touches: its last group's output row, tap kh = 6
+  auto hmax_of = [&](int s) {
+    int gi = 4 * s + 3;
+    if (gi > ngroups - 1) gi = ngroups - 1;
+    return 2 * (oh_lo + gi / gpr) + 4;
+  };
+  const unsigned lds0 = lds_addr(smem);
+  const char* const zeros = (const char*)(p.Wf + (size_t)7 * SG_NPAD * SG_CO) + (lane << 4);   // 1 KiB of zeros behind the weights
+  // G tile of K step s into buffer buf: 16 DMA instructions of 1 KiB (8 positions x 128 B); lane l lands in row l/8, slot l%8 and
+  // therefore fetches chunk (l%8) ^ 2*gsw(row) -- the swizzle the transposing reads below expect.  (Measured: issuing a piece costs
+  // its wave 60-100 cycles; spreading the pieces over the consumer waves -- all of them, or only wave 3 whose SIMD carries half the MFMA
+  // load -- slowed the MFMA phases by more than the producer gained: 0.70-0.76 ms against 0.64 ms for the whole delta-gradient.)
+  auto g_issue = [&](int s, int buf) {
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+      const int gi = 4 * s + gg;
+      const int r = gi / gpr, col = gi - r * gpr;
+      const int oh = oh_lo + r, j = gg * 8 + (lane >> 3);
+      const int gsw = ((j >> 1) & 1) | (((j >> 3) & 1) << 1);
+      const int ch = (lane & 7) ^ (2 * gsw);
+      const size_t pos_off = (((size_t)oh * p.Wo + col * 8 + (lane >> 3)) * p.g_ld + ch * 8) * 2;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const int ot = t2 + 1 - pp;
+        const bool ok = ot >= 0 && ot < p.To && oh < oh_hi;
+        const char* src = ok ? p.G + (size_t)(b * p.To + ot) * p.Ho * p.Wo * p.g_ld * 2 + pos_off : zeros;
+        glds16(src, lds0 + (unsigned)(buf * SG_GTILE + (pp * 32 + gg * 8) * 128));
+      }
+    }
+  };
+  // mask rows h_from..h_to of both frames into their ring slots: 3 DMA instructions (147 x 16 B) per row and frame; rows outside the
+  // frame come from the zero page
+  auto mask_issue = [&](int h_from, int h_to) {
+    for (int h = h_from; h <= h_to; ++h) {
+      const bool inside = h >= 0 && h < p.H;
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const char* row = p.mask + (((size_t)b * p.T + 2 * t2 + qq) * p.H + (inside ? h : 0)) * SG_ROWSET;
+        const unsigned dst = lds0 + (unsigned)(SG_OFF_MRING + (qq * SG_RING + ((h + 2) & (SG_RING - 1))) * SG_ROWSET);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int L = 64 * k + lane;
+          const char* src = inside ? row + (L << 4) : zeros;
+          if (L < SG_ROWSET / 16) glds16(src, dst + 1024u * k);
+        }
+      }
+    }
+  };
+
+  // ---- prologue: the mask rows of steps 0 and 1, G tiles 0 and 1 ----
+  const int h_first = 2 * oh_lo - 2;
+  int h_req = hmax_of(nsteps > 1 ? 1 : 0);           // highest mask row requested
+  if (producer) {
+    mask_issue(h_first, h_req);
+    g_issue(0, 0);
+    if (nsteps > 1) g_issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+
+  float sum[3] = {0.f, 0.f, 0.f};
+  if (producer) {
+    // ================= producer wave: one barrier per K step, like the consumers =================
+    // Step s issues the mask rows and the G tile of step s+2, then waits until only ITS OWN DMA is still in flight: everything issued in
+    // earlier steps -- what step s+1 reads -- has landed (vmcnt retires in issue order).
+    for (int s = 0; s < nsteps; ++s) {
+      int mine = 0;
+      if (s + 2 < nsteps) {
+        const int hm = hmax_of(s + 2);
+        if (hm > h_req && !(p.dbg & 1)) { mask_issue(h_req + 1, hm); mine += 6 * (hm - h_req); }
+        if (hm > h_req) h_req = hm;
+        if (!(p.dbg & 4)) { g_issue(s + 2, (s + 2) % SG_GBUFS); mine += 16; }      // that buffer was last read in step s-1
+      }
+      if (mine >= 28) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
+      else if (mine >= 22) asm volatile("s_waitcnt vmcnt(22)\n\ts_barrier" ::: "memory");
+      else if (mine >= 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+      else if (mine >= 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+      else if (mine >= 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  } else {
+    // ================= consumer waves: MFMA plan of this lane =================
+    // A fragments (ds_read_b64_tr_b16): lane 4q'+p' of a 16-lane group supplies row r0+q', columns 4p'..4p'+3 of the 4 x 16 block
+    int a_off[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = 8 * g + 4 * h + (i16 >> 2), pp = i16 & 3;
+        const int gsw = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+        a_off[i][h] = ((pl * 32 + row) * 8 + ((2 * (i ^ gsw)) + (pp >> 1))) * 16 + 8 * (pp & 1);
+      }
+    // B fragments: column n = 16 f + i16 -> (c, kh, kw); columns >= 147 read column 146 (their weights are zero)
+    int b_row[SG_NF], b_kh[SG_NF];
+#pragma unroll
+    for (int f = 0; f < SG_NF; ++f) {
+      int n = 16 * f + i16;
+      if (n > SG_NCOL - 1) n = SG_NCOL - 1;
+      const int c = n / 49, rem = n - c * 49, kh = rem / 7, kw = rem - kh * 7;
+      b_row[f] = q * SG_RING * SG_ROWSET + (c * 7 + kw) * SG_MROW;
+      b_kh[f] = kh;
+    }
+    int m_row = 0, m_col = g;                          // this lane group's 8-run: relative output row, 8-group column (gpr >= 4)
+    f32x4 acc[4][SG_NF];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int f = 0; f < SG_NF; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsteps; ++s) {
+      if (!(p.dbg & 2)) {
+        const char* const gb = gbuf + (s % SG_GBUFS) * SG_GTILE;
+        bf16x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + a_off[i][0]));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + a_off[i][1]));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          af[i] = __builtin_bit_cast(bf16x8, both);
+        }
+        int oh = oh_lo + m_row;
+        if (oh > oh_hi - 1) oh = oh_hi - 1;                     // padded groups: G is zero there, the address must stay on staged rows
+        const int slot0 = (2 * oh) & (SG_RING - 1);             // ring slot of input row 2*oh - 2 (tap kh = 0)
+        const char* const mb = mring + m_col * 8;
+#pragma unroll
+        for (int f = 0; f < SG_NF; ++f) {
+          const uint2 raw = *(const uint2*)(mb + ((slot0 + b_kh[f]) & (SG_RING - 1)) * SG_ROWSET + b_row[f]);
+          uint4 bw;
+          bw.x = __builtin_amdgcn_perm(0u, raw.x, 0x010c000cu);   // bytes m0, m1 -> bf16 (m0 << 8), (m1 << 8): 0x4000 = 2.0
+          bw.y = __builtin_amdgcn_perm(0u, raw.x, 0x030c020cu);
+          bw.z = __builtin_amdgcn_perm(0u, raw.y, 0x010c000cu);
+          bw.w = __builtin_amdgcn_perm(0u, raw.y, 0x030c020cu);
+          const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][f], 0, 0, 0);
+        }
+      }
+      m_col += 4;
+      if (m_col >= gpr) { m_col -= gpr; ++m_row; }
+      __syncthreads();
+    }
+    // contract the accumulators with the fp32 weights of this wave's tap kt = 2*plane + q
+    const float* const wk = p.Wf + (size_t)(2 * pl + q) * SG_NPAD * SG_CO + 4 * g;
+#pragma unroll
+    for (int f = 0; f < SG_NF; ++f) {
+      const int n = 16 * f + i16;
+      float sf = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 w = *(const float4*)(wk + (size_t)n * SG_CO + 16 * i);
+        sf += acc[i][f][0] * w.x + acc[i][f][1] * w.y + acc[i][f][2] * w.z + acc[i][f][3] * w.w;
+      }
+      // column n belongs to channel n / 49: fragments 0-2 -> 0, 3 mixed 0|1, 4-5 -> 1, 6 mixed 1|2, 7-9 -> 2 (pad columns: zero weights)
+      const int c = n < 49 ? 0 : n < 98 ? 1 : 2;
+      if (f <= 2) sum[0] += sf;
+      else if (f == 4 || f == 5) sum[1] += sf;
+      else if (f >= 7) sum[2] += sf;
+      else { sum[0] += c == 0 ? sf : 0.f; sum[1] += c == 1 ? sf : 0.f; sum[2] += c == 2 ? sf : 0.f; }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = sum[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[wave * 3 + c] = v * 0.5f;                // the mask operand was 2.0
+  }
+  __syncthreads();
+  if (tid < 6) {
+    const int qq = tid / 3, c = tid - qq * 3;
+    float v = 0.f;
+    for (int w = 0; w < 4; ++w) v += red[(qq * 4 + w) * 3 + c];   // fixed order over the taps
+    p.partials[(((size_t)b * T2 + t2) * p.nchunk + chunk) * 6 + qq * 3 + c] = v;
+  }
+}
+
+}  // namespace
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+int flk_grad_reduce_stage2_launch(const flk_apply_args* a, int nchunk, const float* partials, float* gdelta, hipStream_t s);   // attack.hip
+
+static int sg_nchunk(int B, int T, int Ho) {
+  const int pairs = B * (T / 2);
+  int n = (256 + pairs - 1) / pairs;           // one workgroup per CU when the batch fills the chip: the K loop is as long as it gets
+  if (n > 16) n = 16;
+  if (n > Ho) n = Ho;
+  if (n < 1) n = 1;
+  return n;
+}
+
+static int64_t sg_partial_bytes(int B, int T, int H) {
+  (void)H;
+  return ((int64_t)B * (T / 2) * 16 * 6 * (int64_t)sizeof(float) + 255) / 256 * 256;      // (16 = the largest chunk count)
+}
+
+// scratch = [stage-1 partials | clip mask in B-operand order: B*T*H*2352 bytes]
+extern "C" int64_t flk_stem_delta_grad_scratch_bytes(int B, int T, int H) {
+  if (B <= 0 || T <= 0 || H <= 0) return 0;
+  return sg_partial_bytes(B, T, H) + (int64_t)B * T * H * SG_ROWSET;
+}
+
+// w7: the stem's canonical weights [7][7][7][3][64] (kt,kh,kw,c,co); scale: the folded batch-norm scale per output channel.
+extern "C" int flk_stem_delta_grad_weights_create(const float* w7, const float* scale, float** out_dev) {
+  FLK_REQUIRE(w7 && scale && out_dev, "flk_stem_delta_grad_weights_create: null argument");
+  std::vector<float> h((size_t)7 * SG_NPAD * SG_CO + 256, 0.f);   // + 1 KiB of zeros: the DMA source of padded / out-of-range G pieces
+  for (int kt = 0; kt < 7; ++kt)
+    for (int kh = 0; kh < 7; ++kh)
+      for (int kw = 0; kw < 7; ++kw)
+        for (int c = 0; c < 3; ++c)
+          for (int co = 0; co < SG_CO; ++co)
+            h[((size_t)kt * SG_NPAD + c * 49 + kh * 7 + kw) * SG_CO + co] = w7[((((size_t)kt * 7 + kh) * 7 + kw) * 3 + c) * SG_CO + co] * scale[co];
+  float* d = nullptr;
+  FLK_CHECK_HIP(hipMalloc((void**)&d, h.size() * sizeof(float)));
+  FLK_CHECK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out_dev = d;
+  return FLK_OK;
+}
+
+extern "C" int flk_stem_delta_grad_weights_destroy(float* dev) {
+  if (dev) (void)hipFree(dev);
+  return FLK_OK;
+}
+
+static int sg_check(const flk_apply_args* a) {
+  FLK_REQUIRE(a && a->x && a->delta, "flk_stem_delta_grad: null argument");
+  FLK_REQUIRE(!a->delta_dense, "flk_stem_delta_grad: flicker perturbation [T,3] only (the dense attack needs the per-pixel gradient)");
+  FLK_REQUIRE(a->B > 0 && a->T >= 2 && a->T % 2 == 0 && a->H > 0 && a->H % 2 == 0 && a->W == 224,
+              "flk_stem_delta_grad: T, H must be even and W = 224 (the I3D stem; got %d, %d, %d)", a->T, a->H, a->W);
+  FLK_REQUIRE(a->lo <= a->hi, "flk_stem_delta_grad: lo > hi");
+  return FLK_OK;
+}
+
+// step 1 alone: the clip mask into the scratch (it depends on the clip and on delta only, so a caller may run it on another stream
+// while the rest of the backward pass is still busy -- flk_net_backward_delta does)
+extern "C" int flk_stem_delta_grad_mask(const flk_apply_args* a, float* scratch, void* stream) {
+  int rc = sg_check(a);
+  if (rc) return rc;
+  FLK_REQUIRE(scratch, "flk_stem_delta_grad_mask: null scratch");
+  char* const mask = (char*)scratch + sg_partial_bytes(a->B, a->T, a->H);
+  const long nrows = (long)a->B * a->T * a->H;
+  hipLaunchKernelGGL(stem_mask_kernel, dim3((unsigned)(nrows < 8192 ? nrows : 8192)), dim3(256), 0, (hipStream_t)stream, *a, mask);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+// G: bf16 [B][T/2][H/2][W/2][g_ld] = d(loss)/d(pre-ReLU stem output) (64 channels); gdelta: [T,3] fp32.  mask_done != 0: the scratch
+// already holds the mask of these arguments (flk_stem_delta_grad_mask, ordered before this call by the caller).
+extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g_ld, const float* wf_dev, float* gdelta,
+                                   float* scratch, int mask_done, void* stream) {
+  int rc = sg_check(a);
+  if (rc) return rc;
+  FLK_REQUIRE(G && wf_dev && gdelta && scratch, "flk_stem_delta_grad: null argument");
+  FLK_REQUIRE(g_ld >= SG_CO && g_ld % 8 == 0, "flk_stem_delta_grad: bad channel stride %d", g_ld);
+  StemGradKP kp{};
+  kp.G = (const char*)G; kp.g_ld = g_ld; kp.Wf = wf_dev; kp.partials = scratch;
+  kp.B = a->B; kp.T = a->T; kp.H = a->H;
+  kp.To = a->T / 2; kp.Ho = a->H / 2; kp.Wo = a->W / 2;
+  kp.mask = (const char*)scratch + sg_partial_bytes(a->B, a->T, a->H);
+  FLK_REQUIRE((size_t)a->B * kp.To * kp.Ho * kp.Wo * g_ld < (1ull << 31), "flk_stem_delta_grad: tensor too large");
+  { static const char* e = getenv("FLK_SG_DBG"); kp.dbg = e ? atoi(e) : 0; }
+  kp.nchunk = sg_nchunk(a->B, a->T, kp.Ho);
+  { static const char* e = getenv("FLK_SG_NCHUNK"); if (e && atoi(e) > 0) kp.nchunk = atoi(e) < 16 ? atoi(e) : 16; }
+  kp.rows_per_chunk = (kp.Ho + kp.nchunk - 1) / kp.nchunk;
+  kp.nchunk = (kp.Ho + kp.rows_per_chunk - 1) / kp.rows_per_chunk;       // no empty chunks
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_delta_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS));
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (!mask_done && (rc = flk_stem_delta_grad_mask(a, scratch, stream))) return rc;
+  hipLaunchKernelGGL(stem_delta_grad_kernel, dim3((unsigned)(a->B * kp.To * kp.nchunk)), dim3(SG_THREADS), SG_LDS, s, kp);
+  FLK_CHECK_HIP(hipGetLastError());
+  flk_apply_args a2 = *a;
+  a2.fold_t = 2;                                       // stage 2 reads the partials as (frame pair, parity)
+  return flk_grad_reduce_stage2_launch(&a2, kp.nchunk, scratch, gdelta, s);
+}

@@ -103,8 +103,11 @@ class FlickerI3D:
         self._logits = torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev)
         # [g_adv (T*3) | adv loss sum | sum to_min_prob | sum to_max_prob]: ONE all-reduce payload
         self._red = torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev)
-        self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4),
+        self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4,
+                                        ops.load().flk_stem_delta_grad_scratch_bytes(self.B, self.T, self.H) // 4),
                                     dtype=torch.float32, device=dev)
+        # flicker perturbation in bf16: the stem's data-gradient and the (b,h,w) reduction run as ONE MFMA kernel (csrc/stem_grad.hip)
+        self.fused_delta_grad = (not dense_delta) and self.net.has_backward_delta
         self._scalars = torch.empty(8, dtype=torch.float32, device=dev)
         # result slots: [payload | softmax | per-clip table | scalars] written by the kernels, rotated per iteration
         self._slots = [dict(payload=torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev),
@@ -189,9 +192,12 @@ class FlickerI3D:
         gbatch = self.B * self.world
         ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
                              targeted=targeted, margin=margin, mean_scale=1.0 / gbatch, out=(sm, self._dl, pc))
-        self.net.backward(self._dl, self._gx)
         n = self.T * 3
-        ops.perturb_grad_reduce(a, self._gx, red[:n].view(self.T, 3), self._scratch)
+        if self.fused_delta_grad:
+            self.net.backward_delta(self._dl, a, red[:n], self._scratch)
+        else:
+            self.net.backward(self._dl, self._gx)
+            ops.perturb_grad_reduce(a, self._gx, red[:n].view(self.T, 3), self._scratch)
         ops.pack_batch_sums(pc, 1.0 / gbatch, red[n:])                 # [sum adv | mean label prob | mean max-other prob]
         parallel.allreduce_sum_(red, self.pg)                          # RCCL over xGMI: (T*3+3) floats
         p_lab, p_non = red[n + 1], red[n + 2]

@@ -184,6 +184,37 @@ def perturb_grad_reduce(args, gx_s2d, gdelta=None, scratch=None):
     return gdelta
 
 
+class StemDeltaGradWeights:
+    """fp32 weights of flk_stem_delta_grad: canonical stem weights [7,7,7,3,64] x folded batch-norm scale [64]"""
+
+    def __init__(self, w7_dhwio, bn_scale):
+        w = np.ascontiguousarray(w7_dhwio, dtype=np.float32)
+        sc = np.ascontiguousarray(bn_scale, dtype=np.float32)
+        assert w.shape == (7, 7, 7, 3, 64) and sc.shape == (64,)
+        h = C.c_void_p()
+        check(load().flk_stem_delta_grad_weights_create(ptr(w), ptr(sc), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().flk_stem_delta_grad_weights_destroy(self.handle)
+                self.handle = None
+        except Exception:      # interpreter shutdown
+            pass
+
+
+def stem_delta_grad(args, G, weights, gdelta=None, scratch=None):
+    """G: bf16 [B,T/2,H/2,W/2,ld] gradient of the stem's pre-ReLU output; returns d(loss)/d(delta) [T,3]"""
+    assert G.dtype == torch.bfloat16 and G.is_contiguous() and G.dim() == 5
+    if gdelta is None:
+        gdelta = torch.empty((args.T, 3), dtype=torch.float32, device="cuda")
+    if scratch is None:
+        scratch = torch.empty(max(1, load().flk_stem_delta_grad_scratch_bytes(args.B, args.T, args.H) // 4), dtype=torch.float32, device="cuda")
+    check(load().flk_stem_delta_grad(C.byref(args), ptr(G), G.shape[4], weights.handle, ptr(gdelta), ptr(scratch), 0, stream_ptr()))
+    return gdelta
+
+
 def perturb_reg_adam(g_adv, delta, m, v, step, *, dialect="tf", beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5,
                      dyn_max_norm=0.0, g_scale=1.0, lr=1e-3, adam=(0.9, 0.999, 1e-8), scalars=None):
     a = AdamArgs()
@@ -298,6 +329,18 @@ class Net:
             gx = torch.empty(self.input_numel, dtype=torch_dtype(self.dtype), device="cuda")
         check(load().flk_net_backward(self.handle, ptr(dlogits), ptr(gx), stream_ptr()))
         return gx
+
+    @property
+    def has_backward_delta(self):
+        """the fused stem delta-gradient (csrc/stem_grad.hip) is available: I3D plan, bf16 (FLK_STEM_FUSED=0 switches it off)"""
+        return bool(load().flk_net_has_backward_delta(self.handle))
+
+    def backward_delta(self, dlogits, apply_args, gdelta, scratch):
+        """backward straight to the flickering perturbation [T,3]: no per-pixel input gradient is materialised"""
+        assert gdelta.dtype == torch.float32 and gdelta.is_contiguous() and gdelta.numel() == 3 * self.T
+        assert scratch.numel() * 4 >= load().flk_stem_delta_grad_scratch_bytes(self.B, self.T, self.H)
+        check(load().flk_net_backward_delta(self.handle, ptr(dlogits), C.byref(apply_args), ptr(gdelta), ptr(scratch), stream_ptr()))
+        return gdelta
 
     def autotune(self, x, logits, dlogits, gx):
         """tune the launch layout of every convolution of the plan on these operands (one serial forward + backward)"""

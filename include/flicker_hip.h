@@ -160,6 +160,22 @@ int64_t flk_perturb_grad_scratch_bytes(int B, int T, int H, int W);
 int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s2d, int dtype,
                             float* gdelta, float* partials, void* stream);
 
+/* Fused form of (stem data-gradient + flk_perturb_grad_reduce) for the flickering perturbation of I3D: d(loss)/d(delta[t,c]) straight
+ * from G = d(loss)/d(pre-ReLU output of Conv3d_1a_7x7) (bf16 [B,T/2,H/2,W/2,g_ld], 64 channels) -- replaces Conv3DBackpropInputV2 of
+ * i3d.py:169 and the clip_by_value / reduce_sum gradients of kinetics_i3d_utils.py:100-142 with ONE MFMA kernel in the weight-gradient
+ * form (csrc/stem_grad.hip): the per-pixel gradient is never materialised.  `a` are the arguments the clip was applied with (its
+ * clip / roll / 1/std semantics define the mask); wf_dev comes from flk_stem_delta_grad_weights_create (the canonical
+ * [7,7,7,3,64] stem weights x the folded batch-norm scale, fp32); scratch: flk_stem_delta_grad_scratch_bytes() of caller scratch
+ * (stage-1 partials + the clip mask in the GEMM's operand order, 2352 bytes per clip row).  Two launches: the mask pre-pass (HBM-bound;
+ * mask_done != 0 skips it when flk_stem_delta_grad_mask already ran for the same arguments) and the GEMM.
+ * Deterministic (fixed summation order); bf16 gradients only -- the fp32 parity mode keeps the two-kernel path. */
+int64_t flk_stem_delta_grad_scratch_bytes(int B, int T, int H);
+int flk_stem_delta_grad_weights_create(const float* w7_dhwio, const float* bn_scale, float** out_dev);
+int flk_stem_delta_grad_weights_destroy(float* dev);
+int flk_stem_delta_grad_mask(const flk_apply_args* a, float* scratch, void* stream);   /* step 1 alone (clip mask; needs x and delta only) */
+int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g_ld, const float* wf_dev, float* gdelta,
+                        float* scratch, int mask_done, void* stream);
+
 /* Tail of the data-parallel payload (flickering_adversarial_video_amd/parallel.py; replaces the per-iteration
  * reduce_sum / reduce_mean fetches of i3d_adversarial_main_single_video_npy.py:213-217): from the per-clip
  * outputs of flk_softmax_adv_loss ([B,4] = loss, p_label, p_max_other, argmax)
@@ -239,6 +255,11 @@ int64_t flk_net_workspace_bytes(const flk_net* n);
 int flk_net_forward(flk_net* n, const void* x_in, float* logits, int save_for_backward, void* stream);
 /* dlogits fp32 [B,C] -> gradient w.r.t. the network input (same layout/dtype as x_in) */
 int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream);
+/* backward straight to the flickering perturbation: the plan without the stem's data-gradient, then flk_stem_delta_grad on the
+ * stem's output gradient.  gdelta fp32 [T,3]; scratch: flk_stem_delta_grad_scratch_bytes(B, T, H).  I3D in bf16 only
+ * (flk_net_has_backward_delta() tells); `a` = the flk_apply_args the clip of this forward pass was applied with. */
+int flk_net_has_backward_delta(const flk_net* n);
+int flk_net_backward_delta(flk_net* n, const float* dlogits, const flk_apply_args* a, float* gdelta, float* scratch, void* stream);
 /* per-layer HIP-event timing of the next forward/backward (bench.py roofline leg).  While enabled the plan runs serially on
  * the caller's stream (normally independent Inception branches run on parallel streams; FLK_SINGLE_STREAM=1 disables that). */
 int flk_net_profile(flk_net* n, int enable);

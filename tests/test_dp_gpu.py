@@ -188,9 +188,11 @@ def test_dense_delta_two_ranks_equal_one_process():
         g, d, adv, l12 = got[rk]
         np.testing.assert_allclose(g, ref[0], rtol=1e-4, atol=1e-5 * np.abs(ref[0]).max())
         assert adv == pytest.approx(ref[2], rel=1e-5) and l12 == pytest.approx(ref[3], rel=1e-6)
-        # first Adam step = lr * sign(g): identical wherever the gradient is not within rounding of zero
-        big = np.abs(ref[0]) > 1e-3 * np.abs(ref[0]).max()
-        np.testing.assert_allclose(d[big], ref[1][big], rtol=1e-4, atol=1e-9)
+        # first TF-Adam step = lr * g / (|g| + eps / sqrt(1 - b2)): where |g| is comparable to that epsilon term the 1e-5 * max|g|
+        # summation-order differences of g show at the percent level, so delta is compared at 2 % of the step size
+        np.testing.assert_allclose(d, ref[1], rtol=0, atol=2e-5)
+        big = np.abs(ref[0]) > 1e-2 * np.abs(ref[0]).max()
+        np.testing.assert_allclose(d[big], ref[1][big], rtol=2e-3, atol=0)
     np.testing.assert_array_equal(got[0][1], got[1][1])                    # replicas stay bitwise identical
 
 

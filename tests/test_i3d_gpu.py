@@ -280,31 +280,6 @@ def test_attack_trajectory_well_conditioned():
     assert fooled_at["hip"] == fooled_at["oracle"]          # same iteration-to-fool (None: not fooled within the 6 steps)
 
 
-def test_bf16_attack_equivalent_to_fp32_well_conditioned():
-    """bf16 (the benchmarked dtype) on the well-conditioned fixture: the SAME attack as fp32 -- loss curve within 3 %, learned delta
-    within 5 % of its maximum after every one of 12 iterations, identical iteration-to-fool."""
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
-    W, Wt, xu = _coherent_fixture()
-    label = torch.tensor([233]).cuda()
-    out = {}
-    for dt in ("f32", "bf16"):
-        eng = FlickerI3D(W, batch_size=1, frames=T, dtype=dt)
-        rows = []
-        for it in range(12):
-            r = eng.step(xu.cuda(), label).host()
-            rows.append((float(r["adv_loss"]), eng.perturbation.cpu().clone(), bool(r["is_adversarial"])))
-        out[dt] = rows
-        del eng
-    for it, ((l32, d32, a32), (l16, d16, a16)) in enumerate(zip(out["f32"], out["bf16"])):
-        e = rel_err(d16, d32)
-        print(f"iter {it + 1}: adv f32 {l32:.6f} bf16 {l16:.6f}; delta max-rel {e:.3e}; adversarial {a32} / {a16}")
-        assert l16 == pytest.approx(l32, rel=3e-2, abs=2e-3) and e < 5e-2
-    first = lambda rows: next((i for i, r_ in enumerate(rows) if r_[2]), None)
-    assert first(out["f32"]) == first(out["bf16"])
-
-
 def test_evaluate_fooling_rate_vs_oracle():
     """FlickerI3D.evaluate = kinetics_i3d.evaluate (kinetics_i3d_utils.py:217-250): the integer counts (fooled AND clean-correct,
     clean-correct) over an iterator of batches must equal the reference formula applied to the ORACLE's predictions, for the

@@ -326,3 +326,84 @@ def test_conv_two_segment_output_and_input(ops, dtype):
     gx = ops.conv3d(gA.to(dtype).cuda(), pb, in_coff=8, cin=c0 + c1, in2=gB.to(dtype).cuda(), in2_coff=0)
     r, a = tol(dtype, gx_ref)
     torch.testing.assert_close(gx.float().cpu(), gx_ref, rtol=r * 2, atol=a * 2)
+
+
+@pytest.mark.parametrize("case", ["u8", "f32_torch_dialect", "cyclic_u8"])
+def test_stem_delta_grad_fused(case):
+    """flk_stem_delta_grad (csrc/stem_grad.hip): d(loss)/d(delta[t,c]) in ONE kernel from the stem's output gradient G -- against
+    fp64 torch-CPU: gx = conv_transpose3d(G, W * bn_scale) (the data-gradient of the 7x7x7 / 2 SAME convolution, i3d.py:169), masked by
+    the clip of the perturbed clip and summed over (b,h,w) (kinetics_i3d_utils.py:100-142).  G is bf16 on both sides, weights fp32."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.nn.functional as F
+    from flickering_adversarial_video_amd import ops
+    from oracle import attack_math as am
+    rng = np.random.default_rng(17)
+    B, T, H, W = 2, 8, 224, 224
+    To, Ho, Wo = T // 2, H // 2, W // 2
+    w7 = (rng.standard_normal((7, 7, 7, 3, 64)) * 0.05).astype(np.float32)
+    scale = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    G = torch.from_numpy(rng.standard_normal((B, To, Ho, Wo, 64)).astype(np.float32)).to(torch.bfloat16)
+    G[:, :, 5:9] = 0                                   # some structure: zero rows, one strong row
+    G[:, :, 40] *= 8
+    delta = rng.uniform(-0.5, 0.5, (T, 3)).astype(np.float32)       # some entries beyond the +-0.4 clip
+    if case == "f32_torch_dialect":
+        x = torch.from_numpy(rng.uniform(-2.2, 2.9, (B, T, H, W, 3)).astype(np.float32))    # beyond [min_v, max_v] on both sides
+        kw = dict(dialect="torch", dclip=0.2, inv_std=tuple(1.0 / s for s in am.DEFAULT_STD), lo=am.TORCH_MIN_VALUE, hi=am.TORCH_MAX_VALUE)
+        xf = x.double()
+    else:
+        xu = torch.from_numpy(rng.integers(0, 256, (B, T, H, W, 3), dtype=np.uint8))
+        xu[:, :, :, :20] = 0                            # dark / bright bands: pixels that saturate as soon as delta has the right sign
+        xu[:, :, :, 200:] = 255
+        x = xu
+        kw = dict(dialect="tf", dclip=0.4)
+        xf = xu.double() / 128 - 1
+    sx, sp = (3, 5) if case == "cyclic_u8" else (0, 0)
+    args = ops.make_apply_args(x.cuda(), torch.from_numpy(delta).cuda(), shift_x=sx, shift_p=sp, fold_t=ops.I3D_FOLD, **kw)
+    wts = ops.StemDeltaGradWeights(w7, scale)
+    got = ops.stem_delta_grad(args, G.cuda(), wts).cpu().double()
+    # ---- reference ----
+    d = torch.from_numpy(delta).double().requires_grad_(True)
+    dc = d.clamp(-kw["dclip"], kw["dclip"]) * torch.tensor(kw.get("inv_std", (1.0, 1.0, 1.0)), dtype=torch.float64)
+    xr = torch.roll(xf, sx, 1) if sx else xf
+    pr = torch.roll(dc, sp, 0) if sp else dc
+    xa = (xr + pr.view(1, T, 1, 1, 3)).clamp(kw.get("lo", -1.0), kw.get("hi", 1.0))
+    wt = torch.from_numpy(w7 * scale).double().permute(4, 3, 0, 1, 2).contiguous()           # [co, c, kt, kh, kw]
+    xp = F.pad(xa.permute(0, 4, 1, 2, 3), (2, 3, 2, 3, 2, 3))                                 # TF SAME for k 7, s 2 on even sizes
+    y = F.conv3d(xp, wt, None, stride=2)                                                      # [B,64,To,Ho,Wo]
+    (ref,) = torch.autograd.grad(y, d, grad_outputs=G.double().permute(0, 4, 1, 2, 3))
+    err = float((got - ref).abs().max() / ref.abs().max())
+    print(f"[{case}] fused stem delta-gradient: max-rel {err:.2e} (|ref| max {float(ref.abs().max()):.3e})")
+    assert err < 2e-5
+    clipped = torch.from_numpy(np.abs(delta) > kw["dclip"])
+    assert clipped.any() and float(got[clipped].abs().max()) == 0.0
+
+
+def test_stem_delta_grad_in_engine():
+    """the I3D engine's bf16 step with the fused kernel (default) against the two-kernel path (FLK_STEM_FUSED=0 semantics via
+    net.backward + perturb_grad_reduce): same G, so the two delta-gradients differ only by the bf16 rounding of the data-gradient
+    weights and of gx -- and the learned delta after 3 steps stays within 2 %."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec, ops
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    T, B = 16, 2
+    W = i3d_spec.synthetic_i3d_weights(42)
+    x = torch.from_numpy(i3d_spec.synthetic_clip_u8(B, T, seed=8)).cuda()
+    eng = FlickerI3D(W, batch_size=B, frames=T, dtype="bf16")
+    assert eng.fused_delta_grad and eng.net.has_backward_delta
+    labels = eng.logits(x, adv_flag=0.0).argmax(-1).clone()
+    eng.reset_perturbation(np.random.default_rng(1).uniform(-0.45, 0.45, (T, 3)).astype(np.float32))
+    r = eng.step(x, labels, update=False)
+    g_fused = eng.delta_gradient().clone()
+    eng.fused_delta_grad = False
+    eng.step(x, labels, update=False)
+    g_two = eng.delta_gradient().clone()
+    e = float((g_fused - g_two).abs().max() / g_two.abs().max())
+    cos = float(torch.nn.functional.cosine_similarity(g_fused.flatten(), g_two.flatten(), 0))
+    print(f"fused vs two-kernel delta-gradient: max-rel {e:.2e}, cosine {cos:.6f}")
+    assert e < 2e-2 and cos > 0.9999
+    assert bool((g_fused[eng.eps_rgb.abs() > 0.4] == 0).all())
+    # fp32 engines and dense perturbations keep the two-kernel path
+    assert not FlickerI3D(W, batch_size=1, frames=T, dtype="f32").fused_delta_grad
+    assert not FlickerI3D(W, batch_size=1, frames=T, dtype="bf16", dense_delta=True).fused_delta_grad

@@ -65,14 +65,17 @@ def test_videoresnet_forward_backward(arch):
         assert float(res["adv_loss"]) == pytest.approx(r32["adv"], rel=1e-3 if f32 else 1e-1, abs=1e-5)
         # ---- backward, link by link (see tests/test_i3d_gpu.py): stem <- layer1.0 <- ... <- layer4.1 <- logits ----
         Wd = {k: (torch.from_numpy(v).to(torch.bfloat16).double() if (not f32 and v.ndim == 5) else torch.from_numpy(v).double()) for k, v in W.items()}
-        FWD_TOL, BWD_TOL, BWD_FRAC, BWD_L2 = (1e-4, 1e-3, 1e-3, 1e-2) if f32 else (3e-2, 5e-2, 2e-2, 5e-2)
+        # (bf16: this oracle rounds the block ENDPOINTS to bf16 only; the HIP path also stores the activations inside a block in
+        # bf16 -- the (2+1)D mid tensors of r2plus1d_18 above all: measured rel-L2 4e-2 there, 3.5e-3 for r3d_18 / mc3_18;
+        # fp32: measured 1e-6, with up to 7e-4 of the elements of two r2plus1d_18 links next to a flipped ReLU decision)
+        FWD_TOL, BWD_TOL, BWD_FRAC, BWD_L2 = (1e-4, 1e-3, 3e-3, 1e-2) if f32 else (3e-2, 5e-2, 2e-2, 8e-2)
         hip_act = lambda n: torch.from_numpy(eng.net.activation(n)).permute(0, 4, 1, 2, 3).contiguous().double()
         links = [("stem", lambda x, fr: vr.stem(x, Wd, arch, fr))]
         links += [(n, lambda x, fr, a=(n, kind, st, ds): vr.basic_block(x, Wd, a[0], a[1], a[2], a[3], fr)) for n, kind, st, ds in vr.blocks(arch)]
         links.append(("logits", lambda x, fr: torch.nn.functional.linear(x.mean(dim=(2, 3, 4)), Wd["fc.weight"], Wd["fc.bias"])))
         d0 = delta.double().clone().requires_grad_(True)
         xa = am.torch_apply(x_cl.double().permute(0, 4, 1, 2, 3).contiguous(), d0, 0.2)
-        prev_name, prev = "delta", (xa.to(torch.bfloat16).double() + (xa - xa.detach())) if not f32 else xa     # bf16: stored input, straight-through
+        prev_name, prev = "delta", (xa.detach().to(torch.bfloat16).double() + (xa - xa.detach())) if not f32 else xa     # bf16: stored input, straight-through
         for name, fn in links:
             with torch.no_grad():
                 out = fn(prev, True)
@@ -183,7 +186,7 @@ def test_videoresnet_dense_l12_attack():
     logits = vr.videoresnet_logits(xa, Wd, arch)
     label = logits.argmax(-1)
     loss, adv, reg = am.torch_losses(label, logits, torch.softmax(logits, 1), d0.clamp(-0.2, 0.2), 0.5, 0.7, 0.05, True, True, "L12")
-    (gtot,) = torch.autograd.grad(loss, d0)
+    (gtot,) = torch.autograd.grad(loss, d0, retain_graph=True)
     r = eng.step(x_cl.cuda(), label.cuda(), crit, lr=1e-3)
     assert float(r["adv_loss"]) == pytest.approx(adv.item(), rel=1e-3, abs=1e-6)
     assert float(r["reg_loss"]) == pytest.approx(reg.item(), rel=1e-4)
