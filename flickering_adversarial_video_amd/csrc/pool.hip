@@ -396,6 +396,130 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd_bf16(const PoolTP
   }
 }
 
+// W-run form of the bf16 3x3x3 forward: a thread owns one (t, h) of the tile, 8 channels and the whole run of WT outputs along w.  The
+// 9-tap maximum over (dt, dh) of a halo column is computed ONCE and shared by the three outputs whose windows contain it -- (WT+2) * 9
+// element-taps per WT outputs instead of WT * 27 (2.1x fewer VALU operations at WT = 7; the pool is VALU-bound).  Tie rule unchanged:
+// the column stage tags a candidate with 255 - 3*(3 dt + dh), the combine stage subtracts dw, so the low byte is 255 - tap and the
+// larger one (first maximum in scan order) wins among equal keys.
+template <int WT>
+__global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP p) {
+  constexpr int EPL = 8, SLABC = 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const PoolKP& k = p.k;
+  const int tid = threadIdx.x, ch = tid & 3;
+  int bid, cslab;
+  if (!tile_slab_of_block(p.ntiles, p.nslab, bid, cslab)) return;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int c0 = cslab * SLABC + ch * EPL;
+  const bool chvalid = c0 < k.C;
+  const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * WT;
+  const int it0 = ot0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
+  const int HW = p.Hh * p.Wh;
+  for (int hp = tid >> 2; hp < p.P; hp += 64) {
+    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+    const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
+    uint4 v = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);     // -inf
+    if (chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi)
+      v = *(const uint4*)(k.in + ((((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw) * k.in_ld + k.in_coff + c0) * 2);
+    v.x = bf16x2_to_keys(v.x); v.y = bf16x2_to_keys(v.y); v.z = bf16x2_to_keys(v.z); v.w = bf16x2_to_keys(v.w);
+    *(uint4*)(smem + pplane_off(ch, p.plane_b) + hp * 16) = v;
+  }
+  __syncthreads();
+  if (!chvalid) return;
+  const int npairs = p.Tt * p.Ht;
+  for (int pr = tid >> 2; pr < npairs; pr += 64) {
+    const int rt = pr / p.Ht, rh = pr - rt * p.Ht;
+    const int ot = ot0 + rt, oh = oh0 + rh;
+    if (ot >= k.To || oh >= k.Ho) continue;
+    const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * p.Wh) * 16;
+    uint32_t cm[3][8];
+    auto colmax = [&](int c, uint32_t (&m)[8]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m[e] = 0;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) {
+          const uint32_t tag = 255u - 3u * (uint32_t)(dt * 3 + dh);
+          const uint4 v = *(const uint4*)(base + ((dt * p.Hh + dh) * p.Wh + c) * 16);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            m[2 * i] = max(m[2 * i], (w[i] << 16) | tag);
+            m[2 * i + 1] = max(m[2 * i + 1], (w[i] & 0xffff0000u) | tag);
+          }
+        }
+    };
+    colmax(0, cm[0]);
+    colmax(1, cm[1]);
+#pragma unroll
+    for (int rw = 0; rw < WT; ++rw) {
+      colmax(rw + 2, cm[(rw + 2) % 3]);
+      const int ow = ow0 + rw;
+      if (ow >= k.Wo) continue;
+      const uint32_t (&l)[8] = cm[rw % 3];
+      const uint32_t (&m)[8] = cm[(rw + 1) % 3];
+      const uint32_t (&r)[8] = cm[(rw + 2) % 3];
+      uint32_t best[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best[e] = max(max(l[e], m[e] - 1u), r[e] - 2u);
+      uint4 o;
+      o.x = keys_to_bf16x2((best[0] >> 16) | (best[1] & 0xffff0000u));
+      o.y = keys_to_bf16x2((best[2] >> 16) | (best[3] & 0xffff0000u));
+      o.z = keys_to_bf16x2((best[4] >> 16) | (best[5] & 0xffff0000u));
+      o.w = keys_to_bf16x2((best[6] >> 16) | (best[7] & 0xffff0000u));
+      if (k.relu_input) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if ((best[e] >> 16) <= 0x8000u) best[e] &= ~255u;      // tag 0 -> idx 255 ("no cell")
+      }
+      uint2 id;
+      id.x = (255u - (best[0] & 255u)) | ((255u - (best[1] & 255u)) << 8) | ((255u - (best[2] & 255u)) << 16) | ((255u - (best[3] & 255u)) << 24);
+      id.y = (255u - (best[4] & 255u)) | ((255u - (best[5] & 255u)) << 8) | ((255u - (best[6] & 255u)) << 16) | ((255u - (best[7] & 255u)) << 24);
+      const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+      *(uint4*)(k.out + (opos * k.out_ld + k.out_coff + c0) * 2) = o;
+      *(uint2*)(k.idx + opos * k.C + c0) = id;
+    }
+  }
+}
+
+// tile of the W-run kernel: WT outputs along w, (Tt, Ht) with Tt*Ht <= 64 (one (t,h) pair per thread quad) and a halo <= 1008 positions
+template <int WT>
+static int launch_wrun_fwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t s) {
+  PoolTP tp{};
+  tp.k = kp;
+  int bestT = 1, bestH = 1; double bestScore = -1.0;
+  for (int Tt = 1; Tt <= a->To && Tt <= 8; ++Tt)
+    for (int Ht = 1; Ht <= a->Ho && Tt * Ht <= 64; ++Ht) {
+      const long halo = (long)(Tt + 2) * (Ht + 2) * (WT + 2);
+      if (halo > FLK_MAX_HALO) continue;
+      const long tiles = (long)((a->To + Tt - 1) / Tt) * ((a->Ho + Ht - 1) / Ht);
+      // useful outputs per staged halo position, discounted by idle thread quads (pairs < 64) and ragged edge tiles
+      const double eff = (double)a->To * a->Ho / ((double)tiles * Tt * Ht);
+      const double score = eff * (double)(Tt * Ht * WT) / (double)halo * (Tt * Ht >= 48 ? 1.0 : (double)(Tt * Ht) / 48.0);
+      if (score > bestScore) { bestScore = score; bestT = Tt; bestH = Ht; }
+    }
+  tp.Tt = bestT; tp.Ht = bestH; tp.Wt = WT; tp.rows = bestT * bestH * WT;
+  tp.nTt = (a->To + tp.Tt - 1) / tp.Tt; tp.nTh = (a->Ho + tp.Ht - 1) / tp.Ht; tp.nTw = (a->Wo + WT - 1) / WT;
+  tp.Th = tp.Tt + 2; tp.Hh = tp.Ht + 2; tp.Wh = WT + 2;
+  tp.P = tp.Th * tp.Hh * tp.Wh;
+  tp.plane_b = (tp.P * 16 + 255) / 256 * 256;
+  const size_t lds = 4 * (size_t)tp.plane_b + 64;
+  tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
+  const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
+  static bool attr_set = false;
+  if (!attr_set) {
+    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_wrun_fwd_bf16<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((maxpool_s1_wrun_fwd_bf16<WT>), grid, dim3(256), lds, s, tp);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_bwd(const PoolTP p) {
   constexpr int EPL = PV<T>::EPL, SLABC = 4 * EPL;
@@ -658,7 +782,9 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
     attr_set = true;
   }
   if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
-  else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
+  else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3 && a->pt == 1 && a->ph == 1 && a->pw == 1 && !getenv("FLK_POOL_NO_WRUN")) {
+    return a->Wo % 7 == 0 ? launch_wrun_fwd<7>(kp, a, s) : launch_wrun_fwd<8>(kp, a, s);
+  } else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
     static bool attr2 = false;
     if (!attr2) {
       FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_fwd_bf16<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

@@ -3,7 +3,7 @@
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM): both counters are in KiB; FETCH_SIZE reports exactly 1/2 of the bytes of wide
 coalesced streaming reads (16 B per lane: every global access of these kernels) -> doubled; WRITE_SIZE is exact for 16-byte
-stores.  Usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [steps_equivalent]"""
+stores.  Usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [state label, e.g. the git commit]"""
 import collections, csv, json, sys
 
 def agg(path, counter):
@@ -18,7 +18,8 @@ def agg(path, counter):
     return d
 
 f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
-out = {"note": "bytes = 2*FETCH_SIZE*1024 (gfx950 half-count correction) + WRITE_SIZE*1024; separate --pmc passes of "
+out = {"state": sys.argv[4] if len(sys.argv) > 4 else "unknown",
+       "note": "bytes = 2*FETCH_SIZE*1024 (gfx950 half-count correction) + WRITE_SIZE*1024; separate --pmc passes of "
                "`bench.py --steps 2 --warmup 1` (3 iterations + 1 label forward)", "kernels": {}}
 for k in sorted(f, key=lambda k: -f[k][1]):
     launches = f[k][0]
