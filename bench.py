@@ -120,9 +120,11 @@ def parity_check(device):
     x64 = xu.double() / 128 - 1
     label = i3d_ref.i3d_logits(x64, W64).argmax(-1)
     eng = FlickerI3D(Wc, batch_size=1, frames=T, dtype="f32", device=device)
+    eng16 = FlickerI3D(Wc, batch_size=1, frames=T, dtype="bf16", device=device)     # the timed mode, same trajectory, stated tolerance 5e-2
     d = torch.zeros(T, 1, 1, 3, dtype=torch.float64)
     m, v = torch.zeros_like(d), torch.zeros_like(d)
     e_delta = e_logits = e_adv = 0.0
+    b_delta = b_logits = b_adv = 0.0
     for it in range(1, 4):
         dv = d.clone().requires_grad_(True)
         lg = i3d_ref.i3d_logits(am.tf_apply(x64, dv), W64)
@@ -134,12 +136,19 @@ def parity_check(device):
         e_logits = max(e_logits, rel(eng._logits.cpu(), lg.detach()))
         e_adv = max(e_adv, abs(float(r["adv_loss"]) - adv.item()) / abs(adv.item()))
         e_delta = max(e_delta, rel(eng.perturbation.cpu(), d))
+        r = eng16.step(xu.cuda(), label.cuda(), lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05)
+        b_logits = max(b_logits, rel(eng16._logits.cpu(), lg.detach()))
+        b_adv = max(b_adv, abs(float(r["adv_loss"]) - adv.item()) / abs(adv.item()))
+        b_delta = max(b_delta, rel(eng16.perturbation.cpu(), d))
+    out["bf16_well_conditioned_fixture"] = {"iterations": 3, "tolerance": 5e-2, "delta_rel_err": b_delta, "logits_rel_err": b_logits,
+                                            "adv_loss_rel_err": b_adv, "exact_delta_forward": bool(eng16.exact_delta_forward)}
+    del eng16
     out["well_conditioned_fixture"] = {"iterations": 3, "delta_rel_err": e_delta, "logits_rel_err": e_logits, "adv_loss_rel_err": e_adv,
                                        "reference": "fp64 oracle trajectory"}
     del eng
     torch.cuda.empty_cache()
     errs = list(out["noise_weights"].values()) + [e_delta, e_logits, e_adv]
-    out["ok"] = bool(max(errs) < 1e-3)
+    out["ok"] = bool(max(errs) < 1e-3 and max(b_delta, b_logits, b_adv) < 5e-2)
     out["seconds"] = time.time() - t0
     return out
 

@@ -30,7 +30,8 @@ class ConvArgs(C.Structure):
                 ("mask", C.c_void_p), ("mask_ld", C.c_int), ("mask_coff", C.c_int),
                 ("relu", C.c_int),
                 ("in2", C.c_void_p), ("in2_ld", C.c_int), ("in2_coff", C.c_int), ("cin1", C.c_int),
-                ("out2", C.c_void_p), ("out2_ld", C.c_int), ("out2_coff", C.c_int), ("cout1", C.c_int)]
+                ("out2", C.c_void_p), ("out2_ld", C.c_int), ("out2_coff", C.c_int), ("cout1", C.c_int),
+                ("pos_bias", C.c_void_p)]
 
 
 class PoolArgs(C.Structure):
@@ -50,7 +51,7 @@ class ApplyArgs(C.Structure):
                 ("dclip", C.c_float), ("inv_std", C.c_float * 3),
                 ("lo", C.c_float), ("hi", C.c_float), ("adv_flag", C.c_float),
                 ("shift_x", C.c_int), ("shift_p", C.c_int),
-                ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("fold_t", C.c_int)]
+                ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("fold_t", C.c_int), ("center", C.c_int)]
 
 
 class AdamArgs(C.Structure):
@@ -101,6 +102,10 @@ _SIGS = {
     "flk_net_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "flk_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_net_has_forward_flicker": (C.c_int, [C.c_void_p]),
+    "flk_net_forward_flicker": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p]),
+    "flk_stem_delta_bias_weights_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "flk_stem_delta_bias": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_net_has_backward_delta": (C.c_int, [C.c_void_p]),
     "flk_net_backward_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_stem_delta_grad_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

@@ -68,6 +68,13 @@ __device__ static inline void load6(const flk_apply_args& a, size_t off, float* 
 }
 
 __device__ static inline float clipf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+// value written for a pixel x with perturbation pv: the clipped sum, or (flk_apply_args.center) the sum minus pv -- i.e. x itself
+// wherever the clip is inactive
+__device__ static inline float applied(const flk_apply_args& a, float x, float pv) {
+  const float u = x + pv;
+  if (!a.center) return clipf(u, a.lo, a.hi);
+  return (u < a.lo || u > a.hi) ? clipf(u, a.lo, a.hi) - pv : x;
+}
 __device__ static inline int wrap(int t, int T) { t %= T; return t < 0 ? t + T : t; }
 
 // perturbation added at frame t (before adv_flag): p'[t] = p[(t - shift_p) mod T] (tf.roll), p = clip(delta)/std
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float pv = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, t, h, 2 * w2 + qw, c) : 0.f;
-            v[S2D<FTL>::ch(qt, qh, qw * 3 + c)] = clipf(x[qw * 3 + c] + pv, a.lo, a.hi);
+            v[S2D<FTL>::ch(qt, qh, qw * 3 + c)] = applied(a, x[qw * 3 + c], pv);
           }
       }
     }
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void apply_s2d_u8_flicker_kernel(const flk_app
         for (int e = 0; e < 6; ++e) {              // byte 6j + e of the 24-byte run
           const int bi = 6 * j + e;
           const float x = (float)((w[bi >> 2] >> (8 * (bi & 3))) & 255u) * a.x_scale + a.x_bias;
-          v[S2D<FTL>::ch(qt, qh, e)] = clipf(x + pv[qt][e % 3], a.lo, a.hi);
+          v[S2D<FTL>::ch(qt, qh, e)] = applied(a, x, pv[qt][e % 3]);
         }
       }
     store_ch<TO, NCH>(dst + (size_t)j * NCH * sizeof(TO), v);
@@ -171,6 +178,7 @@ static int check_apply(const flk_apply_args* a) {
   FLK_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && (a->fold_t == 1 || a->T % 2 == 0) && a->H % 2 == 0 && a->W % 2 == 0,
               "flk_perturb: H,W (and T when folded) must be positive and even (got %d,%d,%d)", a->T, a->H, a->W);
   FLK_REQUIRE(a->lo <= a->hi, "flk_perturb: lo > hi");
+  FLK_REQUIRE(!(a->center && a->delta_dense), "flk_perturb: center = 1 is defined for the flicker perturbation [T,3] only");
   return FLK_OK;
 }
 

@@ -32,6 +32,7 @@
 struct ConvKP {
   const char* in; const char* in2; const char* w; char* out; char* out2;
   const float* scale; const float* bias; const char* add; const char* mask;
+  const float* pos_bias;
   int in_ld, in_coff, cin;
   int B, Ti, Hi, Wi;
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
@@ -568,6 +569,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
     if (ot >= p.To || oh >= p.Ho || ow >= p.Wo) continue;
     const size_t opos = ((size_t)(b * p.OT + ot * p.ost + p.oot) * p.OH + oh * p.osh + p.ooh) * p.OW + ow * p.osw + p.oow;
+    const float* pb = nullptr;
+    if (p.pos_bias) {                                  // position-class bias row (flk_conv_args.pos_bias)
+      const int hc = oh == 0 ? 0 : oh == p.Ho - 1 ? 3 : oh == p.Ho - 2 ? 2 : 1;
+      const int wc = ow == 0 ? 0 : ow == p.Wo - 1 ? 3 : ow == p.Wo - 2 ? 2 : 1;
+      pb = p.pos_bias + (size_t)((ot * 4 + hc) * 4 + wc) * p.cout;
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int c0 = cbase + g * 4 * EPL;
@@ -587,6 +594,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         for (int e = 0; e < EPL; e += 4) {
           const float4 bi = *(const float4*)(p.bias + c0 + e);
           v[e] += bi.x; v[e + 1] += bi.y; v[e + 2] += bi.z; v[e + 3] += bi.w;
+        }
+      }
+      if (pb) {
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+          const float4 t4 = *(const float4*)(pb + c0 + e);
+          v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
         }
       }
       if (p.add) {
@@ -681,6 +695,8 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   ConvKP kp{};
   kp.in = (const char*)a->in; kp.w = (const char*)w->dev; kp.out = (char*)a->out;
   kp.scale = a->scale; kp.bias = a->bias; kp.add = (const char*)a->add; kp.mask = (const char*)a->mask;
+  kp.pos_bias = a->pos_bias;
+  FLK_REQUIRE(!a->pos_bias || (a->Ho >= 4 && a->Wo >= 4 && !a->out2), "flk_conv3d: pos_bias needs Ho, Wo >= 4 and a single output segment");
   kp.in_ld = a->in_ld; kp.in_coff = a->in_coff; kp.cin = a->cin;
   kp.B = a->B; kp.Ti = a->Ti; kp.Hi = a->Hi; kp.Wi = a->Wi;
   kp.kt = a->kt; kp.kh = a->kh; kp.kw = a->kw; kp.st = a->st; kp.sh = a->sh; kp.sw = a->sw;

@@ -100,6 +100,10 @@ struct flk_net {
   float* d_stem_wf = nullptr;
   int stem_dgrad_op = -1;
   Act stem_G;
+  // exact perturbation path of the stem's forward in bf16 (flk_net_forward_flicker): class sums of the weights, per-call table
+  float* d_stem_sums = nullptr;
+  float* d_stem_tab = nullptr;
+  const float* cur_pos_bias = nullptr;
   // head
   float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
   // profiling
@@ -298,7 +302,11 @@ int flk_net::build_i3d() {
     if ((rc = flk_conv_weights_create_impl(stem->w.data(), 4, 4, 4, 32, 64, stem->scale.data(), 1, dtype, choose_nf(32, 64), 0, &stem->wb))) return rc;
     if ((rc = upload(&stem->d_scale, stem->scale)) || (rc = upload(&stem->d_bias, stem->bias))) return rc;
   }
-  if (dtype == FLK_BF16 && (rc = flk_stem_delta_grad_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_wf))) return rc;
+  if (dtype == FLK_BF16) {
+    if ((rc = flk_stem_delta_grad_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_wf))) return rc;
+    if ((rc = flk_stem_delta_bias_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_sums))) return rc;
+    if ((rc = dmalloc((void**)&d_stem_tab, (size_t)(T / 2) * 16 * 64 * sizeof(float), true))) return rc;
+  }
   const int T1 = T / 2, H1 = H / 2, W1 = W / 2;
   Act xin; xin.T = T1; xin.H = H1; xin.W = W1; xin.ld = 32;       // bound per call
   Act a1, G1;
@@ -319,6 +327,7 @@ int flk_net::build_i3d() {
     const int dt = dtype;
     fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * macs, 0.0, [this, a, wf, dt](hipStream_t s) mutable {
                        a.in = x_in;
+                       a.pos_bias = cur_pos_bias;            // flk_net_forward_flicker: the perturbation enters here, in fp32
                        return flk_conv3d(&a, wf, dt, s);
                      }});
     flk_conv_args g{};
@@ -864,6 +873,7 @@ extern "C" int flk_net_destroy(flk_net* n) {
   if (n->ev_mask_fork) (void)hipEventDestroy(n->ev_mask_fork);
   if (n->ev_mask_done) (void)hipEventDestroy(n->ev_mask_done);
   flk_stem_delta_grad_weights_destroy(n->d_stem_wf);
+  flk_stem_delta_grad_weights_destroy(n->d_stem_sums);
   for (void* p : n->allocs) (void)hipFree(p);
   for (auto& L : n->convs) {
     flk_conv_weights_destroy(L->wf); flk_conv_weights_destroy(L->wb);
@@ -953,6 +963,24 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
   }
   ev_valid = n->profile;
   return FLK_OK;
+}
+
+extern "C" int flk_net_has_forward_flicker(const flk_net* n) {
+  static const bool off = getenv("FLK_STEM_CENTER") && atoi(getenv("FLK_STEM_CENTER")) == 0;
+  return n && n->finalized && n->d_stem_sums && n->d_stem_tab && !off;
+}
+
+extern "C" int flk_net_forward_flicker(flk_net* n, const void* x_in, const flk_apply_args* a, float* logits, void* stream) {
+  FLK_REQUIRE(n && n->finalized && x_in && logits && a, "flk_net_forward_flicker: bad argument / not finalized");
+  FLK_REQUIRE(n->d_stem_sums && n->d_stem_tab, "flk_net_forward_flicker: only the I3D plan in bf16 has the exact perturbation path");
+  FLK_REQUIRE(a->center == 1 && a->T == n->T && !a->delta_dense, "flk_net_forward_flicker: the clip must have been applied with center = 1 "
+              "(flicker perturbation, T = %d)", n->T);
+  int rc = flk_stem_delta_bias(a, n->d_stem_sums, n->d_stem_tab, stream);
+  if (rc) return rc;
+  n->cur_pos_bias = n->d_stem_tab;
+  rc = flk_net_forward(n, x_in, logits, 1, stream);
+  n->cur_pos_bias = nullptr;
+  return rc;
 }
 
 extern "C" int flk_net_forward(flk_net* n, const void* x_in, float* logits, int save_for_backward, void* stream) {

@@ -457,3 +457,51 @@ extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g
   a2.fold_t = 2;                                       // stage 2 reads the partials as (frame pair, parity)
   return flk_grad_reduce_stage2_launch(&a2, kp.nchunk, scratch, gdelta, s);
 }
+
+// ---- exact perturbation path of the stem's FORWARD in bf16 mode (flk_apply_args.center, flk_conv_args.pos_bias) -------------------
+// class of an output index o in [0, n): which taps k of the 7-tap / stride-2 / pad-before-2 window stay inside the frame
+//   0: o == 0 (k >= 2)   1: interior (all)   2: o == n-2 (k <= 5)   3: o == n-1 (k <= 3)
+static inline bool sb_tap_valid(int cls, int k) { return cls == 0 ? k >= 2 : cls == 2 ? k <= 5 : cls == 3 ? k <= 3 : true; }
+
+extern "C" int flk_stem_delta_bias_weights_create(const float* w7, const float* scale, float** out_dev) {
+  FLK_REQUIRE(w7 && scale && out_dev, "flk_stem_delta_bias_weights_create: null argument");
+  std::vector<float> h((size_t)7 * 16 * 3 * SG_CO, 0.f);           // [kt][hc][wc][c][co]
+  for (int kt = 0; kt < 7; ++kt)
+    for (int hc = 0; hc < 4; ++hc)
+      for (int wc = 0; wc < 4; ++wc)
+        for (int kh = 0; kh < 7; ++kh)
+          for (int kw = 0; kw < 7; ++kw) {
+            if (!sb_tap_valid(hc, kh) || !sb_tap_valid(wc, kw)) continue;
+            for (int c = 0; c < 3; ++c)
+              for (int co = 0; co < SG_CO; ++co)
+                h[((((size_t)kt * 4 + hc) * 4 + wc) * 3 + c) * SG_CO + co] += w7[((((size_t)kt * 7 + kh) * 7 + kw) * 3 + c) * SG_CO + co] * scale[co];
+          }
+  float* d = nullptr;
+  FLK_CHECK_HIP(hipMalloc((void**)&d, h.size() * sizeof(float)));
+  FLK_CHECK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out_dev = d;
+  return FLK_OK;
+}
+
+namespace {
+// table[ot][hc][wc][co] = sum_{kt: frame 2*ot+kt-2 inside the clip} sum_c a*p'[t,c] * S[kt][hc][wc][c][co]
+__global__ __launch_bounds__(64) void stem_delta_bias_kernel(const flk_apply_args a, const float* S, float* tab) {
+  const int co = threadIdx.x, cls = blockIdx.x & 15, ot = blockIdx.x >> 4;
+  float acc = 0.f;
+  for (int kt = 0; kt < 7; ++kt) {
+    const int t = 2 * ot + kt - 2;
+    if (t < 0 || t >= a.T) continue;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc += a.adv_flag * sg_pert(a, t, c) * S[(((size_t)kt * 16 + cls) * 3 + c) * SG_CO + co];
+  }
+  tab[((size_t)ot * 16 + cls) * SG_CO + co] = acc;
+}
+}  // namespace
+
+extern "C" int flk_stem_delta_bias(const flk_apply_args* a, const float* sums_dev, float* table_out, void* stream) {
+  FLK_REQUIRE(a && a->delta && sums_dev && table_out, "flk_stem_delta_bias: null argument");
+  FLK_REQUIRE(!a->delta_dense && a->T >= 2 && a->T % 2 == 0, "flk_stem_delta_bias: flicker perturbation [T,3], even T");
+  hipLaunchKernelGGL(stem_delta_bias_kernel, dim3((unsigned)(a->T / 2 * 16)), dim3(64), 0, (hipStream_t)stream, *a, sums_dev, table_out);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}

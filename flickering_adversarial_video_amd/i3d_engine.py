@@ -108,6 +108,8 @@ class FlickerI3D:
                                     dtype=torch.float32, device=dev)
         # flicker perturbation in bf16: the stem's data-gradient and the (b,h,w) reduction run as ONE MFMA kernel (csrc/stem_grad.hip)
         self.fused_delta_grad = (not dense_delta) and self.net.has_backward_delta
+        # ... and the perturbation reaches the stem in fp32 (centred clip + position-class bias) instead of being rounded with the bf16 input
+        self.exact_delta_forward = (not dense_delta) and self.net.has_forward_flicker
         self._scalars = torch.empty(8, dtype=torch.float32, device=dev)
         # result slots: [payload | softmax | per-clip table | scalars] written by the kernels, rotated per iteration
         self._slots = [dict(payload=torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev),
@@ -142,7 +144,14 @@ class FlickerI3D:
         sx = int(self._rng.integers(0, self.T)) if cyclic else 0          # one shift per step for the whole batch
         sp = int(self._rng.integers(0, self.T)) if cyclic_pert else 0     # (kinetics_i3d_utils.py:115,130)
         return ops.make_apply_args(x, self.eps_rgb, dialect="tf", dclip=0.0 if self.dense else 0.4, adv_flag=adv_flag,
-                                   shift_x=sx, shift_p=sp, fold_t=ops.I3D_FOLD)
+                                   shift_x=sx, shift_p=sp, fold_t=ops.I3D_FOLD, center=self.exact_delta_forward)
+
+    def _forward(self, a):
+        """apply + network forward into self._logits"""
+        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
+        if a.center:
+            return self.net.forward_flicker(self._xs2d, a, self._logits)
+        return self.net.forward(self._xs2d, self._logits)
 
     def _check_x(self, x):
         if tuple(x.shape) != (self.B, self.T, self.H, self.W, 3) or x.dtype not in (torch.uint8, torch.float32) or not x.is_cuda:
@@ -162,8 +171,7 @@ class FlickerI3D:
     def logits(self, x, adv_flag=None, cyclic=None):
         x = self._check_x(x)
         a = self._apply_args(x, self.adv_flag if adv_flag is None else adv_flag, self.cyclic_flag if cyclic is None else cyclic, 0)
-        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
-        return self.net.forward(self._xs2d, self._logits)
+        return self._forward(a)
 
     def __call__(self, inputs, adv_flag=0, cyclic=None):
         """softmax of the (clean by default) clip: kinetics_i3d.__call__ (kinetics_i3d_utils.py:210-212)"""
@@ -187,8 +195,7 @@ class FlickerI3D:
         self._it += 1
         red, sm, pc = slot["payload"], slot["sm"], slot["pc"]
         self._red = red
-        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
-        self.net.forward(self._xs2d, self._logits)
+        self._forward(a)
         gbatch = self.B * self.world
         ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
                              targeted=targeted, margin=margin, mean_scale=1.0 / gbatch, out=(sm, self._dl, pc))
@@ -272,6 +279,5 @@ class FlickerI3DInference(FlickerI3D):
         self.last_shift_x = int(self._rng.integers(0, self.T)) if cyclic_input_flag else 0
         self.last_shift_p = int(self._rng.integers(0, self.T)) if cyclic_eps_flag else 0
         a = ops.make_apply_args(x, self.eps_rgb, dialect="tf", dclip=0.0, adv_flag=float(adv_flag), shift_x=self.last_shift_x,
-                                shift_p=self.last_shift_p, fold_t=ops.I3D_FOLD)
-        ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
-        return torch.softmax(self.net.forward(self._xs2d, self._logits), -1)
+                                shift_p=self.last_shift_p, fold_t=ops.I3D_FOLD, center=self.exact_delta_forward)
+        return torch.softmax(self._forward(a), -1)

@@ -142,7 +142,7 @@ I3D_FOLD = 3   # space-to-depth layout the I3D plan (flk_net, FLK_NET_I3D) expec
 
 
 def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=0, shift_p=0, inv_std=(1.0, 1.0, 1.0),
-                    lo=-1.0, hi=1.0, fold_t=2):
+                    lo=-1.0, hi=1.0, fold_t=2, center=False):
     """x: uint8 or fp32 [B,T,H,W,3] on the GPU; delta fp32 [T,3] or [T,H,W,3]."""
     B, T, H, W, c3 = x.shape
     assert c3 == 3 and x.is_contiguous() and delta.is_contiguous() and delta.dtype == torch.float32
@@ -161,6 +161,7 @@ def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=
     a.shift_x, a.shift_p = int(shift_x), int(shift_p)
     a.B, a.T, a.H, a.W = B, T, H, W
     a.fold_t = fold_t
+    a.center = int(center)      # write x_adv - a*p' (the clean value where the clip is inactive); see Net.forward_flicker
     a._keepalive = (x, delta)   # the struct holds raw pointers only
     return a
 
@@ -322,6 +323,19 @@ class Net:
             logits = torch.empty((self.B, self.num_classes), dtype=torch.float32, device="cuda")
         assert x_in.numel() == self.input_numel and x_in.is_contiguous()
         check(load().flk_net_forward(self.handle, ptr(x_in), ptr(logits), 1, stream_ptr()))
+        return logits
+
+    @property
+    def has_forward_flicker(self):
+        """the exact perturbation path of the stem is available: I3D plan, bf16 (FLK_STEM_CENTER=0 switches it off)"""
+        return bool(load().flk_net_has_forward_flicker(self.handle))
+
+    def forward_flicker(self, x_in, apply_args, logits=None):
+        """forward of a clip applied with ``center=True``: the perturbation enters the stem in fp32 through its epilogue"""
+        if logits is None:
+            logits = torch.empty((self.B, self.num_classes), dtype=torch.float32, device="cuda")
+        assert x_in.numel() == self.input_numel and x_in.is_contiguous() and apply_args.center == 1
+        check(load().flk_net_forward_flicker(self.handle, ptr(x_in), C.byref(apply_args), ptr(logits), stream_ptr()))
         return logits
 
     def backward(self, dlogits, gx=None):

@@ -100,6 +100,9 @@ typedef struct {
    * out2 != NULL: output channels [cout1, cout) are written to out2[:, out2_coff + (n - cout1)] (cout1 % 8 == 0). */
   const void* in2; int in2_ld, in2_coff, cin1;
   void* out2; int out2_ld, out2_coff, cout1;
+  /* optional position-class bias (the exact perturbation path of the I3D stem, flk_stem_delta_bias): fp32 [To][4][4][cout], added
+   * after scale / bias; row = (ot, class(oh), class(ow)) with class(o) = 0 for o == 0, 2 for o == n-2, 3 for o == n-1, else 1 */
+  const float* pos_bias;
 } flk_conv_args;
 int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream);
 
@@ -149,6 +152,10 @@ typedef struct {
                                 zero (one (qt,qh) parity per 16-byte chunk: flk_conv_weights_create_s2d_stem);
                                 1: fold (h,w) only -> [B,T,H/2,W/2,16], channel (qh*2+qw)*3+c, 12..15 zero
                                 (VideoResNet stems, stride 1x2x2) */
+  int center;                /* 1 (flicker delta only): write x' = x_adv - a*p' instead of x_adv, i.e. the CLEAN value wherever the
+                                clip is inactive (exactly representable in bf16 for uint8 clips) -- the perturbation then reaches the stem
+                                through flk_conv_args.pos_bias in fp32 (flk_stem_delta_bias) instead of being rounded away with the
+                                bf16 input: |delta| < 2^-9 is below half a bf16 ulp of a pixel value near +-1 */
 } flk_apply_args;
 int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dtype, void* stream);
 
@@ -175,6 +182,13 @@ int flk_stem_delta_grad_weights_destroy(float* dev);
 int flk_stem_delta_grad_mask(const flk_apply_args* a, float* scratch, void* stream);   /* step 1 alone (clip mask; needs x and delta only) */
 int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g_ld, const float* wf_dev, float* gdelta,
                         float* scratch, int mask_done, void* stream);
+
+/* Exact perturbation path of the folded I3D stem in bf16 mode.  conv(x') + sum over the taps inside the clip of W * a*p'[t,c] equals
+ * conv(x_adv) wherever the clip is inactive (x' from flk_perturb_apply_s2d with center = 1); the second term depends on the output
+ * frame and on which taps fall outside the frame only: a [T/2][4][4][64] table, added in the stem's epilogue (flk_conv_args.pos_bias).
+ * weights: [7][4][4][3][64] = bn_scale * (sums of the canonical [7,7,7,3,64] stem weights over the in-frame (kh, kw) of each class). */
+int flk_stem_delta_bias_weights_create(const float* w7_dhwio, const float* bn_scale, float** out_dev);
+int flk_stem_delta_bias(const flk_apply_args* a, const float* sums_dev, float* table_out, void* stream);
 
 /* Tail of the data-parallel payload (flickering_adversarial_video_amd/parallel.py; replaces the per-iteration
  * reduce_sum / reduce_mean fetches of i3d_adversarial_main_single_video_npy.py:213-217): from the per-clip
@@ -253,6 +267,10 @@ int flk_net_finalize(flk_net* n);                 /* pack + upload; plan buffers
 int64_t flk_net_workspace_bytes(const flk_net* n);
 /* x_s2d: output of flk_perturb_apply_s2d (I3D) ; logits: fp32 [B,num_classes] */
 int flk_net_forward(flk_net* n, const void* x_in, float* logits, int save_for_backward, void* stream);
+/* forward of a clip applied with flk_apply_args.center = 1 (I3D plan in bf16: flk_net_has_forward_flicker): computes the stem's
+ * position-class bias table of `a` (flk_stem_delta_bias) and runs the plan with it */
+int flk_net_has_forward_flicker(const flk_net* n);
+int flk_net_forward_flicker(flk_net* n, const void* x_in, const flk_apply_args* a, float* logits, void* stream);
 /* dlogits fp32 [B,C] -> gradient w.r.t. the network input (same layout/dtype as x_in) */
 int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream);
 /* backward straight to the flickering perturbation: the plan without the stem's data-gradient, then flk_stem_delta_grad on the

@@ -351,6 +351,32 @@ def test_step_rejects_bad_labels():
     assert torch.isfinite(pc[0, 0]) and torch.isfinite(dl[0]).all() and torch.isnan(pc[1, 0]) and torch.isnan(dl[1]).all()
 
 
+def test_bf16_trajectory_well_conditioned():
+    """bf16 mode on the well-conditioned fixture: the perturbation reaches the stem in fp32 (centred clip + position-class bias,
+    Net.forward_flicker), so a delta of 1e-3 -- below half a bf16 ulp of most pixels, which a rounded x + delta would swallow -- moves
+    the logits as the reference maths says.  Stated tolerances: learned delta 2e-2 (max-rel), logits 5e-2, and the CHANGE of the
+    adversarial loss from the first iteration within 15% of the fp64 oracle's."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, Wt, xu = _coherent_fixture()
+    steps = 6
+    label, t64 = oracle_trajectory(Wt, xu, torch.float64, steps)
+    eng = FlickerI3D(W, batch_size=1, frames=T, dtype="bf16")
+    assert eng.exact_delta_forward and eng.fused_delta_grad
+    adv = []
+    for it in range(steps):
+        res = eng.step(xu.cuda(), label.cuda(), lr=1e-3, beta0=BETAS[0], beta1=BETAS[1], beta2=BETAS[2], beta3=BETAS[3], margin=0.05).host()
+        e_d = rel_err(eng.perturbation.cpu(), t64[it]["delta"])
+        e_l = rel_err(eng._logits.cpu(), t64[it]["logits"])
+        adv.append(res["adv_loss"])
+        print(f"iter {it + 1}: adv {res['adv_loss']:.6f} (fp64 oracle {t64[it]['adv']:.6f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e}")
+        assert e_d < 2e-2 and e_l < 5e-2
+    d_hip, d_ref = adv[-1] - adv[0], t64[-1]["adv"] - t64[0]["adv"]
+    print(f"adversarial-loss change over {steps} iterations: {d_hip:.3e} (fp64 oracle {d_ref:.3e})")
+    assert d_hip == pytest.approx(d_ref, rel=0.15)
+
+
 def test_bf16_step_runs_and_tracks_fp32(setup):
     """bf16 performance mode: same iteration, looser agreement with the fp32 engine (stated: 5% on the loss,
     first Adam step -- a pure sign step -- agreeing on >= 80% of the delta entries, gradient cosine > 0.85)."""
