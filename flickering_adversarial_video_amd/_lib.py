@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
                 ("relu", C.c_int),
                 ("in2", C.c_void_p), ("in2_ld", C.c_int), ("in2_coff", C.c_int), ("cin1", C.c_int),
                 ("out2", C.c_void_p), ("out2_ld", C.c_int), ("out2_coff", C.c_int), ("cout1", C.c_int),
-                ("pos_bias", C.c_void_p)]
+                ("pos_bias", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64)]
 
 
 class PoolArgs(C.Structure):
@@ -102,6 +102,7 @@ _SIGS = {
     "flk_net_workspace_bytes": (C.c_int64, [C.c_void_p]),
     "flk_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_conv_splitk_bytes": (C.c_int64, [C.POINTER(ConvArgs), C.c_void_p]),
     "flk_net_has_forward_flicker": (C.c_int, [C.c_void_p]),
     "flk_net_forward_flicker": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p]),
     "flk_stem_delta_bias_weights_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -46,6 +46,9 @@ struct ConvKP {
   int in2_ld, in2_coff, cin1, nslab1, out2_ld, out2_coff, cout1;
   unsigned m_HW, m_Wh, m_hw, m_Wt;   // ceil(2^20 / d): exact x / d for x * d < 2^20 (x < 1024 here)
   int ntile_n;
+  // deterministic split-K (blockIdx.y = slice of the input-channel slabs): raw fp32 partial sums [ksplit][positions][part_ld],
+  // summed in slice order and finished by conv_splitk_finish_kernel
+  float* part; int ksplit, part_ld; unsigned npos;
 };
 
 template <typename T> struct Prec;
@@ -88,6 +91,61 @@ template <> struct Prec<float> {
 
 __device__ static inline int plane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
 __device__ static inline int fdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
+
+// position-class bias row of an output position (flk_conv_args.pos_bias), or nullptr
+__device__ static inline const float* pos_bias_row(const ConvKP& p, int ot, int oh, int ow) {
+  if (!p.pos_bias) return nullptr;
+  const int hc = oh == 0 ? 0 : oh == p.Ho - 1 ? 3 : oh == p.Ho - 2 ? 2 : 1;
+  const int wc = ow == 0 ? 0 : ow == p.Wo - 1 ? 3 : ow == p.Wo - 2 ? 2 : 1;
+  return p.pos_bias + (size_t)((ot * 4 + hc) * 4 + wc) * p.cout;
+}
+
+// the epilogue of EPL consecutive output channels [c0, c0 + EPL) of physical output position opos: v = acc*scale + bias (+ position
+// bias) (+ add); relu; mask; 16-byte store into the first or second output segment
+template <typename T>
+__device__ static inline void finish_store(const ConvKP& p, size_t opos, const float* pb, int c0, float* v) {
+  typedef Prec<T> PR;
+  constexpr int EPL = PR::EPL;
+  if (p.scale) {
+#pragma unroll
+    for (int e = 0; e < EPL; e += 4) {
+      const float4 sc = *(const float4*)(p.scale + c0 + e);
+      v[e] *= sc.x; v[e + 1] *= sc.y; v[e + 2] *= sc.z; v[e + 3] *= sc.w;
+    }
+  }
+  if (p.bias) {
+#pragma unroll
+    for (int e = 0; e < EPL; e += 4) {
+      const float4 bi = *(const float4*)(p.bias + c0 + e);
+      v[e] += bi.x; v[e + 1] += bi.y; v[e + 2] += bi.z; v[e + 3] += bi.w;
+    }
+  }
+  if (pb) {
+#pragma unroll
+    for (int e = 0; e < EPL; e += 4) {
+      const float4 t4 = *(const float4*)(pb + c0 + e);
+      v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
+    }
+  }
+  if (p.add) {
+    float a[EPL];
+    PR::to_f32(*(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + c0) * sizeof(T)), a);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] += a[e];
+  }
+  if (p.relu) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (p.mask) {
+    float a[EPL];
+    PR::to_f32(*(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + c0) * sizeof(T)), a);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
+  }
+  if (c0 < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c0) * sizeof(T)) = PR::from_f32(v);
+  else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c0 - p.cout1)) * sizeof(T)) = PR::from_f32(v);
+}
 
 constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pairs staged per thread (16)
 
@@ -189,7 +247,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     return v;
   };
   // slab s -> (segment base pointer incl. channel offset, ld, chunk validity)
+  // split-K: this workgroup reduces the slabs [s_lo, s_lo + nslab) only (blockIdx.y = slice; one slice = everything)
+  const int s_lo = (int)blockIdx.y * p.nslab / p.ksplit;
+  const int nslab = ((int)blockIdx.y + 1) * p.nslab / p.ksplit - s_lo;
   auto slab_src = [&](int s, const char*& src, int& ld) -> bool {
+    s += s_lo;
     if (s < p.nslab1) {
       src = p.in + (size_t)(p.in_coff + s * SLABC + ch * EPL) * sizeof(T); ld = p.in_ld;
       return s * SLABC + ch * EPL < p.cin1;
@@ -198,15 +260,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     src = p.in2 + (size_t)(p.in2_coff + s2 * SLABC + ch * EPL) * sizeof(T); ld = p.in2_ld;
     return s2 * SLABC + ch * EPL < p.cin - p.cin1;
   };
-  const int nsteps = p.nslab * p.ntaps;
   const size_t wstep = (size_t)p.cout_frags * 1024;
+  const int nsteps = nslab * p.ntaps;
+  const char* const wbase = p.w + (size_t)s_lo * p.ntaps * wstep;
   if constexpr (MODE == 0) {
     // ---- wide wave tiles (>= 32 MFMAs per K step): weights through a double-buffered LDS tile shared by the 4 waves,
     // register prefetch one step ahead, nested tap loops.
     // weight stream: (slab, tap) step k lives at w + (k*cout_frags + ntile*NF) KiB.  Every thread moves WCH 16-byte
     // chunks per step, unconditionally (NF=2: threads t and t+128 move the same chunk) so the prefetch stays in VGPRs.
     const int wchunk = NF >= 4 ? tid : (tid & 127);
-    const char* wsrc = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
+    const char* wsrc = wbase + (size_t)ntile * NF * 1024 + wchunk * 16;
     uint4 wreg0 = *(const uint4*)wsrc, wreg1 = make_uint4(0, 0, 0, 0);   // named scalars: an array here is demoted to scratch
     if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
     wsrc += wstep;
@@ -224,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       pre2 = ldhalo(src, ld, goff[2], chvalid); pre3 = ldhalo(src, ld, goff[3], chvalid);
     };
     if (small_halo) prefetch(0);
-    for (int s = 0; s < p.nslab; ++s) {
+    for (int s = 0; s < nslab; ++s) {
       const int hsel = small_halo ? (s & 1) * halo_bytes : 0;
       if (small_halo) {
         // image (s & 1) was last read while computing slab s-2; every wave has passed the barrier of slab s-1 since
@@ -233,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         if (goff[1] != -2) *(uint4*)(hd + 1024) = pre1;
         if (goff[2] != -2) *(uint4*)(hd + 2048) = pre2;
         if (goff[3] != -2) *(uint4*)(hd + 3072) = pre3;
-        if (s + 1 < p.nslab) prefetch(s + 1);
+        if (s + 1 < nslab) prefetch(s + 1);
       } else {
         __syncthreads();  // every wave has finished reading the previous slab's halo
         const char* src; int ld;
@@ -356,12 +419,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     constexpr int NWAIT = D == 2 ? WCH + 4 : 8 + WCH;      // loads younger than the youngest load step k consumes
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int wchunk = NF >= 4 ? tid : (tid & 127);
-    const char* const wfirst = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
+    const char* const wfirst = wbase + (size_t)ntile * NF * 1024 + wchunk * 16;
     const char* const wlast = wfirst + (size_t)(nsteps - 1) * wstep;
     u32x4 pre[D][4], wq[2][2];
     auto aload = [&](u32x4 (&dst)[4], int s) {
       const char* src; int ld;
-      const bool chvalid = slab_src(s < p.nslab ? s : p.nslab - 1, src, ld);
+      const bool chvalid = slab_src(s < nslab ? s : nslab - 1, src, ld);
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const char* ptr = src + (size_t)((goff[n] >= 0 && chvalid) ? goff[n] : 0) * ld * sizeof(T);   // position 0 is always readable
@@ -440,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     //   * K1 (one tap per slab): the activation slabs are prefetched D slabs ahead as well.
     constexpr int D = (NFW <= 2 && !K1) ? 8 : 4;   // K1 also keeps D activation slabs (16 VGPRs each) in flight
     // fragment f of this wave at step k = w + (k*cout_frags + ntile*NF + wn*NFW + f) KiB + lane*16
-    const char* const wfirst = p.w + (size_t)ntile * NF * 1024 + (wn * NFW * 64 + lane) * 16;
+    const char* const wfirst = wbase + (size_t)ntile * NF * 1024 + (wn * NFW * 64 + lane) * 16;
     const char* const wlast = wfirst + (size_t)(nsteps - 1) * wstep;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: inline asm takes it in registers
     u32x4 wq[D][NFW];
@@ -469,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     uint4 pre[D][4];
     auto prefetch = [&](uint4 (&dst)[4], int s) {
       const char* src; int ld;
-      const bool chvalid = slab_src(s < p.nslab ? s : p.nslab - 1, src, ld);
+      const bool chvalid = slab_src(s < nslab ? s : nslab - 1, src, ld);
 #pragma unroll
       for (int n = 0; n < 4; ++n) dst[n] = ldhalo(src, ld, goff[n], chvalid);
     };
@@ -569,12 +632,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
     if (ot >= p.To || oh >= p.Ho || ow >= p.Wo) continue;
     const size_t opos = ((size_t)(b * p.OT + ot * p.ost + p.oot) * p.OH + oh * p.osh + p.ooh) * p.OW + ow * p.osw + p.oow;
-    const float* pb = nullptr;
-    if (p.pos_bias) {                                  // position-class bias row (flk_conv_args.pos_bias)
-      const int hc = oh == 0 ? 0 : oh == p.Ho - 1 ? 3 : oh == p.Ho - 2 ? 2 : 1;
-      const int wc = ow == 0 ? 0 : ow == p.Wo - 1 ? 3 : ow == p.Wo - 2 ? 2 : 1;
-      pb = p.pos_bias + (size_t)((ot * 4 + hc) * 4 + wc) * p.cout;
-    }
+    const float* pb = pos_bias_row(p, ot, oh, ow);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int c0 = cbase + g * 4 * EPL;
@@ -582,47 +640,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       float v[EPL];
 #pragma unroll
       for (int e = 0; e < EPL; ++e) v[e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
-      if (p.scale) {
+      if (p.ksplit > 1) {                                // raw partial sums of this slice; conv_splitk_finish_kernel does the rest
+        float* dst = p.part + ((size_t)blockIdx.y * p.npos + opos) * p.part_ld + c0;
 #pragma unroll
-        for (int e = 0; e < EPL; e += 4) {
-          const float4 sc = *(const float4*)(p.scale + c0 + e);
-          v[e] *= sc.x; v[e + 1] *= sc.y; v[e + 2] *= sc.z; v[e + 3] *= sc.w;
-        }
+        for (int e = 0; e < EPL; e += 4) *(float4*)(dst + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+        continue;
       }
-      if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < EPL; e += 4) {
-          const float4 bi = *(const float4*)(p.bias + c0 + e);
-          v[e] += bi.x; v[e + 1] += bi.y; v[e + 2] += bi.z; v[e + 3] += bi.w;
-        }
-      }
-      if (pb) {
-#pragma unroll
-        for (int e = 0; e < EPL; e += 4) {
-          const float4 t4 = *(const float4*)(pb + c0 + e);
-          v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
-        }
-      }
-      if (p.add) {
-        float a[EPL];
-        PR::to_f32(*(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + c0) * sizeof(T)), a);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) v[e] += a[e];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
-      }
-      if (p.mask) {
-        float a[EPL];
-        PR::to_f32(*(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + c0) * sizeof(T)), a);
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
-      }
-      if (c0 < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c0) * sizeof(T)) = PR::from_f32(v);
-      else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c0 - p.cout1)) * sizeof(T)) = PR::from_f32(v);
+      finish_store<T>(p, opos, pb, c0, v);
     }
   }
+}
+
+// second launch of a split-K convolution: sum the slices in slice order (fixed: bitwise reproducible), then the epilogue.
+// One thread = one output position x EPL channels.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvKP p) {
+  constexpr int EPL = Prec<T>::EPL;
+  const int ngrp = (p.cout + EPL - 1) / EPL;
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;
+  if (gid >= p.npos * (unsigned)ngrp) return;
+  const unsigned opos = gid / (unsigned)ngrp;
+  const int c0 = (int)(gid - opos * (unsigned)ngrp) * EPL;
+  float v[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) v[e] = 0.f;
+  for (int k = 0; k < p.ksplit; ++k) {
+    const float* src = p.part + ((size_t)k * p.npos + opos) * p.part_ld + c0;
+#pragma unroll
+    for (int e = 0; e < EPL; e += 4) {
+      const float4 t = *(const float4*)(src + e);
+      v[e] += t.x; v[e + 1] += t.y; v[e + 2] += t.z; v[e + 3] += t.w;
+    }
+  }
+  const float* pb = nullptr;
+  if (p.pos_bias) {
+    const int ow = (int)(opos % (unsigned)p.OW), oh = (int)(opos / (unsigned)p.OW % (unsigned)p.OH), ot = (int)(opos / (unsigned)(p.OW * p.OH) % (unsigned)p.OT);
+    pb = pos_bias_row(p, ot, oh, ow);
+  }
+  finish_store<T>(p, opos, pb, c0, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,8 +721,38 @@ static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
   return FLK_OK;
 }
 
-// force_wn: 0 = heuristic, else 1 / 2 / 4.  force_da: -1 = heuristic, 0 = LDS weight ring, 1 = direct A.
-static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream, int force_wn, int force_da) {
+constexpr int FLK_MAX_KSPLIT = 8;
+static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, int dtype, int nf, int wn, int mode);
+
+static bool splitk_eligible(const flk_conv_args* a, const flk_conv_weights* w) {
+  return !w->stem4 && w->nslab >= 2 && !a->pos_bias && a->ost == 1 && a->osh == 1 && a->osw == 1 && a->oot == 0 && a->ooh == 0 && a->oow == 0 &&
+         a->To == a->OT && a->Ho == a->OH && a->Wo == a->OW;
+}
+// Slices for this convolution (1 = no split).  Split-K pays where even 256-row tiles leave three quarters of the CUs without a
+// workgroup AND the K loop is long (3x3x3 over >= 4 slabs: Mixed_5*, the late VideoResNet layers): measured on the Mixed_5c
+// 3x3x3 pair 49 -> 37 us forward, 88 -> 35 us data-gradient.  1x1x1 GEMMs (K loop of <= 26 steps) and the 25088-position
+// Mixed_4* layers lose (the fp32 partial sums cost more than the idle CUs): never split.
+static int plan_ksplit(const flk_conv_args* a, const flk_conv_weights* w) {
+  if (!splitk_eligible(a, w) || w->ntaps == 1 || w->nslab < 4) return 1;
+  const int nf = w->nf;
+  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, nf == 2 ? 192 : FLK_ROWS,
+                                     nf == 2 ? 768 : FLK_MAX_HALO);
+  const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * (w->cout_frags / nf);
+  if (wgs > 64) return 1;
+  int ks = (int)(256 / wgs);
+  ks = ks > FLK_MAX_KSPLIT ? FLK_MAX_KSPLIT : ks;
+  return ks > w->nslab ? w->nslab : ks;
+}
+
+extern "C" int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_weights* w) {
+  if (!a || !w || !splitk_eligible(a, w)) return 0;
+  static const char* force = getenv("FLK_CONV_KSPLIT");
+  const int ks = force ? FLK_MAX_KSPLIT : plan_ksplit(a, w);
+  return ks > 1 ? (int64_t)ks * a->B * a->OT * a->OH * a->OW * a->cout * (int64_t)sizeof(float) : 0;
+}
+
+// force_wn: 0 = heuristic, else 1 / 2 / 4.  force_da: -1 = heuristic, 0 = LDS weight ring, 1 = direct A.  force_ks: 0 = heuristic.
+static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream, int force_wn, int force_da, int force_ks = 0) {
   FLK_REQUIRE(a && w && w->dev, "flk_conv3d: null argument");
   FLK_REQUIRE(dtype == w->dtype, "flk_conv3d: dtype %d != packed weight dtype %d", dtype, w->dtype);
   FLK_REQUIRE(a->kt == w->kt && a->kh == w->kh && a->kw == w->kw && a->cin == w->cin && a->cout == w->cout,
@@ -712,6 +797,13 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   const int nf = w->nf;
   const int ntile_n = w->cout_frags / nf;
   int wn = 1;
+  // split-K decision first: a split launch keeps 256-row tiles (wn = 1) and gets its parallelism from the K slices
+  int ksplit = 1;
+  if (a->splitk_ws && splitk_eligible(a, w)) {
+    static const char* force = getenv("FLK_CONV_KSPLIT");
+    ksplit = force ? atoi(force) : force_ks > 0 ? force_ks : plan_ksplit(a, w);
+    ksplit = ksplit > w->nslab ? w->nslab : ksplit > FLK_MAX_KSPLIT ? FLK_MAX_KSPLIT : ksplit < 1 ? 1 : ksplit;
+  }
   // narrow channel tiles (nf = 2) are latency-bound: keep their halo <= 768 so that 3 workgroups fit a CU's LDS
   // the folded stem (mode 4): 192-row tiles (three computing waves, the fourth only stages) with a halo <= 704 keep the
   // workgroup at 53 KiB of LDS, i.e. THREE per CU instead of two: measured 0.62 vs 0.655 ms (4x6x8 vs 4x8x8 tiles)
@@ -726,7 +818,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     const int force = force_wn > 0 ? force_wn : force_env ? atoi(force_env) : 0;
     while (true) {
       const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * ntile_n;
-      const bool more = w->stem4 ? false : force ? wn < force : wgs < 256;   // fewer workgroups than CUs (mode 4 is written for wn = 1)
+      const bool more = w->stem4 ? false : force ? wn < force : (wgs < 256 && ksplit == 1);   // fewer workgroups than CUs (mode 4 is written for wn = 1)
       if (!more || wn * 2 > 4 || wn * 2 > wn_max) break;
       wn *= 2;
       t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, FLK_ROWS / wn, max_halo);
@@ -764,7 +856,17 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   const long ptiles = (long)a->B * kp.nTt * kp.nTh * kp.nTw;
   const long gx = (ptiles + 7) / 8 * 8 * ntile_n;
   FLK_REQUIRE(gx < (1l << 31), "flk_conv3d: grid too large");
-  dim3 grid((unsigned)gx);
+  // Deterministic split-K for launches that cannot fill the chip with output tiles (Mixed_5*: 3136 positions): the input-channel
+  // slabs are divided over blockIdx.y, every slice writes raw fp32 partial sums and a second launch adds them in slice order
+  // and runs the epilogue.  Needs the caller's workspace (flk_conv_args.splitk_ws) and a logical == physical output grid.
+  kp.ksplit = 1;
+  if (ksplit > 1) {
+    const size_t npos = (size_t)a->B * a->OT * a->OH * a->OW;
+    FLK_REQUIRE((size_t)ksplit * npos * a->cout * sizeof(float) <= (size_t)a->splitk_ws_bytes, "flk_conv3d: split-K workspace too small "
+                "(%zu bytes needed, flk_conv_splitk_bytes)", (size_t)ksplit * npos * a->cout * sizeof(float));
+    kp.ksplit = ksplit; kp.part = (float*)a->splitk_ws; kp.part_ld = a->cout; kp.npos = (unsigned)npos;
+  }
+  dim3 grid((unsigned)gx, (unsigned)kp.ksplit);
   hipStream_t s = (hipStream_t)stream;
   // Weight path.  Direct-A (modes 1/2) wherever a K step holds few MFMAs per wave and the waves would otherwise stall
   // on the per-step barrier: all WN >= 2 layouts, and narrow channel tiles (nf <= 4) on grids of at most two
@@ -792,7 +894,22 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
       fprintf(stderr, "conv %dx%dx%d s%d%d%d cin %d cout %d out %dx%dx%dx%d | nf %d wn %d tile %dx%dx%d rows %d halo %d wgs %ld mode %d lds %zu\n",
               a->kt, a->kh, a->kw, a->st, a->sh, a->sw, a->cin, a->cout, a->B, a->To, a->Ho, a->Wo, nf, wn, kp.Tt, kp.Ht, kp.Wt,
               kp.rows, kp.P, ptiles * ntile_n, mode, lds);
+    if (dbg && kp.ksplit > 1) fprintf(stderr, "   split-K x%d (%d slabs)\n", kp.ksplit, kp.nslab);
   }
+  if (kp.ksplit > 1) {
+    const int rc = launch_any(kp, grid, lds, s, dtype, nf, wn, mode);
+    if (rc) return rc;
+    const int epl = dtype == FLK_BF16 ? 8 : 4;
+    const size_t n = (size_t)kp.npos * ((a->cout + epl - 1) / epl);
+    if (dtype == FLK_BF16) hipLaunchKernelGGL(conv_splitk_finish_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kp);
+    else hipLaunchKernelGGL(conv_splitk_finish_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kp);
+    FLK_CHECK_HIP(hipGetLastError());
+    return FLK_OK;
+  }
+  return launch_any(kp, grid, lds, s, dtype, nf, wn, mode);
+}
+
+static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, int dtype, int nf, int wn, int mode) {
 #define FLK_LAUNCH0(TT, NFv, WNv)                                                           \
   if (nf == NFv && wn == WNv && mode == 0) return launch<TT, NFv, WNv, 0>(kp, grid, lds, s); \
   if (nf == NFv && wn == WNv && mode == 3) return launch<TT, NFv, WNv, 3>(kp, grid, lds, s)
@@ -813,7 +930,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   }
 #undef FLK_LAUNCH0
 #undef FLK_LAUNCHD
-  flk_set_error("flk_conv3d: unsupported dtype %d / nf %d / wn %d", dtype, nf, wn);
+  flk_set_error("flk_conv3d: unsupported dtype %d / nf %d / wn %d / mode %d", dtype, nf, wn, mode);
   return FLK_EINVAL;
 }
 

@@ -128,6 +128,17 @@ struct flk_net {
     if (zero) FLK_CHECK_HIP(hipMemset(*p, 0, bytes));
     return FLK_OK;
   }
+  // workspace for deterministic split-K where flk_conv3d would split this launch (flk_conv_splitk_bytes: the Mixed_5* 3x3x3 layers,
+  // the late VideoResNet layers); one per operator, because the branches of a block run concurrently.  bf16 (the performance
+  // mode) only: in fp32, the parity mode, every output keeps ONE summation order whatever the batch size and launch layout
+  // (tests compare plans of different batch sizes at fp32 summation-order noise).
+  void attach_splitk(flk_conv_args& a, const flk_conv_weights* w) {
+    if (dtype != FLK_BF16) return;
+    const bool off = getenv("FLK_NO_SPLITK") && atoi(getenv("FLK_NO_SPLITK"));      // read per plan build
+    const int64_t nb = off ? 0 : flk_conv_splitk_bytes(&a, w);
+    void* ws = nullptr;
+    if (nb > 0 && dmalloc(&ws, (size_t)nb) == FLK_OK) { a.splitk_ws = ws; a.splitk_ws_bytes = nb; }
+  }
   int new_act(Act& a, int T_, int H_, int W_, int ld, bool zero = false) {
     a.T = T_; a.H = H_; a.W = W_; a.ld = ld;
     return dmalloc(&a.p, a.numel(B) * esz(), zero);
@@ -199,6 +210,7 @@ struct flk_net {
     const double macs = (double)B * out.T * out.H * out.W * L->kt * L->kh * L->kw * L->cin * L->cout;
     flk_conv_weights* wf = L->wf;
     const int dt = dtype;
+    attach_splitk(a, wf);
     fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt, in_ptr](hipStream_t s) mutable {
                        if (in_ptr) a.in = *in_ptr;
                        return flk_conv3d(&a, wf, dt, s);
@@ -220,6 +232,7 @@ struct flk_net {
     const double macs = (double)B * gin.T * gin.H * gin.W * L->kt * L->kh * L->kw * L->cin * L->cout;
     flk_conv_weights* wb = L->wb;
     const int dt = dtype;
+    attach_splitk(a, wb);
     bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt, out_ptr](hipStream_t s) mutable {
                        if (out_ptr) a.out = *out_ptr;
                        return flk_conv3d(&a, wb, dt, s);
@@ -647,6 +660,7 @@ void flk_net::emit_gen_fwd(ConvLayer* L, const Act& in, const Act& out, bool rel
   const double macs = (double)B * out.T * out.H * out.W * L->kt * L->kh * L->kw * L->cin * L->cout;
   flk_conv_weights* wf = L->wf;
   const int dt = dtype;
+  attach_splitk(a, wf);
   fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
 }
 
@@ -664,6 +678,7 @@ void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const voi
     const double macs = (double)B * a.To * a.Ho * a.Wo * bc.kt * bc.kh * bc.kw * L->cin * L->cout;
     flk_conv_weights* wb = bc.w;
     const int dt = dtype;
+    attach_splitk(a, wb);
     bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
   }
 }

@@ -64,7 +64,7 @@ class ConvWeights:
 
 def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
            out_stride=(1, 1, 1), out_offset=(0, 0, 0), scale=None, bias=None, add=None, add_coff=0, mask=None,
-           mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0):
+           mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0, splitk=False):
     """x: [B,T,H,W,ld] channels-last; returns / fills out [B,OT,OH,OW,ld_out].  pad = pad-before per dim
     (default: TF SAME).  out_grid = logical output grid (default: SAME output size)."""
     B, Ti, Hi, Wi, in_ld = x.shape
@@ -98,6 +98,12 @@ def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, o
         a.in2, a.in2_ld, a.in2_coff, a.cin1 = ptr(in2), in2.shape[4], in2_coff, w.cin_split
     if out2 is not None:
         a.out2, a.out2_ld, a.out2_coff, a.cout1 = ptr(out2), out2.shape[4], out2_coff, cout1
+    if splitk:           # workspace for deterministic split-K (used only where the launch would leave most CUs idle)
+        nbytes = load().flk_conv_splitk_bytes(C.byref(a), w.handle)
+        if nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            a.splitk_ws, a.splitk_ws_bytes = ptr(ws), nbytes
+            a._keepalive = ws
     check(load().flk_conv3d(C.byref(a), w.handle, dtype_code(x.dtype), stream_ptr()))
     return out
 

@@ -103,8 +103,14 @@ typedef struct {
   /* optional position-class bias (the exact perturbation path of the I3D stem, flk_stem_delta_bias): fp32 [To][4][4][cout], added
    * after scale / bias; row = (ot, class(oh), class(ow)) with class(o) = 0 for o == 0, 2 for o == n-2, 3 for o == n-1, else 1 */
   const float* pos_bias;
+  /* optional workspace for deterministic split-K (launches with too few output tiles to fill the chip: the input-channel slabs are
+   * divided over up to 8 slices, each writes fp32 partial sums here, a second launch adds them in slice order and runs the
+   * epilogue -- bitwise reproducible).  NULL: never split.  Size: flk_conv_splitk_bytes (0 = this convolution is never split).
+   * Two convolutions that may run concurrently need separate workspaces. */
+  void* splitk_ws; int64_t splitk_ws_bytes;
 } flk_conv_args;
 int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream);
+int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_weights* w);
 
 /* tf.nn.max_pool3d SAME (i3d.py:174,189,212,252,398): padded cells never win; argmax = FIRST
  * maximum in (t,h,w) scan order, stored as a uint8 window index for the backward pass.

@@ -85,6 +85,47 @@ def test_conv_forward(ops, case, dtype):
     torch.testing.assert_close(out.float().cpu(), ref, rtol=r, atol=a)
 
 
+SPLITK_CASES = [
+    # name, B,T,H,W, cin,cout, k, nf      (few output tiles, long K loop: the Mixed_5* regime and the late VideoResNet layers)
+    ("3x3x3_192_384", 2, 8, 7, 7, 192, 384, (3, 3, 3), 8),
+    ("3x3x3_160_96_odd_slabs", 1, 4, 7, 7, 160, 96, (3, 3, 3), 4),
+    ("1x3x3_256_256", 1, 4, 14, 14, 256, 256, (1, 3, 3), 8),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_conv_splitk(ops, case, dtype):
+    """deterministic split-K (flk_conv_args.splitk_ws): the input-channel slabs are divided over blockIdx.y, the slices' fp32 partial
+    sums are added in slice order by a second launch that also runs the epilogue (scale, bias, add, relu, mask).  Against the
+    torch-CPU oracle at the usual tolerances; the same call twice gives the same bits."""
+    import ctypes as C
+    from flickering_adversarial_video_amd._lib import load
+    _, B, T, H, W, cin, cout, k, nf = case
+    x = q(rnd((B, T, H, W, cin), 1), dtype)
+    w = q(rnd((*k, cin, cout), 2, (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5), dtype)
+    scale, bias = rnd((cout,), 3).abs() + 0.5, rnd((cout,), 4) * 0.1
+    add = q(rnd((B, T, H, W, cout), 5), dtype)
+    mask = q(rnd((B, T, H, W, cout), 6), dtype)
+    og, pad = zip(*(ops.same_pad(n, kk, 1) for n, kk in zip((T, H, W), k)))
+    ref = torch.relu(ref_conv(x, w, (1, 1, 1), pad, og) * scale + bias + add) * (mask > 0)
+    pw = ops.ConvWeights(w.numpy(), dtype, nf)
+    kw = dict(scale=scale.cuda(), bias=bias.cuda(), add=add.to(dtype).cuda(), mask=mask.to(dtype).cuda(), relu=True)
+    xd = x.to(dtype).cuda()
+    out = ops.conv3d(xd, pw, splitk=True, **kw)
+    r, a = tol(dtype, ref)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=r, atol=a)
+    assert torch.equal(out, ops.conv3d(xd, pw, splitk=True, **kw))
+    # the plan really splits this geometry (a workspace size of 0 would mean the launch above ran in one slice)
+    args = ops.ConvArgs()
+    args.B, args.To, args.Ho, args.Wo, args.OT, args.OH, args.OW = B, T, H, W, T, H, W
+    args.kt, args.kh, args.kw, args.st, args.sh, args.sw, args.ost, args.osh, args.osw = *k, 1, 1, 1, 1, 1, 1
+    args.cin, args.cout = cin, cout
+    assert load().flk_conv_splitk_bytes(C.byref(args), pw.handle) > 0
+    one = ops.conv3d(xd, pw, **kw)                       # one slice: equal up to the summation order
+    torch.testing.assert_close(out.float(), one.float(), rtol=r, atol=a)
+
+
 def fold_stem(w7):
     """[7,7,7,3,cout] -> [4,4,4,32,cout]: tap 2*j + q of an axis goes to folded tap j, parity q; channel (qt*2+qh)*8 + qw*3 + c"""
     cout = w7.shape[4]

@@ -14,7 +14,15 @@ w = (np.random.default_rng(0).standard_normal((kt, kt, kt, cin, cout)) * 0.05).a
 pw = ops.ConvWeights(w, torch.bfloat16, nf, transpose=tr)
 out = torch.empty(B, T, H, W, cin if tr else cout, device="cuda", dtype=torch.bfloat16)
 pad = tuple([kt - 1 - (kt - 1) // 2] * 3) if tr else None
-f = lambda: ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W), out=out)
+splitk = bool(int(os.environ.get("SPLITK", "0")))      # give the launch a split-K workspace (FLK_CONV_KSPLIT forces the slice count)
+if splitk:
+    ref = ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W)).float()
+    got = ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W), splitk=True).float()
+    print("split-K vs one slice: max |diff| %.3e (max |ref| %.3e)" % ((got - ref).abs().max().item(), ref.abs().max().item()))
+import ctypes as C
+_keep = []
+def f():
+    ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W), out=out, splitk=splitk)
 for _ in range(20): f()
 torch.cuda.synchronize()
 ts = []
