@@ -6,6 +6,7 @@
   <tag>_kernel_stats_{single,multi}_stream.csv   rocprofv3 --kernel-trace --stats
   <tag>_pmc_hbm_traffic.json         FETCH_SIZE / WRITE_SIZE passes (tools/pmc_summary.py: gfx950 corrections), state label = git HEAD
   <tag>_pmc_sq_summary.json          effective clock, wave-cycle split and MFMA busy fraction per kernel template
+  <tag>_timeline.txt                 tools/timeline.py on the multi-stream kernel trace: kernels in flight, idle gaps, one step listed
 Usage: collect_profiles.py <tag>"""
 import collections, csv, glob, json, os, re, shutil, subprocess, sys
 
@@ -29,15 +30,24 @@ json.dump(json.loads(line), open(os.path.join(dst, f"{tag}_bench_i3d_bs8_full.js
 shutil.copy(os.path.join(src, "per_layer_serial.txt"), os.path.join(dst, f"{tag}_per_layer_serial.txt"))
 for mode in ("single", "multi"):
     shutil.copy(one(f"{mode}/**/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_{mode}_stream.csv"))
+with open(os.path.join(dst, f"{tag}_timeline.txt"), "w") as f:
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "timeline.py"), one("multi/**/*_kernel_trace.csv"), "--list"], stdout=f)
 subprocess.check_call([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), one("fetch/**/*_counter_collection.csv"),
                        one("write/**/*_counter_collection.csv"), os.path.join(dst, f"{tag}_pmc_hbm_traffic.json"), state])
 
 
 def short(name):
+    m = re.search(r"conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E", name)          # mangled: <T, NF, WN, MODE>
+    if m:
+        return "conv_igemm_kernel<%s,NF=%s,WN=%s,MODE=%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3), m.group(4))
     m = re.search(r"conv_igemm_kernel<([^>]*)>", name)
     if m:
         return "conv_igemm_kernel<" + m.group(1).replace("__hip_bfloat16", "bf16").replace(" ", "") + ">"
-    return name.split("(")[0]
+    m = re.search(r"(stem_delta_grad_kernel|stem_mask_kernel|stem_delta_bias_kernel|conv_splitk_finish_kernel|maxpool_\w+|head_\w+|apply_s2d_\w+|"
+                  r"grad_reduce_\w+|softmax_adv_loss_kernel|reg_adam_kernel|dense_\w+)", name)
+    if m:
+        return m.group(1)
+    return name.split("(")[0].strip() or name[:40]
 
 
 rows = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -26,5 +26,5 @@ FLK_SINGLE_STREAM=1 timeout -k 10 280 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CY
 echo sq done
 # keep only what collect_profiles.py reads (gpurun_out is capped at 64 MiB)
 find $O -name '*_agent_info.csv' -delete
-for d in single multi; do find $O/$d -name '*_kernel_trace.csv' -delete; done
+find $O/single -name '*_kernel_trace.csv' -delete      # the multi-stream trace feeds tools/timeline.py
 du -sh $O
