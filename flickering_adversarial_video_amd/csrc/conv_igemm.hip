@@ -710,11 +710,13 @@ flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st,
 
 template <typename T, int NF, int WN, int MODE>
 static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[16] = {};      // per device: one process may drive several GPUs
+  int dev = 0;
+  FLK_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
     FLK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NF, WN, MODE>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<T, NF, WN, MODE>), grid, dim3(256), lds, s, kp);
   FLK_CHECK_HIP(hipGetLastError());
@@ -946,8 +948,7 @@ extern "C" int flk_conv_set_autotune(int on) { g_tuning = on != 0; return FLK_OK
 
 extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream) {
   if (!a || !w) return conv3d_impl(a, w, dtype, stream, 0, -1);
-  flk_conv_weights* wm = const_cast<flk_conv_weights*>(w);
-  for (const flk_conv_weights::Tuned& tn : wm->tuned)
+  for (const flk_conv_weights::Tuned& tn : w->tuned)
     if (tn.B == a->B && tn.To == a->To && tn.Ho == a->Ho && tn.Wo == a->Wo) return conv3d_impl(a, w, dtype, stream, tn.wn, tn.da);
   if (!g_tuning || w->stem4) return conv3d_impl(a, w, dtype, stream, 0, -1);
   hipStream_t s = (hipStream_t)stream;
@@ -978,6 +979,6 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  wm->tuned.push_back({a->B, a->To, a->Ho, a->Wo, best.wn, best.da});
+  w->tuned.push_back({a->B, a->To, a->Ho, a->Wo, best.wn, best.da});
   return conv3d_impl(a, w, dtype, stream, best.wn, best.da);
 }

@@ -48,7 +48,8 @@ struct flk_conv_weights {
   int cin_split = 0, nslab1 = 0;   // two-segment K order: slabs [0,nslab1) = channels [0,cin_split)
   int stem4 = 0;                   // folded-stem K-step packing (49 steps of non-zero chunks; conv_igemm.hip mode 4)
   struct Tuned { int B, To, Ho, Wo, wn, da; };
-  std::vector<Tuned> tuned;        // autotuned launch layout per call geometry (conv_igemm.hip: flk_conv_set_autotune)
+  mutable std::vector<Tuned> tuned;   // cache of autotuned launch layouts per call geometry (conv_igemm.hip: flk_conv_set_autotune):
+                                      // not part of the operator's value, filled by the tuning pass of the owning thread
   size_t bytes = 0;
 };
 
