@@ -62,3 +62,45 @@ def coherent_i3d_weights(xu, seed=5, label=233, num_classes=400):
     W[P + "Logits/Conv3d_0c_1x1/conv_3d/w"] = wfc.reshape(1, 1, 1, x.shape[1], num_classes)
     W[P + "Logits/Conv3d_0c_1x1/conv_3d/b"] = np.zeros(num_classes, np.float32)
     return W
+
+
+def coherent_videoresnet_weights(W_base, x_ncdhw, arch, label=233, seed=5):
+    """Well-conditioned VideoResNet weights (same idea as coherent_i3d_weights) from a base weight dict of the right shapes
+    (torchvision state_dict names): every convolution weight becomes |w|, BatchNorm gamma = 1 with a small random beta and running
+    statistics calibrated on the fixture clip (one oracle forward pass in which every BatchNorm records the mean / variance of its
+    own input), fc >= 0 favouring ``label``.  x_ncdhw: the normalised clip [1,3,T,H,W] (float64)."""
+    from . import videoresnet_ref as vr
+    rng = np.random.default_rng(seed)
+    W = {}
+    for k, v in W_base.items():
+        v = np.asarray(v, np.float32)
+        if v.ndim == 5:
+            W[k] = np.abs(v)
+        elif k.endswith(".weight") and v.ndim == 1:
+            W[k] = np.ones_like(v)                                   # BatchNorm gamma
+        elif k.endswith(".bias") and not k.startswith("fc."):
+            W[k] = (rng.standard_normal(v.shape) * 0.3).astype(np.float32)   # BatchNorm beta
+        else:
+            W[k] = v.copy()
+    Wt = {k: torch.from_numpy(v).double() for k, v in W.items()}
+    orig_bn = vr.bn
+
+    def calibrating_bn(x, Wd, pre):
+        Wd[pre + ".running_mean"] = x.mean(dim=(0, 2, 3, 4))
+        Wd[pre + ".running_var"] = x.var(dim=(0, 2, 3, 4), unbiased=False).clamp_min(1e-6)
+        return orig_bn(x, Wd, pre)
+
+    vr.bn = calibrating_bn
+    try:
+        with torch.no_grad():
+            vr.videoresnet_logits(x_ncdhw.double(), Wt, arch)
+    finally:
+        vr.bn = orig_bn
+    for k in W:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            W[k] = Wt[k].numpy().astype(np.float32)
+    C, F_ = W["fc.weight"].shape
+    wfc = np.abs(rng.standard_normal((C, F_))).astype(np.float32) * np.float32(0.002)
+    wfc[label] += np.float32(0.02)
+    W["fc.weight"], W["fc.bias"] = wfc, np.zeros(C, np.float32)
+    return W

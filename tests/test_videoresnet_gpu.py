@@ -113,6 +113,56 @@ def test_videoresnet_forward_backward(arch):
         del eng
 
 
+def test_videoresnet_attack_trajectory_well_conditioned():
+    """BASELINE config 3 (r2plus1d_18, bs 1, 16 x 112 x 112, torch dialect) at the north-star bar: logits, adversarial loss and the
+    LEARNED DELTA of the fp32 mode within 1e-3 of the reference maths (fp64 oracle) over 6 iterations of the single-video loop
+    (model.py:1073-1101: Perturbation -> net -> Losses -> backward -> torch-Adam) on the well-conditioned fixture
+    (oracle/fixtures.py::coherent_videoresnet_weights).  The fixture is first shown to be well-conditioned: the torch-CPU fp32
+    oracle reproduces the fp64 trajectory to < 1e-4."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet, Losses
+    from oracle import fixtures
+    arch, steps, LR = "r2plus1d_18", 6, 1e-3
+    x_cl = torch.from_numpy(vs.synthetic_clip(1, T, HW, HW, seed=5))
+    x = x_cl.permute(0, 4, 1, 2, 3).contiguous()
+    W = fixtures.coherent_videoresnet_weights(vs.synthetic_weights(arch, 42), x, arch, label=233)
+
+    def trajectory(dt):
+        Wd = {k: torch.from_numpy(v).to(dt) for k, v in W.items()}
+        xd = x.to(dt)
+        label = vr.videoresnet_logits(xd, Wd, arch).argmax(-1)
+        d = torch.zeros(3, T, 1, 1, dtype=dt)
+        m, v = torch.zeros_like(d), torch.zeros_like(d)
+        out = []
+        for it in range(1, steps + 1):
+            dv = d.clone().requires_grad_(True)
+            logits = vr.videoresnet_logits(am.torch_apply(xd, dv, 0.2), Wd, arch)
+            loss, adv, reg = am.torch_losses(label, logits, torch.softmax(logits, 1), dv.clamp(-0.2, 0.2), 0.5, 1.0, 0.05, True, True, "flickering")
+            (g,) = torch.autograd.grad(loss, dv)
+            d, m, v = am.torch_adam_step(d, g, m, v, it, lr=LR)
+            out.append(dict(logits=logits.detach().double(), adv=adv.item(), delta=d.detach().double().clone()))
+        return label, out
+
+    label, t64 = trajectory(torch.float64)
+    label32, t32 = trajectory(torch.float32)
+    assert int(label) == int(label32) == 233
+    for it in range(steps):
+        assert rel_err(t32[it]["delta"], t64[it]["delta"]) < 1e-4, "fixture is not well-conditioned"
+    eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype="f32", l_inf_pert_norm=0.2)
+    eng.pert_model.init_perturbation(np.zeros((3, T, 1, 1), np.float32))      # (the default start is U(-1,1)*1e-6, model.py:121-126)
+    crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)
+    for it in range(steps):
+        res = eng.step(x_cl.cuda(), label.cuda(), crit, lr=LR).host()
+        delta = eng.pert_model.perturbation.cpu().t().reshape(3, T, 1, 1)
+        e_d, e_l = rel_err(delta, t64[it]["delta"]), rel_err(eng._logits.cpu(), t64[it]["logits"])
+        print(f"iter {it + 1}: adv {res['adv_loss']:.7f} (fp64 oracle {t64[it]['adv']:.7f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e} "
+              f"(torch-CPU fp32 oracle delta {rel_err(t32[it]['delta'], t64[it]['delta']):.2e})")
+        assert e_d < 1e-3 and e_l < 1e-3
+        assert res["adv_loss"] == pytest.approx(t64[it]["adv"], rel=1e-3, abs=1e-7)
+
+
 @pytest.mark.gpu
 def test_videoresnet_drivers():
     """fit_single_video_attack (restart-with-1.3x-norm schedule, model.py:1056-1066) and fit / train_an_epoch (StepLR,
