@@ -417,6 +417,41 @@ def test_dense_delta_step(setup):
     assert float(moved.abs().max()) == pytest.approx(1e-3, rel=1e-2)
 
 
+def test_dense_delta_trajectory_well_conditioned():
+    """the dense-delta baseline (kinetics_i3d_L12, kinetics_i3d_utils.py:308-521; loss = adv + beta0 * beta1 * L12,
+    i3d_adversarial_main_universal.py:129-133) at the north-star bar on the well-conditioned fixture: the dense gradient
+    d(adv)/d(delta) [T,224,224,3] of the first iteration and the LEARNED dense delta, the adversarial loss and L12 of 3 iterations
+    within 1e-3 of the fp64 oracle (autograd through the oracle network, TF-Adam)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, Wt, xu = _coherent_fixture()
+    W64 = Wt[torch.float64]
+    x64 = xu.double() / 128 - 1
+    label = i3d_ref.i3d_logits(x64, W64).argmax(-1)
+    assert int(label) == 233
+    B0, B1, LR, steps = 1.0, 0.5, 1e-3, 3
+    d = torch.full((T, 224, 224, 3), 1e-8, dtype=torch.float64)
+    m, v = torch.zeros_like(d), torch.zeros_like(d)
+    eng = FlickerI3D(W, batch_size=1, frames=T, dtype="f32", dense_delta=True)
+    for it in range(1, steps + 1):
+        dv = d.clone().requires_grad_(True)
+        lg = i3d_ref.i3d_logits(am.tf_apply(x64, dv, clip_delta=False), W64)
+        adv, _, _ = am.tf_improve_adversarial_loss(lg, label, 0.05, False, False)
+        l12 = am.tf_l12(dv)
+        (g_adv,) = torch.autograd.grad(adv, dv, retain_graph=True)
+        (g,) = torch.autograd.grad(adv + B0 * B1 * l12, dv)
+        d, m, v = am.tf_adam_step(d, g, m, v, it, lr=LR)
+        res = eng.step(xu.cuda(), label.cuda(), lr=LR, beta0=B0, beta1=B1, margin=0.05).host()
+        e_g = rel_err(eng._gdense.cpu(), g_adv)
+        e_d = rel_err(eng.perturbation.cpu(), d)
+        print(f"iter {it}: adv {res['adv_loss']:.7f} (fp64 oracle {adv.item():.7f}); L12 {res['L12']:.6e} ({l12.item():.6e}); "
+              f"dense d(adv)/d(delta) max-rel {e_g:.2e}; dense delta max-rel {e_d:.2e}")
+        assert res["adv_loss"] == pytest.approx(adv.item(), rel=1e-3, abs=1e-7)
+        assert res["L12"] == pytest.approx(l12.item(), rel=1e-3)
+        assert e_g < 1e-3 and e_d < 1e-3
+
+
 def test_inference_engine_cyclic_flags():
     """kinetics_i3d_inference (kinetics_i3d_utils.py:574-647): rolls of the clip / the perturbation are tf.roll by the drawn
     shift, the perturbation is NOT clipped to 0.4, adv_flag=0 ignores it."""
