@@ -452,6 +452,57 @@ def test_dense_delta_trajectory_well_conditioned():
         assert e_g < 1e-3 and e_d < 1e-3
 
 
+VARIANTS = {
+    # name: (oracle loss, engine step kwargs, labels are the target class)
+    "targeted_prob": (lambda lg, y: am.tf_improve_adversarial_loss(lg, y, 0.05, True, False)[0], dict(targeted=True), True),
+    "use_logits": (lambda lg, y: am.tf_improve_adversarial_loss(lg, y, 0.05, False, True)[0], dict(use_logits=True), False),
+    "targeted_logits": (lambda lg, y: am.tf_improve_adversarial_loss(lg, y, 0.05, True, True)[0], dict(targeted=True, use_logits=True), True),
+    "ce": (lambda lg, y: am.tf_ce_adversarial_loss(lg, y, False)[0], dict(improve_loss=False), False),
+    "ce_targeted": (lambda lg, y: am.tf_ce_adversarial_loss(lg, y, True)[0], dict(improve_loss=False, targeted=True), True),
+    "cyclic": (lambda lg, y: am.tf_improve_adversarial_loss(lg, y, 0.05, False, False)[0], dict(cyclic=True, cyclic_pert=True), False),
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_attack_variants_trajectory_well_conditioned(variant):
+    """the attack variants of SURVEY N4 through the COMPLETE iteration (not only the loss head): targeted attacks, logits-mode margin,
+    cross-entropy losses (kinetics_i3d_utils.py:253-307) and the cyclic clip / perturbation rolls (:100-142) -- adversarial loss,
+    logits and learned delta of 2 iterations within 1e-3 of the fp64 oracle on the well-conditioned fixture."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    loss_fn, kw, targeted = VARIANTS[variant]
+    W, Wt, xu = _coherent_fixture()
+    W64 = Wt[torch.float64]
+    x64 = xu.double() / 128 - 1
+    y = torch.tensor([100]) if targeted else i3d_ref.i3d_logits(x64, W64).argmax(-1)
+    eng = FlickerI3D(W, batch_size=1, frames=T, dtype="f32")
+    shifts = iter([3, 11, 7, 2, 5, 9])                      # (clip shift, perturbation shift) per iteration when the rolls are on
+    if "cyclic" in kw:
+        eng._rng = type("FixedShifts", (), {"integers": lambda self, lo, hi: next(shifts)})()
+        oracle_shifts = iter([3, 11, 7, 2, 5, 9])
+    d = torch.zeros(T, 1, 1, 3, dtype=torch.float64)
+    m, v = torch.zeros_like(d), torch.zeros_like(d)
+    for it in range(1, 3):
+        dv = d.clone().requires_grad_(True)
+        if "cyclic" in kw:
+            sx, sp = next(oracle_shifts), next(oracle_shifts)
+            xa = am.tf_apply(x64, dv, shift_x=sx, cyclic_flag=1.0, shift_p=sp, cyclic_pert_flag=1.0)
+        else:
+            xa = am.tf_apply(x64, dv)
+        lg = i3d_ref.i3d_logits(xa, W64)
+        adv = loss_fn(lg, y)
+        total, _ = am.tf_total_loss(adv, dv, *BETAS)
+        (g,) = torch.autograd.grad(total, dv)
+        d, m, v = am.tf_adam_step(d, g, m, v, it)
+        res = eng.step(xu.cuda(), y.cuda(), lr=1e-3, beta0=BETAS[0], beta1=BETAS[1], beta2=BETAS[2], beta3=BETAS[3], margin=0.05, **kw).host()
+        e_d, e_l = rel_err(eng.perturbation.cpu(), d), rel_err(eng._logits.cpu(), lg.detach())
+        print(f"[{variant}] iter {it}: adv {res['adv_loss']:.7f} (fp64 oracle {adv.item():.7f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e}")
+        assert res["adv_loss"] == pytest.approx(adv.item(), rel=1e-3, abs=1e-7)
+        assert e_d < 1e-3 and e_l < 1e-3
+        assert float(g.abs().max()) > 0
+
+
 def test_inference_engine_cyclic_flags():
     """kinetics_i3d_inference (kinetics_i3d_utils.py:574-647): rolls of the clip / the perturbation are tf.roll by the drawn
     shift, the perturbation is NOT clipped to 0.4, adv_flag=0 ignores it."""
