@@ -503,6 +503,36 @@ def test_attack_variants_trajectory_well_conditioned(variant):
         assert float(g.abs().max()) > 0
 
 
+def test_universal_batch_trajectory_well_conditioned():
+    """the universal attack's batch semantics (one shared delta, margin loss SUMMED over the clips of the batch,
+    kinetics_i3d_utils.py:285; i3d_adversarial_main_universal.py:129-133) against the fp64 oracle: 2 different clips, 2 iterations,
+    learned delta / logits / loss at 1e-3 on the well-conditioned fixture."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W, Wt, xu = _coherent_fixture()
+    W64 = Wt[torch.float64]
+    xb = torch.cat([xu, torch.from_numpy(i3d_spec.synthetic_clip_u8(1, T, seed=99))], 0)
+    x64 = xb.double() / 128 - 1
+    y = i3d_ref.i3d_logits(x64, W64).argmax(-1)
+    eng = FlickerI3D(W, batch_size=2, frames=T, dtype="f32")
+    d = torch.zeros(T, 1, 1, 3, dtype=torch.float64)
+    m, v = torch.zeros_like(d), torch.zeros_like(d)
+    for it in range(1, 3):
+        dv = d.clone().requires_grad_(True)
+        lg = i3d_ref.i3d_logits(am.tf_apply(x64, dv), W64)
+        adv, _, _ = am.tf_improve_adversarial_loss(lg, y, 0.05, False, False)
+        total, _ = am.tf_total_loss(adv, dv, *BETAS)
+        (g,) = torch.autograd.grad(total, dv)
+        d, m, v = am.tf_adam_step(d, g, m, v, it)
+        res = eng.step(xb.cuda(), y.cuda(), lr=1e-3, beta0=BETAS[0], beta1=BETAS[1], beta2=BETAS[2], beta3=BETAS[3], margin=0.05).host()
+        e_d, e_l = rel_err(eng.perturbation.cpu(), d), rel_err(eng._logits.cpu(), lg.detach())
+        print(f"iter {it}: adv (sum over 2 clips) {res['adv_loss']:.7f} (fp64 oracle {adv.item():.7f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e}")
+        assert res["adv_loss"] == pytest.approx(adv.item(), rel=1e-3, abs=1e-7)
+        assert e_d < 1e-3 and e_l < 1e-3
+
+
 def test_inference_engine_cyclic_flags():
     """kinetics_i3d_inference (kinetics_i3d_utils.py:574-647): rolls of the clip / the perturbation are tf.roll by the drawn
     shift, the perturbation is NOT clipped to 0.4, adv_flag=0 ignores it."""
