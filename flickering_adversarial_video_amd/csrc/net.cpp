@@ -195,19 +195,27 @@ struct flk_net {
     return FLK_OK;
   }
 
+  // ---- batch slices: the emitters below build their operator for clips [bs_b0, bs_b0 + bs_nb) of every tensor (default: all).
+  // The I3D stem segment is emitted once per half of the batch on two streams, so that the HBM-bound pools / 1x1x1 of one half
+  // run beside the MFMA-bound convolutions of the other (per-sample arithmetic is unchanged: tiles never span clips).
+  int bs_b0 = 0, bs_nb = 0;         // bs_nb == 0: the whole batch
+  int nbatch() const { return bs_nb ? bs_nb : B; }
+  char* bp(const Act& a) const { return (char*)a.p + (size_t)bs_b0 * a.T * a.H * a.W * a.ld * esz(); }
+  const char* bp(const void* p, const Act& geom, int ld) const { return p ? (const char*)p + (size_t)bs_b0 * geom.T * geom.H * geom.W * ld * esz() : nullptr; }
+
   // ---- op emitters -------------------------------------------------------------------------------
   // forward Unit3D: out[:, coff:coff+cout] = relu(conv(in[:, in_coff:in_coff+cin]) * scale + bias), stride 1 SAME
   void emit_conv_fwd(ConvLayer* L, const Act& in, int in_coff, const Act& out, int out_coff, const void* const* in_ptr = nullptr) {
     flk_conv_args a{};
-    a.in = in.p; a.in_ld = in.ld; a.in_coff = in_coff; a.cin = L->cin;
-    a.B = B; a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
+    a.in = bp(in); a.in_ld = in.ld; a.in_coff = in_coff; a.cin = L->cin;
+    a.B = nbatch(); a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
     a.kt = L->kt; a.kh = L->kh; a.kw = L->kw; a.st = a.sh = a.sw = 1;
     a.pt = (L->kt - 1) / 2; a.ph = (L->kh - 1) / 2; a.pw = (L->kw - 1) / 2;
     a.To = out.T; a.Ho = out.H; a.Wo = out.W;
-    a.out = out.p; a.out_ld = out.ld; a.out_coff = out_coff; a.cout = L->cout;
+    a.out = bp(out); a.out_ld = out.ld; a.out_coff = out_coff; a.cout = L->cout;
     a.OT = out.T; a.OH = out.H; a.OW = out.W; a.ost = a.osh = a.osw = 1;
     a.scale = L->d_scale; a.bias = L->d_bias; a.relu = 1;
-    const double macs = (double)B * out.T * out.H * out.W * L->kt * L->kh * L->kw * L->cin * L->cout;
+    const double macs = (double)nbatch() * out.T * out.H * out.W * L->kt * L->kh * L->kw * L->cin * L->cout;
     flk_conv_weights* wf = L->wf;
     const int dt = dtype;
     attach_splitk(a, wf);
@@ -220,16 +228,16 @@ struct flk_net {
   void emit_conv_bwd(ConvLayer* L, const Act& G, int g_coff, const Act& gin, int gin_coff, const void* add, int add_ld,
                      int add_coff, const Act* mask, int mask_coff, void* const* out_ptr = nullptr) {
     flk_conv_args a{};
-    a.in = G.p; a.in_ld = G.ld; a.in_coff = g_coff; a.cin = L->cout;
-    a.B = B; a.Ti = G.T; a.Hi = G.H; a.Wi = G.W;
+    a.in = bp(G); a.in_ld = G.ld; a.in_coff = g_coff; a.cin = L->cout;
+    a.B = nbatch(); a.Ti = G.T; a.Hi = G.H; a.Wi = G.W;
     a.kt = L->kt; a.kh = L->kh; a.kw = L->kw; a.st = a.sh = a.sw = 1;
     a.pt = L->kt - 1 - (L->kt - 1) / 2; a.ph = L->kh - 1 - (L->kh - 1) / 2; a.pw = L->kw - 1 - (L->kw - 1) / 2;
     a.To = gin.T; a.Ho = gin.H; a.Wo = gin.W;
-    a.out = gin.p; a.out_ld = gin.ld; a.out_coff = gin_coff; a.cout = L->cin;
+    a.out = bp(gin); a.out_ld = gin.ld; a.out_coff = gin_coff; a.cout = L->cin;
     a.OT = gin.T; a.OH = gin.H; a.OW = gin.W; a.ost = a.osh = a.osw = 1;
-    a.add = add; a.add_ld = add_ld; a.add_coff = add_coff;
-    if (mask) { a.mask = mask->p; a.mask_ld = mask->ld; a.mask_coff = mask_coff; }
-    const double macs = (double)B * gin.T * gin.H * gin.W * L->kt * L->kh * L->kw * L->cin * L->cout;
+    a.add = bp(add, gin, add_ld); a.add_ld = add_ld; a.add_coff = add_coff;
+    if (mask) { a.mask = bp(*mask); a.mask_ld = mask->ld; a.mask_coff = mask_coff; }
+    const double macs = (double)nbatch() * gin.T * gin.H * gin.W * L->kt * L->kh * L->kw * L->cin * L->cout;
     flk_conv_weights* wb = L->wb;
     const int dt = dtype;
     attach_splitk(a, wb);
@@ -238,23 +246,26 @@ struct flk_net {
                        return flk_conv3d(&a, wb, dt, s);
                      }});
   }
-  struct PoolRec { flk_pool_args a; };
+  struct PoolRec { flk_pool_args a; uint8_t* idx_base = nullptr; };
   int emit_pool_fwd(const std::string& name, const Act& in, int C, int kt, int kh, int kw, int st, int sh, int sw, Act& out,
                     PoolRec& rec, bool relu_input = false) {
     flk_pool_args a{};
     a.relu_input = relu_input;
-    a.in = in.p; a.in_ld = in.ld; a.in_coff = 0; a.C = C;
-    a.B = B; a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
+    a.in = bp(in); a.in_ld = in.ld; a.in_coff = 0; a.C = C;
+    a.B = nbatch(); a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
     a.kt = kt; a.kh = kh; a.kw = kw; a.st = st; a.sh = sh; a.sw = sw;
     same_pad(in.T, kt, st, a.To, a.pt); same_pad(in.H, kh, sh, a.Ho, a.ph); same_pad(in.W, kw, sw, a.Wo, a.pw);
-    int rc = new_act(out, a.To, a.Ho, a.Wo, C);
-    if (rc) return rc;
-    void* idx = nullptr;
-    if ((rc = dmalloc(&idx, (size_t)B * a.To * a.Ho * a.Wo * C))) return rc;
-    a.out = out.p; a.out_ld = C; a.out_coff = 0; a.idx = (uint8_t*)idx;
+    int rc;
+    if (!out.p && (rc = new_act(out, a.To, a.Ho, a.Wo, C))) return rc;      // (a later batch slice reuses the buffers of the first:
+    if (!rec.idx_base) {                                                      //  its PoolRec arrives with idx_base already set)
+      void* idx = nullptr;
+      if ((rc = dmalloc(&idx, (size_t)B * a.To * a.Ho * a.Wo * C))) return rc;
+      rec.idx_base = (uint8_t*)idx;
+    }
+    a.out = bp(out); a.out_ld = C; a.out_coff = 0; a.idx = rec.idx_base + (size_t)bs_b0 * a.To * a.Ho * a.Wo * C;
     rec.a = a;
     const int dt = dtype;
-    const double bytes = ((double)in.numel(B) + out.numel(B)) * esz() + (double)B * a.To * a.Ho * a.Wo * C;
+    const double bytes = ((double)in.numel(nbatch()) + out.numel(nbatch())) * esz() + (double)nbatch() * a.To * a.Ho * a.Wo * C;
     fwd.push_back(Op{name, K_POOL, 0.0, bytes, [a, dt](hipStream_t s) { return flk_maxpool3d_fwd(&a, dt, s); }});
     return FLK_OK;
   }
@@ -263,9 +274,13 @@ struct flk_net {
     const int dt = dtype;
     const void* mp = mask ? mask->p : nullptr;
     const int mld = mask ? mask->ld : 0;
-    const double bytes = ((double)gout.numel(B) + gin.numel(B) + (mask ? gin.numel(B) : 0)) * esz() + (double)B * a.To * a.Ho * a.Wo * a.C;
-    bwd.push_back(Op{name + "/grad", K_POOL, 0.0, bytes, [a, dt, gout, gin, mp, mld](hipStream_t s) {
-                       return flk_maxpool3d_bwd(&a, gout.p, gout.ld, 0, gin.p, gin.ld, 0, mp, mld, 0, dt, s);
+    const int nb = a.B;                                  // the slice the forward operator was built for (bs_b0 must match)
+    const double bytes = ((double)gout.numel(nb) + gin.numel(nb) + (mask ? gin.numel(nb) : 0)) * esz() + (double)nb * a.To * a.Ho * a.Wo * a.C;
+    const void* gop = bp(gout);
+    void* gip = bp(gin);
+    if (mask) mp = bp(*mask);
+    bwd.push_back(Op{name + "/grad", K_POOL, 0.0, bytes, [a, dt, gop, gip, gout, gin, mp, mld](hipStream_t s) {
+                       return flk_maxpool3d_bwd(&a, gop, gout.ld, 0, gip, gin.ld, 0, mp, mld, 0, dt, s);
                      }});
   }
 
@@ -331,68 +346,98 @@ int flk_net::build_i3d() {
   named["Conv3d_1a_7x7"] = {a1, 64};
   named["grad:Conv3d_1a_7x7"] = {G1, 64};
   stem_G = G1;
+  // ---- Conv3d_2b_1x1, Conv3d_2c_3x3 and the buffers of the segment ----
+  ConvLayer *c2b = nullptr, *c2c = nullptr;
+  if ((rc = make_unit3d("Conv3d_2b_1x1", 1, 1, 1, 64, 64, &c2b)) || (rc = pack(c2b))) return rc;
+  if ((rc = make_unit3d("Conv3d_2c_3x3", 3, 3, 3, 64, 192, &c2c)) || (rc = pack(c2c))) return rc;
+  Act p2a, Gp2a, a2b, G2b, a2c, G2c, p3a, Gp3a;
+  // The segment up to Mixed_3b alternates MFMA-bound convolutions (Conv3d_1a, Conv3d_2c) with HBM-bound pools and a 1x1x1, one
+  // kernel at a time.  With an even batch >= 4 it is emitted once per HALF of the batch, the halves on two streams: the pools of one
+  // half run beside the convolutions of the other.  FLK_STEM_SPLIT=0: one pass over the whole batch (round-1 order).
+  const bool split = B >= 4 && B % 2 == 0 && !(getenv("FLK_STEM_SPLIT") && atoi(getenv("FLK_STEM_SPLIT")) == 0);
+  const int nhalf = split ? 2 : 1;
+  PoolRec r2a[2], r3a[2];
+  const double stem_macs = (double)(B / nhalf) * T1 * H1 * W1 * 343.0 * 3 * 64;   // algorithmic (7x7x7x3), not the padded 4x4x4x32
+  // Measured (bs 8): both halves started together 6.94 ms per step against 6.99 unsplit; the second half started one kernel late
+  // (so that a pool always meets a convolution) 7.00 -- a convolution and a pool slow each other about as much as they overlap,
+  // the gain comes from the tails of the half-size launches filling each other.
+  if (split) push_sync(fwd, K_FORK, 1);
+  for (int h = 0; h < nhalf; ++h) {
+    if (split) { bs_b0 = h * (B / 2); bs_nb = B / 2; }
+    const size_t m0 = fwd.size();
+    {
+      // SAME padding of the 7/2 conv on an even size is (2,3) -> in s2d space taps j=0..3 read o-1+j: pad-before 1
+      flk_conv_args a{};
+      a.in_ld = 32; a.in_coff = 0; a.cin = 32; a.B = nbatch(); a.Ti = T1; a.Hi = H1; a.Wi = W1;
+      a.kt = a.kh = a.kw = 4; a.st = a.sh = a.sw = 1; a.pt = a.ph = a.pw = 1;
+      a.To = T1; a.Ho = H1; a.Wo = W1; a.out = bp(a1); a.out_ld = 64; a.cout = 64;
+      a.OT = T1; a.OH = H1; a.OW = W1; a.ost = a.osh = a.osw = 1;
+      a.scale = stem->d_scale; a.bias = stem->d_bias; a.relu = 1;
+      flk_conv_weights* wf = stem->wf;
+      const int dt = dtype;
+      const size_t in_off = (size_t)bs_b0 * T1 * H1 * W1 * 32 * esz();
+      fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * stem_macs, 0.0, [this, a, wf, dt, in_off](hipStream_t s) mutable {
+                         a.in = (const char*)x_in + in_off;
+                         a.pos_bias = cur_pos_bias;            // flk_net_forward_flicker: the perturbation enters here, in fp32
+                         return flk_conv3d(&a, wf, dt, s);
+                       }});
+    }
+    // main pools read ReLU outputs whose gradient is masked by (input > 0): relu_input makes the mask read unnecessary
+    if (h) { r2a[h].idx_base = r2a[0].idx_base; r3a[h].idx_base = r3a[0].idx_base; }
+    if ((rc = emit_pool_fwd("MaxPool3d_2a_3x3", a1, 64, 1, 3, 3, 1, 2, 2, p2a, r2a[h], true))) return rc;
+    if (h == 0) {
+      if ((rc = new_act(Gp2a, p2a.T, p2a.H, p2a.W, 64))) return rc;
+      if ((rc = new_act(a2b, p2a.T, p2a.H, p2a.W, 64)) || (rc = new_act(G2b, p2a.T, p2a.H, p2a.W, 64))) return rc;
+      if ((rc = new_act(a2c, p2a.T, p2a.H, p2a.W, 192)) || (rc = new_act(G2c, p2a.T, p2a.H, p2a.W, 192))) return rc;
+    }
+    emit_conv_fwd(c2b, p2a, 0, a2b, 0);
+    emit_conv_fwd(c2c, a2b, 0, a2c, 0);
+    if ((rc = emit_pool_fwd("MaxPool3d_3a_3x3", a2c, 192, 1, 3, 3, 1, 2, 2, p3a, r3a[h], true))) return rc;
+    if (h == 0 && (rc = new_act(Gp3a, p3a.T, p3a.H, p3a.W, 192))) return rc;
+    set_lane(fwd, m0, h);
+  }
+  bs_b0 = bs_nb = 0;
+  if (split) push_sync(fwd, K_JOIN, 1);
+  named["MaxPool3d_2a_3x3"] = {p2a, 64};
+  named["grad:MaxPool3d_2a_3x3"] = {Gp2a, 64};
+  named["Conv3d_2b_1x1"] = {a2b, 64};
+  named["Conv3d_2c_3x3"] = {a2c, 192};
+  named["grad:Conv3d_2b_1x1"] = {G2b, 64};
+  named["grad:Conv3d_2c_3x3"] = {G2c, 192};
+  named["MaxPool3d_3a_3x3"] = {p3a, 192};
+  named["grad:MaxPool3d_3a_3x3"] = {Gp3a, 192};
   {
-    // SAME padding of the 7/2 conv on an even size is (2,3) -> in s2d space taps j=0..3 read o-1+j: pad-before 1
-    flk_conv_args a{};
-    a.in_ld = 32; a.in_coff = 0; a.cin = 32; a.B = B; a.Ti = T1; a.Hi = H1; a.Wi = W1;
-    a.kt = a.kh = a.kw = 4; a.st = a.sh = a.sw = 1; a.pt = a.ph = a.pw = 1;
-    a.To = T1; a.Ho = H1; a.Wo = W1; a.out = a1.p; a.out_ld = 64; a.cout = 64;
-    a.OT = T1; a.OH = H1; a.OW = W1; a.ost = a.osh = a.osw = 1;
-    a.scale = stem->d_scale; a.bias = stem->d_bias; a.relu = 1;
-    const double macs = (double)B * T1 * H1 * W1 * 343.0 * 3 * 64;   // algorithmic (7x7x7x3), not the padded 4x4x4x32
-    flk_conv_weights* wf = stem->wf;
-    const int dt = dtype;
-    fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * macs, 0.0, [this, a, wf, dt](hipStream_t s) mutable {
-                       a.in = x_in;
-                       a.pos_bias = cur_pos_bias;            // flk_net_forward_flicker: the perturbation enters here, in fp32
-                       return flk_conv3d(&a, wf, dt, s);
-                     }});
+    // backward of the segment (emitters run in reverse: this block's second emitter runs first)
     flk_conv_args g{};
     g.in = G1.p; g.in_ld = 64; g.cin = 64; g.B = B; g.Ti = T1; g.Hi = H1; g.Wi = W1;
     g.kt = g.kh = g.kw = 4; g.st = g.sh = g.sw = 1; g.pt = g.ph = g.pw = 2;   // k-1-pad
     g.To = T1; g.Ho = H1; g.Wo = W1; g.out_ld = 32; g.cout = 32;
     g.OT = T1; g.OH = H1; g.OW = W1; g.ost = g.osh = g.osw = 1;
     flk_conv_weights* wb = stem->wb;
+    const int dt = dtype;
+    const double macs = stem_macs * nhalf;
     bwd_emit.push_back([this, g, wb, dt, macs]() {
       bwd.push_back(Op{"Conv3d_1a_7x7/dgrad", K_CONV, 2.0 * macs, 0.0, [this, g, wb, dt](hipStream_t s) mutable {
                          g.out = gx_in;
                          return flk_conv3d(&g, wb, dt, s);
                        }});
     });
+    const PoolRec r2a0 = r2a[0], r2a1 = r2a[1], r3a0 = r3a[0], r3a1 = r3a[1];
+    bwd_emit.push_back([=]() {
+      if (split) push_sync(bwd, K_FORK, 1);
+      for (int h = 0; h < nhalf; ++h) {
+        if (split) { bs_b0 = h * (B / 2); bs_nb = B / 2; }
+        const size_t m0 = bwd.size();
+        emit_pool_bwd("MaxPool3d_3a_3x3", h ? r3a1 : r3a0, Gp3a, G2c, nullptr);
+        emit_conv_bwd(c2c, G2c, 0, G2b, 0, nullptr, 0, 0, &a2b, 0);
+        emit_conv_bwd(c2b, G2b, 0, Gp2a, 0, nullptr, 0, 0, nullptr, 0);
+        emit_pool_bwd("MaxPool3d_2a_3x3", h ? r2a1 : r2a0, Gp2a, G1, nullptr);
+        set_lane(bwd, m0, h);
+      }
+      bs_b0 = bs_nb = 0;
+      if (split) push_sync(bwd, K_JOIN, 1);
+    });
   }
-
-  // ---- MaxPool3d_2a_3x3 ----
-  Act p2a, Gp2a; PoolRec r2a;
-  // main pools read ReLU outputs whose gradient is masked by (input > 0): relu_input makes the mask read unnecessary
-  if ((rc = emit_pool_fwd("MaxPool3d_2a_3x3", a1, 64, 1, 3, 3, 1, 2, 2, p2a, r2a, true))) return rc;
-  if ((rc = new_act(Gp2a, p2a.T, p2a.H, p2a.W, 64))) return rc;
-  named["MaxPool3d_2a_3x3"] = {p2a, 64};
-  named["grad:MaxPool3d_2a_3x3"] = {Gp2a, 64};
-  bwd_emit.push_back([this, r2a, Gp2a, G1]() { emit_pool_bwd("MaxPool3d_2a_3x3", r2a, Gp2a, G1, nullptr); });
-
-  // ---- Conv3d_2b_1x1, Conv3d_2c_3x3 ----
-  ConvLayer *c2b = nullptr, *c2c = nullptr;
-  if ((rc = make_unit3d("Conv3d_2b_1x1", 1, 1, 1, 64, 64, &c2b)) || (rc = pack(c2b))) return rc;
-  if ((rc = make_unit3d("Conv3d_2c_3x3", 3, 3, 3, 64, 192, &c2c)) || (rc = pack(c2c))) return rc;
-  Act a2b, G2b, a2c, G2c;
-  if ((rc = new_act(a2b, p2a.T, p2a.H, p2a.W, 64)) || (rc = new_act(G2b, p2a.T, p2a.H, p2a.W, 64))) return rc;
-  if ((rc = new_act(a2c, p2a.T, p2a.H, p2a.W, 192)) || (rc = new_act(G2c, p2a.T, p2a.H, p2a.W, 192))) return rc;
-  emit_conv_fwd(c2b, p2a, 0, a2b, 0);
-  emit_conv_fwd(c2c, a2b, 0, a2c, 0);
-  named["Conv3d_2b_1x1"] = {a2b, 64};
-  named["Conv3d_2c_3x3"] = {a2c, 192};
-  named["grad:Conv3d_2b_1x1"] = {G2b, 64};
-  named["grad:Conv3d_2c_3x3"] = {G2c, 192};
-  bwd_emit.push_back([this, c2b, G2b, Gp2a]() { emit_conv_bwd(c2b, G2b, 0, Gp2a, 0, nullptr, 0, 0, nullptr, 0); });
-  bwd_emit.push_back([this, c2c, G2c, G2b, a2b]() { emit_conv_bwd(c2c, G2c, 0, G2b, 0, nullptr, 0, 0, &a2b, 0); });
-
-  // ---- MaxPool3d_3a_3x3 ----
-  Act p3a, Gp3a; PoolRec r3a;
-  if ((rc = emit_pool_fwd("MaxPool3d_3a_3x3", a2c, 192, 1, 3, 3, 1, 2, 2, p3a, r3a, true))) return rc;
-  if ((rc = new_act(Gp3a, p3a.T, p3a.H, p3a.W, 192))) return rc;
-  named["MaxPool3d_3a_3x3"] = {p3a, 192};
-  named["grad:MaxPool3d_3a_3x3"] = {Gp3a, 192};
-  bwd_emit.push_back([this, r3a, Gp3a, G2c]() { emit_pool_bwd("MaxPool3d_3a_3x3", r3a, Gp3a, G2c, nullptr); });
 
   // ---- Inception blocks ----
   struct Blk { const char* name; int c[6]; int pool_before; int pk[3]; int ps[3]; const char* pool_name; };
@@ -988,6 +1033,7 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       in_fork = false;
       if (ms)
         for (int l = 0; l < kSideStreams; ++l) {
+          if (!(op.mask >> l & 1)) continue;              // side streams that took no part in this fork
           FLK_CHECK_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
           FLK_CHECK_HIP(hipStreamWaitEvent(s, n->ev_join[l], 0));
         }
