@@ -21,8 +21,8 @@ state = head + ("+uncommitted" if dirty else "")
 
 def one(pattern):
     g = glob.glob(os.path.join(src, pattern), recursive=True)
-    assert len(g) == 1, (pattern, g)
-    return g[0]
+    assert g, pattern
+    return max(g, key=os.path.getmtime)      # gpurun merges into gpurun_out/ without deleting: an earlier run of the same tag may remain
 
 
 line = [l for l in open(os.path.join(src, "bench_full.json")).read().splitlines() if l.startswith("{")][-1]
