@@ -202,13 +202,17 @@ def main(default_section, argv=None):
         run_eval()                                     # single_class_gen.py:200-208
     if not universal and not last:
         save_checkpoint()                              # :214
+    # i3d_adversarial_main_single_class_gen.py:39-46 / _universal.py:121-127: the loss node is chosen once from the config switches
+    if c.IMPROVE_ADV_LOSS:
+        adversarial_loss = eng.improve_adversarial_loss(margin=c.PROB_MARGIN, targeted=bool(c.TARGETED_ATTACK), logits=bool(c.USE_LOGITS))
+    else:
+        adversarial_loss = eng.ce_adversarial_loss(targeted=bool(c.TARGETED_ATTACK))
     epoch = 0
     while step < max_steps:
         t0, nb = time.time(), 0
         for batch in tio.batches(train_files, B, T, rank, world):
             x, y = to_dev(batch)
-            r = eng.step(x, y, lr=1e-3, beta0=c.LAMBDA, beta1=c.BETA_1, beta2=c.BETA_2, beta3=beta3, margin=c.PROB_MARGIN,
-                         targeted=bool(c.TARGETED_ATTACK), use_logits=bool(c.USE_LOGITS), improve_loss=bool(c.IMPROVE_ADV_LOSS))
+            r = eng.step(x, y, lr=1e-3, beta0=c.LAMBDA, beta1=c.BETA_1, beta2=c.BETA_2, beta3=beta3, **adversarial_loss)
             step += 1; nb += 1
             if tb is not None and step % a.summary_steps == 0:
                 tb.add_step_result(step, r.host(), beta0=c.LAMBDA)

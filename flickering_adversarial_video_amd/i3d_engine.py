@@ -81,7 +81,7 @@ class FlickerI3D:
 
     def __init__(self, weights, batch_size=1, frames=SAMPLE_VIDEO_FRAMES, dtype="bf16", device=0, dense_delta=False,
                  cyclic_flag_default_c=0.0, cyclic_pert_flag_default_c=0.0, default_adv_flag_c=1.0, process_group=None,
-                 seed=0):
+                 seed=0, kinetics_classes=None):
         if not torch.cuda.is_available():
             raise RuntimeError("FlickerI3D needs an MI355X (HIP) device; there is no CPU fallback")
         torch.cuda.set_device(device)
@@ -119,6 +119,12 @@ class FlickerI3D:
         self._dl = torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev)
         self._it = 0
         self._rng = np.random.default_rng(seed)
+        # class names, index = label id (kinetics_i3d_utils.py:68-74 reads data/label_map.txt in the constructor; here the caller passes
+        # the list or a path -- config.load_kinetics_classes -- because the engine has no file dependencies)
+        if isinstance(kinetics_classes, (str, bytes)):
+            from .config import load_kinetics_classes
+            kinetics_classes = load_kinetics_classes(kinetics_classes)
+        self.kinetics_classes = list(kinetics_classes) if kinetics_classes is not None else [str(i) for i in range(NUM_CLASSES)]
 
     @property
     def net_torch_dtype(self):
@@ -176,6 +182,26 @@ class FlickerI3D:
     def __call__(self, inputs, adv_flag=0, cyclic=None):
         """softmax of the (clean by default) clip: kinetics_i3d.__call__ (kinetics_i3d_utils.py:210-212)"""
         return torch.softmax(self.logits(inputs, adv_flag, cyclic), -1)
+
+    predict = __call__                                   # SURVEY 8(b): predict(x, adv_flag)
+
+    def get_kinetics_classes(self):
+        """kinetics_i3d.get_kinetics_classes (kinetics_i3d_utils.py:214-215)"""
+        return self.kinetics_classes
+
+    # The reference's loss methods return the TF loss node that the script adds to its train_op
+    # (i3d_adversarial_main_single_video_npy.py:46-59).  The eager engine has no graph: the same calls return the loss CHOICE as
+    # keyword arguments of step(), so a script reads  loss = k_i3d.improve_adversarial_loss(margin, targeted, logits);
+    # res = k_i3d.step(x, labels, lr=..., beta0=..., **loss).
+    @staticmethod
+    def improve_adversarial_loss(margin=0.05, targeted=False, logits=False):
+        """kinetics_i3d.improve_adversarial_loss(margin, targeted, logits) (kinetics_i3d_utils.py:253-288)"""
+        return dict(improve_loss=True, margin=float(margin), targeted=bool(targeted), use_logits=bool(logits))
+
+    @staticmethod
+    def ce_adversarial_loss(targeted=False):
+        """kinetics_i3d.ce_adversarial_loss(targeted) (kinetics_i3d_utils.py:290-307)"""
+        return dict(improve_loss=False, targeted=bool(targeted))
 
     # ---- one attack iteration ----------------------------------------------------------------------
     def step(self, x, labels, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05, targeted=False,

@@ -40,11 +40,15 @@ def attack_clip(eng, x, label_id, c, max_steps, target_id=None, log_every=100):
         am = int(sm.argmax())
         return am == target_id if targeted else am != label_id
 
+    # reference :37-44: the loss node is chosen once, from the same three config switches
+    if c.IMPROVE_ADV_LOSS:
+        adversarial_loss = eng.improve_adversarial_loss(margin=c.PROB_MARGIN, targeted=targeted, logits=bool(c.USE_LOGITS))
+    else:
+        adversarial_loss = eng.ce_adversarial_loss(targeted=targeted)
     step, last, pending = 0, None, False
     while True:
         # one device pass: scalars of the CURRENT delta (what the reference fetches together with train_op, :213-215), then the update
-        r = eng.step(x, lab, lr=1e-3, beta0=c.LAMBDA, beta1=c.BETA_1, beta2=c.BETA_2, beta3=beta3, margin=c.PROB_MARGIN,
-                     targeted=targeted, use_logits=bool(c.USE_LOGITS), improve_loss=bool(c.IMPROVE_ADV_LOSS), cyclic=cyc)
+        r = eng.step(x, lab, lr=1e-3, beta0=c.LAMBDA, beta1=c.BETA_1, beta2=c.BETA_2, beta3=beta3, cyclic=cyc, **adversarial_loss)
         h = r.host()                       # one host sync per step, like the reference's fetches
         # the reference's second sess.run (:217) evaluates is_adversarial / softmax AFTER the update: the forward of step k+1 is
         # that evaluation for step k (same delta), so the softmax list is filled with one step of lag ...

@@ -40,3 +40,21 @@ def test_label_and_result_names(tmp_path):
     # README.md:71 sample result name of the reference
     assert cfgmod.result_filename("bartending", 0.1, 1.67, 1.19) == "bartending_beta1_0.1_th_1.67%_rg_1.19%.pkl"
     assert len(cfgmod.RESULT_KEYS) == 20
+
+
+def test_engine_surface_mirrors_the_reference_loss_methods():
+    """kinetics_i3d.improve_adversarial_loss(margin, targeted, logits) / ce_adversarial_loss(targeted) /
+    get_kinetics_classes / predict exist on the engine under the reference's names and argument meaning
+    (kinetics_i3d_utils.py:214-215,253-307); the loss methods return the choice as keyword arguments of step()."""
+    import inspect
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    assert FlickerI3D.improve_adversarial_loss(margin=0.1, targeted=True, logits=True) == dict(improve_loss=True, margin=0.1, targeted=True,
+                                                                                            use_logits=True)
+    assert FlickerI3D.improve_adversarial_loss() == dict(improve_loss=True, margin=0.05, targeted=False, use_logits=False)
+    assert FlickerI3D.ce_adversarial_loss(targeted=True) == dict(improve_loss=False, targeted=True)
+    step_params = inspect.signature(FlickerI3D.step).parameters
+    for spec in (FlickerI3D.improve_adversarial_loss(), FlickerI3D.ce_adversarial_loss()):
+        assert set(spec) <= set(step_params)
+    for name in ("get_kinetics_classes", "predict", "evaluate", "__call__", "reset_perturbation"):
+        assert callable(getattr(FlickerI3D, name))
+    assert "kinetics_classes" in inspect.signature(FlickerI3D.__init__).parameters
