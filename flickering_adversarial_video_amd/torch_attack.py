@@ -65,6 +65,26 @@ class Perturbation:
                                    inv_std=tuple(1.0 / s for s in DEFAULT_STD),
                                    lo=self.min_value if adversarial else -inf, hi=self.max_value if adversarial else inf, fold_t=1)
 
+    def forward(self, input):
+        """model.py:80-101: ``input = [x, adversarial]`` -> the perturbed (or, with adversarial False, the untouched) clip.  ``x`` is the
+        reference's NCDHW tensor [B,3,T,H,W] or the channels-last [B,T,H,W,3] the engine works on; the result has x's layout.  The
+        kernel writes the (h,w)-folded tensor the network consumes (flk_perturb_apply_s2d); it is unfolded here."""
+        x, adversarial = input
+        ncdhw = x.dim() == 5 and x.shape[1] == 3 and x.shape[-1] != 3
+        xcl = (x.permute(0, 2, 3, 4, 1) if ncdhw else x).contiguous().float().cuda()
+        B, T, H, W, _ = xcl.shape
+        if T != self.T:
+            raise ValueError(f"clip has {T} frames, the perturbation {self.T}")
+        folded = ops.perturb_apply_s2d(self.apply_args(xcl, bool(adversarial)), torch.float32)      # [B,T,H/2,W/2,16]
+        out = folded[..., :12].reshape(B, T, H // 2, W // 2, 2, 2, 3).permute(0, 1, 2, 4, 3, 5, 6).reshape(B, T, H, W, 3)
+        return out.permute(0, 4, 1, 2, 3).contiguous() if ncdhw else out.contiguous()
+
+    __call__ = forward
+
+    def apply_perturbation(self, x):
+        """model.py:103-105"""
+        return self.forward([x, True])
+
     def clamp_perturbation(self):
         return self.perturbation.clamp(-self.dynamic_max_norm, self.dynamic_max_norm)
 
@@ -92,6 +112,15 @@ class Losses:
         self.beta_1, self.lambda_, self.targeted, self.target_class = beta_1, lambda_, targeted, target_class
         self.margin, self.improve_loss, self.logits, self.attack_type = margin, improve_loss, logits, attack_type
         self.label_prob = None
+
+    def __call__(self, labels, model_logits, prob, perturbation):
+        """model.py:169-175: ``[loss, adv_loss, reg_loss]`` (values; the engine's step takes the gradients from the kernels).
+        ``prob`` is accepted for signature parity -- the kernel recomputes the softmax; ``perturbation`` is the clamped delta in the
+        reference layout [3,T,1,1] / [3,T,H,W] (model.py:1078).  Sets ``label_prob`` like the reference (:232)."""
+        _, _, pc = self.adv(labels, model_logits.contiguous().float(), model_logits.shape[0])
+        adv_loss = pc[:, 0].sum()
+        reg_loss = self.regularization_loss(perturbation)
+        return [adv_loss + self.lambda_ * reg_loss, adv_loss, reg_loss]
 
     def adv(self, labels, model_logits, global_batch, out=None):
         lab = labels if not self.targeted else torch.full_like(labels, self.target_class)
@@ -367,3 +396,30 @@ class FlickerVideoResNet:
                 res = dict(res, prob_clean_input=res["prob_clean_input"].cpu().numpy())
                 np.save(dest, res, allow_pickle=True)
         return out
+
+
+class VideoLearnerAdversarial(FlickerVideoResNet):
+    """The reference's class name and constructor keywords (model.py:337-347: ``dataset, num_classes, base_model, sample_length,
+    cyclic_pert, l_inf_pert_norm, attack_type, labaels_id_to_text`` [sic]) over the HIP engine.  ``dataset`` only supplies
+    ``sample_length`` / batch size when it has them (the decord mp4 loader stays out of scope); ``weights`` = torchvision
+    ``state_dict`` arrays or a ``.pth`` / ``.npz`` path (videoresnet_spec.load_weights) replaces ``pretrained=True``.
+    ``.pert_model``, ``.model_name``, ``.results``, ``.fit``, ``.fit_many_videos``, ``.fit_single_video_attack`` as in the reference."""
+
+    def __init__(self, dataset=None, num_classes=400, base_model="r2plus1d_18", sample_length=None, cyclic_pert=False, l_inf_pert_norm=0.1,
+                 attack_type="flickering", labaels_id_to_text=None, weights=None, batch_size=None, image_size=112, dtype="bf16", device=0,
+                 process_group=None):
+        from . import videoresnet_spec as vs
+        if weights is None:
+            raise ValueError("weights: a torchvision state_dict ({name: array}) or a .pth / .npz path -- there is no network to download "
+                             "the pretrained checkpoint the reference uses (model.py:421)")
+        if isinstance(weights, (str, bytes)):
+            weights = vs.load_weights(weights, base_model)
+        if sample_length is None:
+            sample_length = getattr(dataset, "sample_length", 16)
+        if batch_size is None:
+            batch_size = getattr(dataset, "batch_size", 1)
+        super().__init__(base_model, weights, batch_size=batch_size, sample_length=sample_length, image_size=image_size, dtype=dtype,
+                         device=device, l_inf_pert_norm=l_inf_pert_norm, cyclic_pert=cyclic_pert, num_classes=num_classes,
+                         process_group=process_group, attack_type=attack_type)
+        self.dataset, self.labaels_id_to_text = dataset, labaels_id_to_text
+        self.results = {}

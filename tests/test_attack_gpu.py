@@ -262,3 +262,52 @@ def test_torch_l12_regulariser_vs_golden(ops, golden):
     M = Adversarial_metrics()
     miss, valid = M.accuracy_for_eval(torch.from_numpy(g["met_adv"]).cuda(), torch.from_numpy(g["met_gt"]).cuda(), clean_pred=torch.from_numpy(g["met_clean"]).cuda())
     assert [float(miss), float(valid)] == list(g["met_miss_valid"])
+
+
+def test_torch_surface_classes_vs_golden(golden):
+    """the reference's class-level interface against the reference's own outputs: ``Perturbation.forward([x, adversarial])`` /
+    ``apply_perturbation`` on NCDHW clips (model.py:80-105) and ``Losses.__call__(labels, logits, prob, delta) -> [loss, adv, reg]`` with
+    its ``label_prob`` attribute (model.py:169-175,232), flicker and dense (L12) perturbations."""
+    from flickering_adversarial_video_amd.torch_attack import Losses, Perturbation
+    g = golden
+    x = torch.from_numpy(g["pert_x"]).cuda()                      # [2,3,16,8,8] NCDHW
+    for tag in ("flk01", "flk02", "dense02"):
+        d = g[f"pert_{tag}_delta"]
+        pm = Perturbation(d.shape, max_norm=float(g[f"pert_{tag}_max_norm"]))
+        pm.init_perturbation(d)
+        out = pm([x, True])
+        assert out.shape == x.shape
+        torch.testing.assert_close(out.cpu(), torch.from_numpy(g[f"pert_{tag}_xadv"]), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(pm.apply_perturbation(x).cpu(), torch.from_numpy(g[f"pert_{tag}_xadv"]), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(pm.forward([x, False]).cpu(), torch.from_numpy(g[f"pert_{tag}_clean"]), rtol=0, atol=0)
+        cl = pm([x.permute(0, 2, 3, 4, 1).contiguous(), True])     # channels-last in, channels-last out
+        torch.testing.assert_close(cl.permute(0, 4, 1, 2, 3).cpu(), torch.from_numpy(g[f"pert_{tag}_xadv"]), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(pm.get_perturbation()[0].cpu(), torch.from_numpy(g[f"pert_{tag}_clamped"]), rtol=0, atol=0)
+    lg, labels = torch.from_numpy(g["loss_logits"]).cuda(), torch.from_numpy(g["loss_labels"]).cuda()
+    prob = torch.softmax(lg, 1)
+    for kind, attack_type in (("flk", "flickering"), ("dense", "L12")):
+        delta = torch.from_numpy(g[f"loss_{kind}_delta"]).cuda()
+        for mode, improve, use_logits in (("improve_prob", True, False), ("improve_logits", True, True), ("ce", False, False)):
+            crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=improve, logits=use_logits, attack_type=attack_type)
+            loss, adv, reg = crit(labels, lg, prob, delta)
+            ref = g[f"loss_{kind}_{mode}_out"]
+            np.testing.assert_allclose([float(loss), float(adv), float(reg)], ref, rtol=1e-4, atol=1e-7, err_msg=f"{kind} {mode}")
+            np.testing.assert_allclose(crit.label_prob.cpu().numpy().reshape(-1), g[f"loss_{kind}_{mode}_label_prob"].reshape(-1), rtol=1e-5)
+
+
+def test_video_learner_adversarial_name_and_keywords():
+    """VideoLearnerAdversarial(dataset, num_classes, base_model, sample_length, cyclic_pert, l_inf_pert_norm, attack_type,
+    labaels_id_to_text) (model.py:337-347) constructs the HIP engine and runs an iteration; .pert_model / .model_name / .results exist"""
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import Losses, VideoLearnerAdversarial
+    W = vs.synthetic_weights("r3d_18", 7)
+    learner = VideoLearnerAdversarial(None, num_classes=400, base_model="r3d_18", sample_length=8, cyclic_pert=False, l_inf_pert_norm=0.1,
+                                      attack_type="flickering", labaels_id_to_text={0: "a"}, weights=W, image_size=32, dtype="f32")
+    assert learner.model_name == "r3d_18" and learner.results == {} and learner.pert_model.size == (3, 8, 1, 1)
+    assert learner.pert_model.max_norm == 0.1
+    x = torch.from_numpy(vs.synthetic_clip(1, 8, 32, 32, seed=3)).cuda()
+    y = learner.logits(x).argmax(-1).clone()
+    r = learner.step(x, y, Losses(improve_loss=True)).host()
+    assert np.isfinite(r["adv_loss"]) and float(learner.pert_model.perturbation.abs().max()) > 0
+    with pytest.raises(ValueError):
+        VideoLearnerAdversarial(None, base_model="r3d_18")
