@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflicker_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "pool.hip", "head.hip", "attack.hip", "stem_grad.hip", "net.cpp"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "pool.hip", "head.hip", "attack.hip", "stem_grad.hip", "net.cpp", "comm.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-x", "hip"]
 
@@ -50,7 +50,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -42,9 +42,65 @@ def force_collective():
     return os.environ.get("FLK_FORCE_COLLECTIVE", "0") == "1" and dist.is_available() and dist.is_initialized()
 
 
+class DirectRccl:
+    """The all-reduce through the C ABI (flk_allreduce_sum_f32: RCCL on the caller's HIP stream, no event hop between the attack
+    kernels and the collective) instead of torch.distributed's own NCCL binding.  Opt-in (FLK_RCCL_DIRECT=1): torch.distributed is
+    still what launches the ranks and carries the 128-byte RCCL id from rank 0 to the others."""
+
+    def __init__(self, device, group=None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self._C = _lib, C
+        lib = _lib.load()
+        rk, world = rank(group), world_size(group)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rk == 0:
+            buf = (C.c_char * 128)()
+            _lib.check(lib.flk_comm_unique_id(buf))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            dev_uid = uid.cuda(device) if dist.get_backend(group) == "nccl" else uid
+            dist.broadcast(dev_uid, src=0, group=group)
+            uid = dev_uid.cpu()
+        self.handle = C.c_void_p()
+        raw = (C.c_char * 128).from_buffer_copy(bytes(uid.numpy().tobytes()))
+        _lib.check(lib.flk_comm_create(raw, rk, world, int(device), C.byref(self.handle)))
+        self.world = world
+
+    def allreduce_sum_(self, t):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._lib.check(self._lib.load().flk_allreduce_sum_f32(self.handle, self._C.c_void_p(t.data_ptr()), t.numel(),
+                                                                self._C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return t
+
+    def close(self):
+        if self.handle:
+            self._lib.load().flk_comm_destroy(self.handle)
+            self.handle = None
+
+
+_direct = {}
+
+
+def direct_rccl(device, group=None):
+    """the process-wide DirectRccl communicator of ``group`` (created on first use) when FLK_RCCL_DIRECT=1, else None"""
+    import os
+    if os.environ.get("FLK_RCCL_DIRECT", "0") != "1":
+        return None
+    key = id(group)
+    if key not in _direct:
+        _direct[key] = DirectRccl(device, group)
+    return _direct[key]
+
+
 def allreduce_sum_(payload, group=None):
     """in-place sum over ranks (no-op for a single process unless FLK_FORCE_COLLECTIVE=1)"""
     if world_size(group) > 1 or force_collective():
+        # (fp32 payloads: the gradient / loss sums; the float64 fooling counters of evaluate() stay on torch.distributed)
+        direct_ok = payload.is_cuda and payload.dtype == torch.float32 and payload.is_contiguous()
+        comm = direct_rccl(payload.device.index, group) if direct_ok else None
+        if comm is not None:
+            return comm.allreduce_sum_(payload)
         dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group)
     return payload
 

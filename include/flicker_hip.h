@@ -296,6 +296,18 @@ int flk_net_num_classes(const flk_net* n);
 /* debugging / parity: copy a named activation (fp32, NDHWC) to the host */
 int flk_net_get_activation(flk_net* n, const char* name, float* host_out, int64_t cap_numel, int64_t* dims5);
 
+/* ---- data-parallel exchange: RCCL over xGMI behind the C ABI -------------------------------------------------
+ * Replaces nn.DataParallel's gather of the perturbation gradient (model.py:576-578) / the dead tf.distribute.MirroredStrategy of
+ * i3d_adversarial_main_universal.py:309-312: one process per GPU, ONE in-place sum all-reduce per attack iteration of the
+ * (T*3 + 3)-float payload [d(sum adv)/d(delta) | sum adv | sum p_min | sum p_max] (or of the dense gradient), issued on the
+ * caller's stream.  Rank 0 obtains a 128-byte id with flk_comm_unique_id and hands it to the other ranks by any side channel
+ * (the Python host uses its torch.distributed process group); every rank then calls flk_comm_create.  RCCL is loaded at run time. */
+typedef struct flk_comm flk_comm;
+int flk_comm_unique_id(void* id128_out);
+int flk_comm_create(const void* id128, int rank, int world, int device, flk_comm** out);
+int flk_allreduce_sum_f32(flk_comm* c, float* buf, int64_t n, void* stream);
+int flk_comm_destroy(flk_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,7 +117,16 @@ def _rccl_worker(port, q):
         try:
             run("rccl:")
             out["backend"] = dist.get_backend()
+            # the same collectives through the C ABI (flk_comm_* / flk_allreduce_sum_f32: RCCL on the engine's own stream)
+            os.environ["FLK_RCCL_DIRECT"] = "1"
+            run("cabi:")
+            from flickering_adversarial_video_amd import parallel
+            comm = parallel.direct_rccl(0)
+            out["cabi_comm"] = comm is not None and comm.world == 1
+            t = torch.arange(1000, dtype=torch.float32, device="cuda")
+            out["cabi_identity"] = bool(torch.equal(comm.allreduce_sum_(t.clone()), t))
         finally:
+            os.environ.pop("FLK_RCCL_DIRECT", None)
             dist.destroy_process_group()
         q.put(out)
     except Exception as e:      # noqa: BLE001 -- report instead of hanging the parent on q.get
@@ -144,6 +153,11 @@ def test_rccl_collectives_execute_world_size_one():
         assert out["plain:" + k][1] == out["rccl:" + k][1]
     assert out["rccl:dense"][2] == pytest.approx(38.535168)                # the dense all-reduce payload in MB
     assert out["plain:eval"] == out["rccl:eval"]
+    # ... and through the C-ABI communicator (FLK_RCCL_DIRECT=1)
+    assert out["cabi_comm"] and out["cabi_identity"]
+    for k in ("flicker", "dense"):
+        np.testing.assert_array_equal(out["plain:" + k][0], out["cabi:" + k][0])
+        assert out["plain:" + k][1] == out["cabi:" + k][1]
 
 
 def _dense_worker(rk, world, port, labels, q):
