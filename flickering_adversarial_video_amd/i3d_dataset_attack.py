@@ -30,7 +30,7 @@ import time
 import numpy as np
 import torch
 
-from . import config as cfgmod, i3d_spec, tb_events, tf_checkpoint, tfrecord_io as tio
+from . import config as cfgmod, i3d_spec, prefetch, tb_events, tf_checkpoint, tfrecord_io as tio
 from .i3d_engine import FlickerI3D
 
 ADAM_B1, ADAM_B2 = 0.9, 0.999        # tf.train.AdamOptimizer defaults (i3d_adversarial_main_single_class_gen.py:83)
@@ -165,10 +165,11 @@ def main(default_section, argv=None):
         y = torch.from_numpy(y).cuda()
         # training feeds the target class as the label of a targeted attack (single_class_gen.py:226-229); evaluation counts a
         # clip as valid when its CLEAN prediction equals the TRUE label (kinetics_i3d_utils.py:241-243)
-        return torch.from_numpy(x).cuda(), (torch.full_like(y, target_id) if (c.TARGETED_ATTACK and not true_labels) else y)
+        x = x if torch.is_tensor(x) else torch.from_numpy(x).cuda()        # (prefetch.DeviceBatches yields device tensors)
+        return x, (torch.full_like(y, target_id) if (c.TARGETED_ATTACK and not true_labels) else y)
 
     def evaluate():
-        it = (to_dev(b, true_labels=True) for b in tio.batches(val_files, B, T, rank, world))
+        it = (to_dev(b, true_labels=True) for b in prefetch.DeviceBatches(val_files, B, T, rank, world))
         # the reference evaluates with cyclic=0 (single_class_gen.py:202,340)
         return eng.evaluate(it, bool(c.TARGETED_ATTACK), target_id, cyclic=0.0)
 
@@ -207,10 +208,11 @@ def main(default_section, argv=None):
         adversarial_loss = eng.improve_adversarial_loss(margin=c.PROB_MARGIN, targeted=bool(c.TARGETED_ATTACK), logits=bool(c.USE_LOGITS))
     else:
         adversarial_loss = eng.ce_adversarial_loss(targeted=bool(c.TARGETED_ATTACK))
+    train_batches = prefetch.DeviceBatches(train_files, B, T, rank, world)
     epoch = 0
     while step < max_steps:
         t0, nb = time.time(), 0
-        for batch in tio.batches(train_files, B, T, rank, world):
+        for batch in train_batches:          # background reader -> pinned ring -> asynchronous H2D copy (prefetch.py)
             x, y = to_dev(batch)
             r = eng.step(x, y, lr=1e-3, beta0=c.LAMBDA, beta1=c.BETA_1, beta2=c.BETA_2, beta3=beta3, **adversarial_loss)
             step += 1; nb += 1

@@ -76,8 +76,9 @@ def _fields(buf):
         yield fn, wt, v
 
 
-def parse_example(payload):
-    """-> {feature name: bytes | np.int64 array | np.float32 array}"""
+def parse_example(payload, copy=True):
+    """-> {feature name: bytes | np.int64 array | np.float32 array}.  copy=False leaves byte features as memoryviews into ``payload``
+    (a clip is 9.6-13.5 MB: the batch loader copies it exactly once, into the batch array)"""
     buf = memoryview(payload)
     out = {}
     for fn, _, features in _fields(buf):
@@ -94,7 +95,7 @@ def parse_example(payload):
                     feat = v
             for kind, _, lst in _fields(feat):
                 if kind == 1:                                  # BytesList
-                    vals = [bytes(v) for f, _, v in _fields(lst) if f == 1]
+                    vals = [bytes(v) if copy else v for f, _, v in _fields(lst) if f == 1]
                     out[key] = vals[0] if len(vals) == 1 else vals
                 elif kind == 3:                                # Int64List (packed or not)
                     vals = []
@@ -139,9 +140,10 @@ def read_records(path, verify_crc=False):
             yield data
 
 
-def parse_example_uint8(payload, frames=90, size=224):
-    """pre_process_rgb_flow.py:211-236 without the float conversion: (uint8 [T,size,size,3], int64 label)"""
-    ex = parse_example(payload)
+def parse_example_uint8(payload, frames=90, size=224, copy=True):
+    """pre_process_rgb_flow.py:211-236 without the float conversion: (uint8 [T,size,size,3], int64 label); copy=False: the clip is a
+    view into ``payload``"""
+    ex = parse_example(payload, copy)
     video = np.frombuffer(ex["train/video"], dtype=np.uint8)
     per = size * size * 3
     if video.size % per:
@@ -186,8 +188,9 @@ def _read_span(path, off, length):
         return f.read(length)
 
 
-def batches(files, batch_size, frames=90, rank=0, world=1, drop_remainder=True):
-    """uint8 batches [B,T,224,224,3] + labels.
+def batches(files, batch_size, frames=90, rank=0, world=1, drop_remainder=True, buffers=None):
+    """uint8 batches [B,T,224,224,3] + labels.  ``buffers``: optional iterator of ``(clips, labels)`` numpy arrays to fill instead of
+    allocating a new pair per batch (prefetch.DeviceBatches hands in pinned buffers); a batch is then yielded as those arrays.
 
     Data-parallel sharding: the record stream is cut into GLOBAL batches of ``world * batch_size`` consecutive records and
     rank r takes records [r*B, (r+1)*B) of each; the global remainder is dropped.  Every rank therefore yields the SAME number
@@ -199,11 +202,17 @@ def batches(files, batch_size, frames=90, rank=0, world=1, drop_remainder=True):
     spans = []
 
     def load(span_list):
-        clips, labels = [], []
-        for path, off, ln in span_list:
-            v, l = parse_example_uint8(_read_span(path, off, ln), frames)
-            clips.append(v); labels.append(l)
-        return np.stack(clips), np.array(labels, dtype=np.int64)
+        # one read + one copy per clip: the payload is parsed in place and the frames go straight into the batch array
+        # (np.stack of 8 clips took 2 s here -- 30 MB/s -- against 0.03 s for slice assignment)
+        if buffers is not None and len(span_list) == batch_size:
+            clips, labels = next(buffers)
+        else:
+            clips = np.empty((len(span_list), frames, 224, 224, 3), dtype=np.uint8)
+            labels = np.empty(len(span_list), dtype=np.int64)
+        for i, (path, off, ln) in enumerate(span_list):
+            v, labels[i] = parse_example_uint8(_read_span(path, off, ln), frames, copy=False)
+            clips[i] = v
+        return clips, labels
 
     for path in files:
         for off, ln in record_spans(path):

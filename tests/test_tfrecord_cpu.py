@@ -79,3 +79,26 @@ def test_equal_batch_counts_per_rank(tmp_path, n, world, B):
     assert counts == [n // (world * B)] * world == [tio.count_batches(files, B, world)] * world
     seen = [int(l) for k in range(counts[0]) for r in range(world) for l in per_rank[r][k][1]]
     assert seen == [recs[i][1] for i in range(counts[0] * world * B)]        # rank-major within a global batch, nothing read twice
+
+
+def test_prefetcher_yields_the_same_batches_in_order(tmp_path):
+    """prefetch.DeviceBatches (reader thread -> ring of reusable buffers) against the plain loader: same batches, same order, for
+    both ranks of a 2-rank shard; buffers are reused, so a batch is compared before the next one is requested"""
+    import numpy as np
+    from flickering_adversarial_video_amd import prefetch, tfrecord_io as tio
+    rng = np.random.default_rng(3)
+    T = 4
+    clips = [rng.integers(0, 256, (T, 224, 224, 3), dtype=np.uint8) for _ in range(9)]
+    path = str(tmp_path / "a.tfrecords")
+    tio.write_records(path, [tio.make_example(c, i) for i, c in enumerate(clips)])
+    for rank in (0, 1):
+        ref = list(tio.batches([path], 2, frames=T, rank=rank, world=2))
+        assert len(ref) == 2                                   # 9 records -> 2 global batches of 4, remainder dropped
+        n = 0
+        for (x, y), (xr, yr) in zip(prefetch.DeviceBatches([path], 2, T, rank, 2, device="cpu", depth=2), ref):
+            assert (x.numpy() == xr).all() and y.tolist() == yr.tolist()
+            n += 1
+        assert n == 2
+    # two passes over the same object (epochs) restart the reader
+    db = prefetch.DeviceBatches([path], 4, T, device="cpu")
+    assert [y.tolist() for _, y in db] == [y.tolist() for _, y in db] == [[0, 1, 2, 3], [4, 5, 6, 7]]
