@@ -443,7 +443,9 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
       for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh) {
-          const uint32_t tag = 255u - 3u * (uint32_t)(dt * 3 + dh);
+          // tag = 27 - tap of (dt, dh, dw = 0): small enough for an inline constant, so the high-half key is ONE v_and_or_b32
+          // (with 255 - tap the mask and the tag were two literals: v_and + v_or)
+          const uint32_t tag = 27u - 3u * (uint32_t)(dt * 3 + dh);
           const uint4 v = *(const uint4*)(base + ((dt * p.Hh + dh) * p.Wh + c) * 16);
           const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -476,9 +478,12 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
         for (int e = 0; e < 8; ++e)
           if ((best[e] >> 16) <= 0x8000u) best[e] &= ~255u;      // tag 0 -> idx 255 ("no cell")
       }
+      uint32_t ix[8];                                                // tag 27 - tap -> tap; tag 0 -> 255 ("no cell")
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const uint32_t tg = best[e] & 255u; ix[e] = tg ? 27u - tg : 255u; }
       uint2 id;
-      id.x = (255u - (best[0] & 255u)) | ((255u - (best[1] & 255u)) << 8) | ((255u - (best[2] & 255u)) << 16) | ((255u - (best[3] & 255u)) << 24);
-      id.y = (255u - (best[4] & 255u)) | ((255u - (best[5] & 255u)) << 8) | ((255u - (best[6] & 255u)) << 16) | ((255u - (best[7] & 255u)) << 24);
+      id.x = ix[0] | (ix[1] << 8) | (ix[2] << 16) | (ix[3] << 24);
+      id.y = ix[4] | (ix[5] << 8) | (ix[6] << 16) | (ix[7] << 24);
       const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
       *(uint4*)(k.out + (opos * k.out_ld + k.out_coff + c0) * 2) = o;
       *(uint2*)(k.idx + opos * k.C + c0) = id;
