@@ -7,7 +7,8 @@ page faults of fresh 77 MB arrays cost more than the read), and the consumer tur
 asynchronous copy on its own stream -- the uint8 bytes (77 MB for 8 x 64 x 224 x 224 x 3) are what crosses PCIe, the
 ``u8/128 - 1`` conversion happens in the apply kernel.  At 7 ms per step the attack consumes 8 clips x 144 steps/s = 11 GB/s per
 GPU, more than one PCIe Gen5 x16 link or any disk delivers: with real data the loop is input-bound, and the loader's job is to
-stay out of the way (measured on the build container's page cache: 1.3 GB/s parsed per reader thread)."""
+stay out of the way (measured on the MI355X box, tools/input_pipeline_rate.py: 19 GB/s from the page cache, and 6.91 ms per step with
+a new batch every step against 6.90 ms with the batch resident)."""
 import queue
 import threading
 
