@@ -18,6 +18,10 @@ import torch
 from . import tfrecord_io as tio
 
 
+class _ConsumerGone(Exception):
+    pass
+
+
 class DeviceBatches:
     """iterate ``(clips uint8 [B,T,224,224,3] on the device, labels int64 [B] on the host as numpy)`` over TFRecord files.
 
@@ -45,16 +49,28 @@ class DeviceBatches:
         stop = threading.Event()
 
         def reader():
+            """fills free buffers in order; ends quietly when the consumer stops early (a None arrives on the free queue)"""
+            def bufs():
+                while True:
+                    k = free.get()
+                    if k is None:
+                        raise _ConsumerGone
+                    yield self.host_np[k], self.labels[k]
+
             try:
-                bufs = ((self.host_np[k], self.labels[k]) for k in iter(free.get, None))
-                for k_clips, k_labels in tio.batches(*self.args, buffers=bufs):
-                    k = next(i for i, h in enumerate(self.host_np) if h is k_clips)
-                    full.put(k)
+                for k_clips, _ in tio.batches(*self.args, buffers=bufs()):
                     if stop.is_set():
                         return
+                    full.put(next(i for i, h in enumerate(self.host_np) if h is k_clips))
                 full.put(None)
-            except BaseException as e:          # noqa: BLE001 -- hand the error to the consumer instead of dying silently
-                full.put(e)
+            except RuntimeError as e:                       # PEP 479 wraps the generator's _ConsumerGone
+                if not isinstance(e.__cause__, _ConsumerGone) and not stop.is_set():
+                    full.put(e)
+            except _ConsumerGone:
+                pass
+            except BaseException as e:                      # noqa: BLE001 -- hand the error to the consumer instead of dying silently
+                if not stop.is_set():
+                    full.put(e)
 
         th = threading.Thread(target=reader, daemon=True)
         th.start()
@@ -102,3 +118,8 @@ class DeviceBatches:
         finally:
             stop.set()
             free.put(None)
+            try:                                               # a reader blocked on a full queue: make room so that it can see `stop`
+                while True:
+                    full.get_nowait()
+            except queue.Empty:
+                pass

@@ -102,3 +102,27 @@ def test_prefetcher_yields_the_same_batches_in_order(tmp_path):
     # two passes over the same object (epochs) restart the reader
     db = prefetch.DeviceBatches([path], 4, T, device="cpu")
     assert [y.tolist() for _, y in db] == [y.tolist() for _, y in db] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+
+
+def test_prefetcher_consumer_may_stop_early(tmp_path):
+    """the attack loop leaves the epoch when MAX_NUM_STEP is reached: the reader thread must end instead of blocking, and the next
+    pass over the same object starts from the first record again"""
+    import threading
+    import time
+    import numpy as np
+    from flickering_adversarial_video_amd import prefetch, tfrecord_io as tio
+    T = 2
+    rng = np.random.default_rng(4)
+    path = str(tmp_path / "b.tfrecords")
+    tio.write_records(path, [tio.make_example(rng.integers(0, 256, (T, 224, 224, 3), dtype=np.uint8), i) for i in range(12)])
+    db = prefetch.DeviceBatches([path], 2, T, device="cpu", depth=2)
+    before = threading.active_count()
+    for n, (x, y) in enumerate(db):
+        if n == 1:
+            break
+    assert y.tolist() == [2, 3]
+    deadline = time.time() + 5
+    while threading.active_count() > before and time.time() < deadline:
+        time.sleep(0.05)
+    assert threading.active_count() == before, "reader thread still alive after the consumer stopped"
+    assert [y.tolist() for _, y in db][0] == [0, 1]
