@@ -1007,9 +1007,14 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
                    int replace_op = -1, const std::function<int(hipStream_t)>* replacement = nullptr) {
   if (n->profile && ev.size() != ops.size()) {
     for (size_t i = ev.size(); i < ops.size(); ++i) {
+      // timing-only events (hipEventDisableSystemFence, the flag's documented use): a default event's system-scope fence writes the
+      // caches back / invalidates them for the host at every record and that cost lands inside the measured interval of an
+      // 8-70 us kernel (measured: 73.5 -> 71.7 us per conv launch; rocprofv3's kernel time is 69.8).  hipEventReleaseToDevice
+      // alone changes nothing.  FLK_PROFILE_EVENT_FLAGS overrides (0 = default events).
+      const unsigned pf = getenv("FLK_PROFILE_EVENT_FLAGS") ? (unsigned)strtoul(getenv("FLK_PROFILE_EVENT_FLAGS"), nullptr, 0) : hipEventDisableSystemFence;
       hipEvent_t a, b;
-      FLK_CHECK_HIP(hipEventCreate(&a));
-      FLK_CHECK_HIP(hipEventCreate(&b));
+      FLK_CHECK_HIP(hipEventCreateWithFlags(&a, pf));
+      FLK_CHECK_HIP(hipEventCreateWithFlags(&b, pf));
       ev.push_back({a, b});
     }
   }
