@@ -203,6 +203,13 @@ struct flk_net {
   char* bp(const Act& a) const { return (char*)a.p + (size_t)bs_b0 * a.T * a.H * a.W * a.ld * esz(); }
   const char* bp(const void* p, const Act& geom, int ld) const { return p ? (const char*)p + (size_t)bs_b0 * geom.T * geom.H * geom.W * ld * esz() : nullptr; }
 
+  // compulsory HBM bytes of a convolution launch: input once, output once, plus the epilogue's add / mask operands (reported beside
+  // the flops by the per-layer profile: the 1x1x1 layers are bound by these, the 3x3x3 / 7x7x7 ones by MFMA)
+  double conv_bytes(const flk_conv_args& a) const {
+    const double in = (double)a.B * a.Ti * a.Hi * a.Wi * a.cin, out = (double)a.B * a.To * a.Ho * a.Wo * a.cout;
+    return (in + out * (1 + (a.add != nullptr) + (a.mask != nullptr))) * esz();
+  }
+
   // ---- op emitters -------------------------------------------------------------------------------
   // forward Unit3D: out[:, coff:coff+cout] = relu(conv(in[:, in_coff:in_coff+cin]) * scale + bias), stride 1 SAME
   void emit_conv_fwd(ConvLayer* L, const Act& in, int in_coff, const Act& out, int out_coff, const void* const* in_ptr = nullptr) {
@@ -219,7 +226,7 @@ struct flk_net {
     flk_conv_weights* wf = L->wf;
     const int dt = dtype;
     attach_splitk(a, wf);
-    fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt, in_ptr](hipStream_t s) mutable {
+    fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, conv_bytes(a), [a, wf, dt, in_ptr](hipStream_t s) mutable {
                        if (in_ptr) a.in = *in_ptr;
                        return flk_conv3d(&a, wf, dt, s);
                      }});
@@ -241,7 +248,7 @@ struct flk_net {
     flk_conv_weights* wb = L->wb;
     const int dt = dtype;
     attach_splitk(a, wb);
-    bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt, out_ptr](hipStream_t s) mutable {
+    bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, conv_bytes(a), [a, wb, dt, out_ptr](hipStream_t s) mutable {
                        if (out_ptr) a.out = *out_ptr;
                        return flk_conv3d(&a, wb, dt, s);
                      }});
@@ -376,7 +383,7 @@ int flk_net::build_i3d() {
       flk_conv_weights* wf = stem->wf;
       const int dt = dtype;
       const size_t in_off = (size_t)bs_b0 * T1 * H1 * W1 * 32 * esz();
-      fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * stem_macs, 0.0, [this, a, wf, dt, in_off](hipStream_t s) mutable {
+      fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * stem_macs, conv_bytes(a), [this, a, wf, dt, in_off](hipStream_t s) mutable {
                          a.in = (const char*)x_in + in_off;
                          a.pos_bias = cur_pos_bias;            // flk_net_forward_flicker: the perturbation enters here, in fp32
                          return flk_conv3d(&a, wf, dt, s);
@@ -417,7 +424,7 @@ int flk_net::build_i3d() {
     const int dt = dtype;
     const double macs = stem_macs * nhalf;
     bwd_emit.push_back([this, g, wb, dt, macs]() {
-      bwd.push_back(Op{"Conv3d_1a_7x7/dgrad", K_CONV, 2.0 * macs, 0.0, [this, g, wb, dt](hipStream_t s) mutable {
+      bwd.push_back(Op{"Conv3d_1a_7x7/dgrad", K_CONV, 2.0 * macs, conv_bytes(g), [this, g, wb, dt](hipStream_t s) mutable {
                          g.out = gx_in;
                          return flk_conv3d(&g, wb, dt, s);
                        }});
@@ -524,7 +531,7 @@ int flk_net::build_i3d() {
       const double macs = (double)B * cur.T * cur.H * cur.W * cur_c * (c0 + c1a + c2a);
       flk_conv_weights* wf = Lf->wf;
       const int dt = dtype;
-      fwd.push_back(Op{Lf->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
+      fwd.push_back(Op{Lf->name, K_CONV, 2.0 * macs, conv_bytes(a), [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
     }
     // The Branch_3 pool reads the block input only: it starts beside the fused 1x1x1 GEMM (98-392 workgroups, which leave CUs
     // idle) on side stream 2 and Branch_3's 1x1x1 follows it there.  The two 3x3x3 branches fork after the GEMM (disjoint
@@ -579,7 +586,7 @@ int flk_net::build_i3d() {
         const double macs = (double)B * Gin.T * Gin.H * Gin.W * Lf->cin * (c0 + c1a + c2a);
         flk_conv_weights* wb = Lf->wb;
         const int dt = dtype;
-        bwd.push_back(Op{Lf->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
+        bwd.push_back(Op{Lf->name + "/dgrad", K_CONV, 2.0 * macs, conv_bytes(a), [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
       }
     });
     cur = out; Gcur = Gout; cur_c = cout_total; cur_is_relu = true;
@@ -706,7 +713,7 @@ void flk_net::emit_gen_fwd(ConvLayer* L, const Act& in, const Act& out, bool rel
   flk_conv_weights* wf = L->wf;
   const int dt = dtype;
   attach_splitk(a, wf);
-  fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, 0.0, [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
+  fwd.push_back(Op{L->name, K_CONV, 2.0 * macs, conv_bytes(a), [a, wf, dt](hipStream_t s) { return flk_conv3d(&a, wf, dt, s); }});
 }
 
 void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const void* add, int add_ld, const Act* mask) {
@@ -724,7 +731,7 @@ void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const voi
     flk_conv_weights* wb = bc.w;
     const int dt = dtype;
     attach_splitk(a, wb);
-    bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, 0.0, [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
+    bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, conv_bytes(a), [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
   }
 }
 
@@ -774,7 +781,7 @@ int flk_net::build_videoresnet() {
     const double macs = (double)B * T * H2 * W2 * skt * 49.0 * 3 * sc_out;
     flk_conv_weights* wf = stem->wf;
     const int dt = dtype;
-    fwd.push_back(Op{"stem.0", K_CONV, 2.0 * macs, 0.0, [this, a, wf, dt](hipStream_t s) mutable { a.in = x_in; return flk_conv3d(&a, wf, dt, s); }});
+    fwd.push_back(Op{"stem.0", K_CONV, 2.0 * macs, conv_bytes(a), [this, a, wf, dt](hipStream_t s) mutable { a.in = x_in; return flk_conv3d(&a, wf, dt, s); }});
     const ConvLayer::BwdClass bc = stem->bcls[0];
     flk_conv_args g{};
     g.in = G_st.p; g.in_ld = G_st.ld; g.cin = stem->cout; g.B = B; g.Ti = T; g.Hi = H2; g.Wi = W2;
@@ -783,7 +790,7 @@ int flk_net::build_videoresnet() {
     g.out_ld = 16; g.cout = 16;
     flk_conv_weights* wb = bc.w;
     bwd_emit.push_back([this, g, wb, dt, macs]() {
-      bwd.push_back(Op{"stem.0/dgrad", K_CONV, 2.0 * macs, 0.0, [this, g, wb, dt](hipStream_t s) mutable { g.out = gx_in; return flk_conv3d(&g, wb, dt, s); }});
+      bwd.push_back(Op{"stem.0/dgrad", K_CONV, 2.0 * macs, conv_bytes(g), [this, g, wb, dt](hipStream_t s) mutable { g.out = gx_in; return flk_conv3d(&g, wb, dt, s); }});
     });
   }
   Act cur = a_st, Gcur = G_st;
