@@ -1117,7 +1117,9 @@ extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const fl
   hipStream_t s = (hipStream_t)stream;
   // the clip mask depends on the clip and on delta only: it runs on a side stream beside the whole backward pass and is joined
   // right in front of the GEMM that consumes it (serial mode: inline)
-  const bool beside = n->multi_stream && n->side[0];
+  // (per-layer profiling is serial: the mask pre-pass then runs inline, inside the stem slot it belongs to, instead of stretching the
+  // first backward operators it would otherwise run beside)
+  const bool beside = n->multi_stream && n->side[0] && !n->profile;
   if (beside) {
     FLK_CHECK_HIP(hipEventRecord(n->ev_mask_fork, s));
     FLK_CHECK_HIP(hipStreamWaitEvent(n->side[0], n->ev_mask_fork, 0));
