@@ -4,10 +4,10 @@
 //             (i3d.py:174,189,212,252,398); the winning window index is kept as one byte.
 //   backward: default = scatter form (maxpool_scatter_bwd): a workgroup owns a tile of INPUT cells in LDS and every
 //             window that reaches the tile adds its gradient to the cell its saved argmax names.  bf16 mode sums in
-//             32-bit fixed point with integer LDS atomics (order-independent, bitwise reproducible); fp32 mode uses
-//             float LDS atomics (sum order not fixed: last-ulp differences between runs).
-//             FLK_POOL_GATHER=1 selects the gather forms (every input cell scans the windows containing it; fixed
-//             summation order in both precisions).  Optional relu mask of the producing layer (mask > 0) fused in.
+//             32-bit fixed point with integer LDS atomics (order-independent, bitwise reproducible).  fp32 (the parity mode)
+//             takes the gather forms (every input cell scans the windows containing it; fixed summation order), as does
+//             FLK_POOL_GATHER=1 in bf16; the scatter form in fp32 (float LDS atomics, last-ulp run-to-run differences) only
+//             with FLK_POOL_SCATTER_F32=1.  Optional relu mask of the producing layer (mask > 0) fused in.
 #include <stdlib.h>
 #include "flk_internal.h"
 
@@ -871,7 +871,11 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
     FLK_OWNER(1, 3, 3, 1, 2, 2); FLK_OWNER(3, 3, 3, 2, 2, 2); FLK_OWNER(2, 2, 2, 2, 2, 2);
 #undef FLK_OWNER
   }
-  if (!use_gather)
+  // fp32 is the parity mode: it takes the gather form (fixed summation order) so that two fp32 runs are bitwise equal; the scatter
+  // form's float LDS atomics are order-dependent in the last ulp, which Adam turns into 1e-4 relative on tiny components
+  // (FLK_POOL_SCATTER_F32=1 restores the scatter form for fp32)
+  static const bool scatter_f32 = getenv("FLK_POOL_SCATTER_F32") != nullptr;
+  if (!use_gather && (dtype == FLK_BF16 || scatter_f32))
     return dtype == FLK_BF16 ? launch_scatter_bwd<bf16_t>(kp, a, (hipStream_t)stream) : launch_scatter_bwd<float>(kp, a, (hipStream_t)stream);
   if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, true, (hipStream_t)stream) : launch_tiled<float>(kp, a, true, (hipStream_t)stream);
   const int epl = dtype == FLK_BF16 ? 8 : 4;
