@@ -325,6 +325,9 @@ def main():
         eng.net.profile(True)
         per_kind = {}
         fused = {"ms": 0.0, "flops": 0.0, "launches": 0}     # the stem's data-gradient slot: stem_delta_grad_kernel when the engine fuses it
+        # conv_igemm launches split by the roofline that bounds each of them (time at the MFMA peak for its flops against time at
+        # the HBM peak for its compulsory bytes): the 3x3x3 / 7x7x7 layers are MFMA-bound, the 1x1x1 GEMMs HBM-bound
+        by_bound = {"mfma": {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0}, "hbm": {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0}}
         reps = 3
         for _ in range(reps):
             eng.step(x, labels, **hp)
@@ -333,6 +336,9 @@ def main():
                 k["ms"] += r["ms"]; k["flops"] += r["flops"]; k["bytes"] += r["bytes"]; k["launches"] += 1
                 if getattr(eng, "fused_delta_grad", False) and r["name"] == "Conv3d_1a_7x7/dgrad":
                     fused["ms"] += r["ms"]; fused["flops"] += r["flops"]; fused["launches"] += 1
+                elif r["kind"] == "conv":
+                    bb = by_bound["mfma" if r["flops"] / (PEAK_TFLOPS[a.dtype] * 1e12) >= r["bytes"] / 8e12 else "hbm"]
+                    bb["ms"] += r["ms"]; bb["flops"] += r["flops"]; bb["bytes"] += r["bytes"]; bb["launches"] += 1
         eng.net.profile(False)
         cv = per_kind["conv"]
         ig = {k: cv[k] - fused[k] for k in ("ms", "flops", "launches")}        # conv_igemm_kernel launches only
@@ -353,6 +359,15 @@ def main():
                            "launches_per_step": ig["launches"] // reps, "avg_launch_ms": ig["ms"] / ig["launches"],
                            "conv_ms_per_step": cv["ms"] / reps, "algorithmic_gflop_per_step": cv["flops"] / reps / 1e9,
                            "all_conv_achieved": cv["flops"] / (cv["ms"] * 1e-3) / 1e12}
+        m, h = by_bound["mfma"], by_bound["hbm"]
+        out["roofline"]["conv_igemm_by_bound"] = {
+            "mfma_bound": {"launches_per_step": m["launches"] // reps, "ms_per_step": m["ms"] / reps,
+                           "achieved_TFLOPs": m["flops"] / (m["ms"] * 1e-3) / 1e12 if m["ms"] else None,
+                           "frac": m["flops"] / (m["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype] if m["ms"] else None},
+            "hbm_bound": {"launches_per_step": h["launches"] // reps, "ms_per_step": h["ms"] / reps,
+                          "achieved_GBps": h["bytes"] / (h["ms"] * 1e-3) / 1e9 if h["ms"] else None, "peak_GBps": 8000.0,
+                          "frac": h["bytes"] / (h["ms"] * 1e-3) / 8e12 if h["ms"] else None,
+                          "note": "compulsory bytes (input + output + epilogue operands once) of the 1x1x1 GEMMs"}}
         if fused["launches"]:
             out["roofline"]["stem_delta_grad_kernel"] = {"ms": fused["ms"] / reps, "achieved": fused["flops"] / (fused["ms"] * 1e-3) / 1e12,
                                                          "unit": "TFLOP/s (algorithmic flops of the stem data-gradient it replaces)",
