@@ -231,6 +231,14 @@ def bench_videoresnet(a, world, rank, local_rank):
     print(json.dumps(out))
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (parallel.launch_ranks: one CHILD process per GPU
+    through torch.distributed.run, exactly the driver's multi-GPU form; this parent has not touched the GPU -- nothing above
+    imports the extension or calls torch.cuda), relay their output (rank 0 prints the JSON line) and exit with their code."""
+    from flickering_adversarial_video_amd.parallel import launch_ranks
+    sys.exit(launch_ranks(n, __file__, sys.argv[1:]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,11 +257,17 @@ def main():
                     "(measured: no gain over the built-in heuristics, which is why it is off by default)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return _self_launch(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        print(f"[bench] warning: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        # never report n_gpus != what was asked for: a SCALE run would record a mislabelled line
+        print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to run", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("FLK_BENCH_ECHO_RANKS"):
+        print(f"[bench] rank {rank} of {world}", file=sys.stderr, flush=True)
     # FLK_DIST_BACKEND=gloo rehearses the multi-rank plumbing on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("FLK_DIST_BACKEND", "nccl")
     if backend != "nccl":

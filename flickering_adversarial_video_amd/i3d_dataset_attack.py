@@ -25,12 +25,13 @@ import glob
 import os
 import pickle
 import re
+import sys
 import time
 
 import numpy as np
 import torch
 
-from . import config as cfgmod, i3d_spec, prefetch, tb_events, tf_checkpoint, tfrecord_io as tio
+from . import config as cfgmod, i3d_spec, parallel, prefetch, tb_events, tf_checkpoint, tfrecord_io as tio
 from .i3d_engine import FlickerI3D
 
 ADAM_B1, ADAM_B2 = 0.9, 0.999        # tf.train.AdamOptimizer defaults (i3d_adversarial_main_single_class_gen.py:83)
@@ -87,9 +88,14 @@ def main(default_section, argv=None):
                     "(the reference's Saver() also saves the 12.7 M frozen I3D weights every time)")
     ap.add_argument("--frames", type=int, default=None)
     ap.add_argument("--dtype", default=None)
+    ap.add_argument("--gpus", type=int, default=None, help="data-parallel ranks (one process per GPU, RCCL all-reduce of the delta-gradient); "
+                    "without a launcher in the environment the script starts them itself")
     a = ap.parse_args(argv)
     universal = a.section == "UNIVERSAL_ATTACK"
-    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if a.gpus and a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # before anything touches the GPU
+        import __main__
+        sys.exit(parallel.launch_ranks(a.gpus, __main__.__file__, sys.argv[1:] if argv is None else argv))
+    world, rank, local_rank = parallel.ranks_from_env(a.gpus)
     backend = os.environ.get("FLK_DIST_BACKEND", "nccl")          # gloo: rehearse the multi-rank plumbing on fewer GPUs than ranks
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)

@@ -17,6 +17,39 @@ import torch
 import torch.distributed as dist
 
 
+def launch_ranks(n, script, argv):
+    """Start `script argv` as n ranks of ONE node (one process per GPU, `python -m torch.distributed.run`, rendezvous on 127.0.0.1)
+    from a parent that has NOT touched the GPU, wait, and return the launcher's exit code (non-zero if any rank failed).  This is what
+    `--gpus N` means in bench.py and the universal / class-generalisation scripts when no launcher has set WORLD_SIZE -- the
+    reference's multi-GPU entry is one command too (nn.DataParallel over DEVICES_IDS, r2plus1d_main_universal_attack.py:30-33,
+    model.py:576-578).  The ranks are CHILD processes: a process that has initialised HIP must never be replaced by exec."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(script)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def ranks_from_env(gpus):
+    """(world, rank, local_rank) from the launcher's environment; refuses (SystemExit 2) a world size that differs from an explicit
+    --gpus request instead of silently running a different job."""
+    import os
+    import sys
+    world, rk, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    if gpus is not None and gpus != world:
+        print(f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to run", file=sys.stderr)
+        raise SystemExit(2)
+    return world, rk, local
+
+
 def world_size(group=None):
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 

@@ -68,9 +68,12 @@ def main():
     ap.add_argument("--batch-size", type=int, default=BATCH_SIZE)
     ap.add_argument("--lr", type=float, default=LR)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--gpus", type=int, default=None, help="data-parallel ranks, one process per GPU (the reference's DEVICES_IDS, "
+                    "r2plus1d_main_universal_attack.py:30-33); without a launcher in the environment the script starts them itself")
     a = ap.parse_args()
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus and a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # before anything touches the GPU
+        sys.exit(parallel.launch_ranks(a.gpus, __file__, sys.argv[1:]))
+    world, rank, local_rank = parallel.ranks_from_env(a.gpus)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

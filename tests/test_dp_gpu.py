@@ -211,18 +211,19 @@ def test_dense_delta_two_ranks_equal_one_process():
 
 
 def test_bench_two_ranks_rehearsal():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on the one test GPU
-    with FLK_DIST_BACKEND=gloo: the roofline leg runs on EVERY rank (its steps end in the all-reduce), rank 0 prints one JSON line."""
+    """plain `python bench.py --gpus 2` (bench.py launches its own ranks through torch.distributed.run, one process per rank), rehearsed
+    on the one test GPU with FLK_DIST_BACKEND=gloo: the roofline leg runs on EVERY rank (its steps end in the all-reduce), rank 0 prints one JSON line."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, FLK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
+    # the PLAIN form: no launcher, no WORLD_SIZE in the environment -- bench.py starts its own ranks (bench.py: _self_launch)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "1",
            "--frames", "16", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
