@@ -81,9 +81,19 @@ class Perturbation:
 
     __call__ = forward
 
+    @staticmethod
+    def convert_adversarial_video_zero_one(adv_vid):
+        """model.py:107-112: the normalised clip back to pixel range, as a NUMPY array ``[B,T,H,W,3]`` in [0,1]:
+        ``(x^T + mean/std) * std`` (float64, like the reference's numpy arithmetic).  ``adv_vid`` is the reference's NCDHW
+        tensor [B,3,T,H,W] or the engine's channels-last [B,T,H,W,3]."""
+        x = adv_vid.detach().cpu().numpy()
+        if x.ndim == 5 and x.shape[1] == 3 and x.shape[-1] != 3:
+            x = x.transpose([0, 2, 3, 4, 1])
+        return (x + np.array(DEFAULT_MEAN) / np.array(DEFAULT_STD)) * np.array(DEFAULT_STD)
+
     def apply_perturbation(self, x):
-        """model.py:103-105"""
-        return self.forward([x, True])
+        """model.py:103-105: the perturbed clip de-normalised to [0,1], numpy [B,T,H,W,3] (what the scripts save / plot)"""
+        return self.convert_adversarial_video_zero_one(self.forward([x, True]))
 
     def clamp_perturbation(self):
         return self.perturbation.clamp(-self.dynamic_max_norm, self.dynamic_max_norm)
@@ -152,6 +162,27 @@ class Adversarial_metrics:
 
     def __init__(self, targeted=False, target_class=None):
         self.targeted, self.target_class = targeted, target_class
+
+    def accuracy(self, output, ground_truth, topk=(1,), clean_pred=None):
+        """model.py:262-291: fooling percentages as a list of 1-element tensors.  Targeted: ONE entry, 100 * #(top-maxk predictions
+        equal to the target class) / batch.  Untargeted: per k, 100 * (1 - #(adv top-k hit AND clean top-k hit, at the SAME rank
+        position) / #(clean top-k hits)) -- the rank-wise product is the reference's (model.py:287), reproduced as is."""
+        with torch.no_grad():
+            res = []
+            batch_size = ground_truth.size(0)
+            maxk = max(topk)
+            pred = output.topk(maxk, 1, True, True)[1].t()
+            if self.targeted:
+                correct = pred.eq(self.target_class).reshape(-1).float().sum(0, keepdim=True)
+                res.append(correct[0] * (100.0 / batch_size))
+                return res
+            correct = pred.eq(ground_truth.view(1, -1).expand_as(pred))
+            pred_no_adv = clean_pred.topk(maxk, 1, True, True)[1].t()
+            correct_no_adv = pred_no_adv.eq(ground_truth.view(1, -1).expand_as(pred_no_adv))
+            for k in topk:
+                correct_k = (correct[:k] * correct_no_adv[:k]).reshape(-1).float().sum(0, keepdim=True)
+                res.append((1 - correct_k * (1.0 / correct_no_adv[:k].reshape(-1).float().sum())) * 100.0)
+            return res
 
     def accuracy_for_eval(self, output, ground_truth, topk=(1,), clean_pred=None):
         adv, clean = output.argmax(1), clean_pred.argmax(1)

@@ -88,6 +88,7 @@ def main():
         G[f"pert_{tag}_metric"] = np.array([th.item(), ro.item()], np.float32)
         c, raw = P.get_perturbation()
         G[f"pert_{tag}_clamped"] = c.detach().numpy()
+        G[f"pert_{tag}_zero_one"] = np.asarray(P.apply_perturbation(xt))            # model.py:103-112: numpy [B,T,H,W,3] in [0,1]
     G["pert_min_value"] = np.float64(m.Perturbation((3, 2, 1, 1), device="cpu").min_value)
     G["pert_max_value"] = np.float64(m.Perturbation((3, 2, 1, 1), device="cpu").max_value)
 
@@ -139,6 +140,16 @@ def main():
     d = rng.uniform(-0.2, 0.2, (3, 16, 1, 1)).astype(np.float32)
     th, ro = M.adversarial_metric(torch.from_numpy(d))
     G["met_delta"], G["met_thick_rough"] = d, np.array([th.item(), ro.item()], np.float32)
+    # Adversarial_metrics.accuracy (model.py:262-291): top-1 fooling percentage, untargeted (needs clean_pred) and targeted.  (topk with
+    # maxk > 1 raises in the reference under torch >= 1.5 -- .view(-1) of a transposed product, model.py:287 -- so only the default
+    # topk=(1,) has reference outputs to pin.)
+    acc = M.accuracy(torch.from_numpy(adv_lg), torch.from_numpy(gt.astype(np.int64)), clean_pred=torch.from_numpy(clean))
+    G["met_accuracy_top1"] = np.array([float(a) for a in acc], np.float64)
+    tc = int((gt[2] + 1) % 400)
+    Mt = m.Adversarial_metrics(targeted=True, target_class=tc)
+    acc_t = Mt.accuracy(torch.from_numpy(adv_lg), torch.from_numpy(gt.astype(np.int64)))
+    G["met_accuracy_targeted_class"] = np.int64(tc)
+    G["met_accuracy_targeted"] = np.array([float(a) for a in acc_t], np.float64)
 
     # ---- 4. 20-step mini attack on a tiny seeded conv3d net, loop ordering of model.py:1056-1101 ----
     torch.manual_seed(7)

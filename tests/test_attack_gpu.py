@@ -278,7 +278,11 @@ def test_torch_surface_classes_vs_golden(golden):
         out = pm([x, True])
         assert out.shape == x.shape
         torch.testing.assert_close(out.cpu(), torch.from_numpy(g[f"pert_{tag}_xadv"]), rtol=1e-6, atol=1e-6)
-        torch.testing.assert_close(pm.apply_perturbation(x).cpu(), torch.from_numpy(g[f"pert_{tag}_xadv"]), rtol=1e-6, atol=1e-6)
+        # apply_perturbation / convert_adversarial_video_zero_one (model.py:103-112): numpy [B,T,H,W,3] de-normalised to [0,1]
+        z = pm.apply_perturbation(x)
+        assert isinstance(z, np.ndarray) and z.shape == (2, 16, 8, 8, 3) and z.dtype == np.float64
+        np.testing.assert_allclose(z, g[f"pert_{tag}_zero_one"], rtol=0, atol=5e-7)
+        np.testing.assert_allclose(pm.convert_adversarial_video_zero_one(out.permute(0, 2, 3, 4, 1)), g[f"pert_{tag}_zero_one"], rtol=0, atol=5e-7)
         torch.testing.assert_close(pm.forward([x, False]).cpu(), torch.from_numpy(g[f"pert_{tag}_clean"]), rtol=0, atol=0)
         cl = pm([x.permute(0, 2, 3, 4, 1).contiguous(), True])     # channels-last in, channels-last out
         torch.testing.assert_close(cl.permute(0, 4, 1, 2, 3).cpu(), torch.from_numpy(g[f"pert_{tag}_xadv"]), rtol=1e-6, atol=1e-6)
