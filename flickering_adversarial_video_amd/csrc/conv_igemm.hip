@@ -710,14 +710,8 @@ flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st,
 
 template <typename T, int NF, int WN, int MODE>
 static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
-  static bool attr_set[16] = {};      // per device: one process may drive several GPUs
-  int dev = 0;
-  FLK_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
-    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NF, WN, MODE>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    if (dev >= 0 && dev < 16) attr_set[dev] = true;
-  }
+  static bool attr_set[FLK_MAX_DEVICES] = {};      // per device: one process may drive several GPUs
+  if (int rc = flk_raise_lds_limit((const void*)conv_igemm_kernel<T, NF, WN, MODE>, 96 * 1024, attr_set)) return rc;
   hipLaunchKernelGGL((conv_igemm_kernel<T, NF, WN, MODE>), grid, dim3(256), lds, s, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;

@@ -32,6 +32,20 @@ void flk_set_error(const char* fmt, ...);
 
 static inline int flk_esize(int dtype) { return dtype == FLK_BF16 ? 2 : 4; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel and one process may drive several GPUs:
+// `done` is the call site's `static bool done[FLK_MAX_DEVICES]`, indexed by the current device (set once per device, always
+// set for a device id outside the table).
+constexpr int FLK_MAX_DEVICES = 16;
+static inline int flk_raise_lds_limit(const void* kernel, int bytes, bool* done) {
+  int dev = 0;
+  FLK_CHECK_HIP(hipGetDevice(&dev));
+  const bool tracked = dev >= 0 && dev < FLK_MAX_DEVICES;
+  if (tracked && done[dev]) return FLK_OK;
+  FLK_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  if (tracked) done[dev] = true;
+  return FLK_OK;
+}
+
 // ---- packed convolution weights ---------------------------------------------------------------
 // Layout on device: [nslab][ntaps][cout_frags][64 lanes][EPL elems] where EPL = 16 B / elem size,
 // a slab = 4*EPL input channels (one 64-byte run per position) and fragment F = ntile*nf + f of

@@ -515,11 +515,8 @@ static int launch_wrun_fwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t
   const size_t lds = 4 * (size_t)tp.plane_b + 64;
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
-  static bool attr_set = false;
-  if (!attr_set) {
-    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_wrun_fwd_bf16<WT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
-  }
+  static bool attr_set[FLK_MAX_DEVICES] = {};
+  if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_wrun_fwd_bf16<WT>, 96 * 1024, attr_set)) return rc;
   hipLaunchKernelGGL((maxpool_s1_wrun_fwd_bf16<WT>), grid, dim3(256), lds, s, tp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
@@ -780,21 +777,15 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
   const size_t lds = 4 * (size_t)tp.plane_b + 64 + (bwd ? (size_t)4 * tp.P * EPL + 16 : 0);
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 4 * EPL - 1) / (4 * EPL);
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
-  static bool attr_set = false;
-  if (!attr_set) {
-    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_fwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_bwd<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    attr_set = true;
-  }
+  static bool attr_fwd[FLK_MAX_DEVICES] = {}, attr_bwd[FLK_MAX_DEVICES] = {};
+  if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_fwd<T>, 96 * 1024, attr_fwd)) return rc;
+  if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_bwd<T>, 96 * 1024, attr_bwd)) return rc;
   if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
   else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3 && a->pt == 1 && a->ph == 1 && a->pw == 1 && !getenv("FLK_POOL_NO_WRUN")) {
     return a->Wo % 7 == 0 ? launch_wrun_fwd<7>(kp, a, s) : launch_wrun_fwd<8>(kp, a, s);
   } else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
-    static bool attr2 = false;
-    if (!attr2) {
-      FLK_CHECK_HIP(hipFuncSetAttribute((const void*)maxpool_s1_tiled_fwd_bf16<3, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-      attr2 = true;
-    }
+    static bool attr2[FLK_MAX_DEVICES] = {};
+    if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_fwd_bf16<3, 3, 3>, 96 * 1024, attr2)) return rc;
     hipLaunchKernelGGL((maxpool_s1_tiled_fwd_bf16<3, 3, 3>), grid, dim3(256), lds, s, tp);
   } else hipLaunchKernelGGL(maxpool_s1_tiled_fwd<T>, grid, dim3(256), lds, s, tp);
   FLK_CHECK_HIP(hipGetLastError());

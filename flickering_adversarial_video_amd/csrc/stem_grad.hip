@@ -444,11 +444,8 @@ extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g
   { static const char* e = getenv("FLK_SG_NCHUNK"); if (e && atoi(e) > 0) kp.nchunk = atoi(e) < 16 ? atoi(e) : 16; }
   kp.rows_per_chunk = (kp.Ho + kp.nchunk - 1) / kp.nchunk;
   kp.nchunk = (kp.Ho + kp.rows_per_chunk - 1) / kp.rows_per_chunk;       // no empty chunks
-  static bool attr_set = false;
-  if (!attr_set) {
-    FLK_CHECK_HIP(hipFuncSetAttribute((const void*)stem_delta_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SG_LDS));
-    attr_set = true;
-  }
+  static bool attr_set[FLK_MAX_DEVICES] = {};
+  if ((rc = flk_raise_lds_limit((const void*)stem_delta_grad_kernel, SG_LDS, attr_set))) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (!mask_done && (rc = flk_stem_delta_grad_mask(a, scratch, stream))) return rc;
   hipLaunchKernelGGL(stem_delta_grad_kernel, dim3((unsigned)(a->B * kp.To * kp.nchunk)), dim3(SG_THREADS), SG_LDS, s, kp);

@@ -143,21 +143,28 @@ def main(default_section, argv=None):
     if world > 1:
         torch.distributed.barrier()
     step = 0
-    last = latest_checkpoint(out_dir, ck_pattern)
+    # WHAT to resume from is decided on rank 0 and broadcast: every rank restores the same state (or none does), and no rank can
+    # glob a bundle that rank 0 is about to write
+    last = latest_checkpoint(out_dir, ck_pattern) if rank == 0 else None
+    old = sorted(glob.glob(os.path.join(out_dir, "model_step_*.npz"))) if rank == 0 and not last else []      # round-1 format, still accepted
+    if world > 1:
+        decided = [(last, old)]
+        torch.distributed.broadcast_object_list(decided, src=0)
+        last, old = decided[0]
     if last:
         step = last[0]
         restore(eng, last[1])
         if rank == 0:
             print(f"resumed from {last[1]} at step {step}", flush=True)
-    else:
-        old = sorted(glob.glob(os.path.join(out_dir, "model_step_*.npz")))           # round-1 format, still accepted
-        if old:
-            ck = np.load(old[-1])
-            eng.reset_perturbation(ck["delta"])
-            eng.adam_m.copy_(torch.from_numpy(ck["m"]).reshape(eng.adam_m.shape)); eng.adam_v.copy_(torch.from_numpy(ck["v"]).reshape(eng.adam_v.shape))
-            eng.adam_t, step = int(ck["t"]), int(ck["step"])
-            if rank == 0:
-                print(f"resumed from {old[-1]} at step {step}", flush=True)
+    elif old:
+        ck = np.load(old[-1])
+        eng.reset_perturbation(ck["delta"])
+        eng.adam_m.copy_(torch.from_numpy(ck["m"]).reshape(eng.adam_m.shape)); eng.adam_v.copy_(torch.from_numpy(ck["v"]).reshape(eng.adam_v.shape))
+        eng.adam_t, step = int(ck["t"]), int(ck["step"])
+        if rank == 0:
+            print(f"resumed from {old[-1]} at step {step}", flush=True)
+    if world > 1:
+        torch.distributed.barrier()                    # every rank has finished reading before rank 0 writes its first checkpoint
     max_steps = a.max_steps if a.max_steps is not None else int(c.MAX_NUM_STEP)
     beta3 = c.BETA_2                                   # reference: beta_3 := BETA_2 (single_class_gen.py:98; universal.py:131)
     log_every = a.log_every if a.log_every is not None else (10 if universal else 1)

@@ -2,6 +2,7 @@
 memory and streams only; every computation happens in libflicker_hip.so."""
 import ctypes as C
 import json
+import os
 
 import numpy as np
 import torch
@@ -263,27 +264,22 @@ def pack_batch_sums(per_clip, prob_scale, out3):
     return out3
 
 
-_labels_ok = {}      # (data_ptr, _version, numel) -> number of classes the tensor was range-checked against
-
-
-def check_labels(labels, batch, num_classes):
-    """labels must be a CUDA int64 tensor of shape (batch,) with 0 <= label < num_classes: anything else would hand the loss
-    kernel a host pointer (GPU memory fault) or an out-of-range class index.  Device / dtype / shape are checked on every call
-    (free); the range check costs one device read-back and is cached per (storage, version), so a loop that reuses its label
-    tensor pays it once.  (The kernel itself clamps a bad index and poisons that clip's outputs with NaN.)"""
+def check_labels(labels, batch, num_classes, check_range=False):
+    """labels must be a contiguous CUDA int64 tensor of shape (batch,): anything else would hand the loss kernel a host pointer
+    (GPU memory fault) or a wrong stride.  These checks are free and run on every call.  The RANGE 0 <= label < num_classes is
+    validated where labels originate, on the host (i3d_dataset_attack.to_dev, the scripts' label look-ups); the kernel clamps a
+    bad index and poisons that clip's outputs with NaN (head.hip), so an out-of-range label cannot fault and cannot go unnoticed.
+    ``check_range=True`` (or FLK_CHECK_LABEL_RANGE=1) adds the device read-back of min / max -- two syncs, for debugging, never
+    cached: a tensor's address and version do not identify its contents (the caching allocator recycles both)."""
     if not torch.is_tensor(labels) or not labels.is_cuda or labels.dtype != torch.int64 or tuple(labels.shape) != (batch,):
         desc = f"{tuple(labels.shape)} {labels.dtype} {labels.device}" if torch.is_tensor(labels) else type(labels).__name__
         raise ValueError(f"labels must be a CUDA int64 tensor of shape ({batch},), got {desc}")
     if not labels.is_contiguous():
         raise ValueError("labels must be contiguous")
-    key = (labels.data_ptr(), labels._version, labels.numel())
-    if _labels_ok.get(key) != num_classes:
+    if check_range or os.environ.get("FLK_CHECK_LABEL_RANGE") == "1":
         lo, hi = int(labels.min()), int(labels.max())
         if lo < 0 or hi >= num_classes:
             raise ValueError(f"labels must lie in [0, {num_classes}), got [{lo}, {hi}]")
-        if len(_labels_ok) > 64:
-            _labels_ok.clear()
-        _labels_ok[key] = num_classes
     return labels
 
 

@@ -118,8 +118,15 @@ class DeviceBatches:
         finally:
             stop.set()
             free.put(None)
-            try:                                               # a reader blocked on a full queue: make room so that it can see `stop`
-                while True:
-                    full.get_nowait()
-            except queue.Empty:
-                pass
+            # The reader may still be filling a pinned buffer (it looks at `stop` only between batches) or be blocked on a full
+            # queue: keep making room until it has ENDED.  A DeviceBatches object is iterated again every epoch and the ring of
+            # pinned buffers is shared between iterations -- a second reader must never start while the first can still write.
+            while th.is_alive():
+                try:
+                    while True:
+                        full.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
+            if cuda:
+                copy_stream.synchronize()                      # copies still reading host buffers that the next iteration refills

@@ -212,7 +212,10 @@ def write_bundle(prefix, tensors, with_crc=True):
     items, offset = [], 0
     header = bytes([0x08, 0x01]) + _ld(3, bytes([0x08, 0x01]))          # num_shards = 1, version.producer = 1
     items.append((b"", header))
-    with open(prefix + ".data-00000-of-00001", "wb") as f:
+    # a reader discovers a bundle by its .index file (latest_checkpoint globs for it): the data shard is complete before the index
+    # appears, and both appear atomically (temporary name + rename), so a concurrent reader never sees a half-written bundle
+    data_path, index_path = prefix + ".data-00000-of-00001", prefix + ".index"
+    with open(data_path + ".tmp", "wb") as f:
         for name in sorted(tensors, key=lambda s: s.encode()):
             a = np.asarray(tensors[name])                            # (ascontiguousarray would turn a scalar into shape (1,))
             if a.dtype not in _DTYPE_CODES:
@@ -221,7 +224,9 @@ def write_bundle(prefix, tensors, with_crc=True):
             f.write(raw)
             items.append((name.encode(), _enc_entry(_DTYPE_CODES[a.dtype], a.shape, offset, len(raw), masked_crc(raw) if with_crc else None)))
             offset += len(raw)
-    write_table(prefix + ".index", items)
+    os.replace(data_path + ".tmp", data_path)
+    write_table(index_path + ".tmp", items)
+    os.replace(index_path + ".tmp", index_path)
 
 
 def load_i3d_checkpoint(ckpt_path, scope="RGB"):
