@@ -56,3 +56,47 @@ def build(force=False, verbose=True):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+
+
+def build_asan_driver(verbose=False):
+    """AddressSanitizer build of the library's HOST code (sanitizer stance: sanitizers run on the CPU build only --
+    this pool has no GPU ASan): every source compiled with ``--offload-host-only -fsanitize=address`` and linked, together with
+    tests/asan/hip_stub.cpp (heap-backed stand-in for the HIP runtime) and tests/asan/abi_driver.cpp, into build/asan/abi_driver.
+    Returns the executable's path.  Driven by tests/test_asan_cpu.py."""
+    hipcc = _hipcc()
+    clangxx = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(clangxx):
+        clangxx = "/opt/rocm/lib/llvm/bin/clang++"
+    root = os.path.dirname(HERE)
+    out_dir = os.path.join(root, "build", "asan")
+    os.makedirs(out_dir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(root, "include", "flicker_hip.h")]
+    san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g", "-O1", "-fPIC", "-std=c++17"]
+    objs, jobs = [], []
+    for src in SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if _stale(o, [s] + headers):
+            jobs.append([hipcc, "--offload-arch=gfx950", "--offload-host-only", "-Wno-unused-function", "-x", "hip"] + san + ["-c", s, "-o", o])
+    for src in ("hip_stub.cpp", "abi_driver.cpp"):
+        s, o = os.path.join(root, "tests", "asan", src), os.path.join(out_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if _stale(o, [s] + headers):
+            jobs.append([clangxx, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + san + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("asan build failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    exe = os.path.join(out_dir, "abi_driver")
+    if jobs or _stale(exe, objs):
+        # host-only objects still reference their (absent) device code object: __hip_fatbin_<hash>; the stub's registration ignores it
+        und = subprocess.run(["nm", "-u"] + objs, capture_output=True, text=True).stdout
+        defs = sorted({"-Wl,--defsym=" + tok + "=0" for line in und.splitlines() for tok in line.split() if tok.startswith("__hip_fatbin_")})
+        run([clangxx, "-fsanitize=address"] + objs + defs + ["-o", exe, "-ldl", "-lpthread"])
+    return exe
