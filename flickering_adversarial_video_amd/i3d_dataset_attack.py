@@ -31,7 +31,7 @@ import time
 import numpy as np
 import torch
 
-from . import config as cfgmod, i3d_spec, parallel, prefetch, tb_events, tf_checkpoint, tfrecord_io as tio
+from . import config as cfgmod, i3d_spec, ops, parallel, prefetch, tb_events, tf_checkpoint, tfrecord_io as tio
 from .i3d_engine import FlickerI3D
 
 ADAM_B1, ADAM_B2 = 0.9, 0.999        # tf.train.AdamOptimizer defaults (i3d_adversarial_main_single_class_gen.py:83)
@@ -175,11 +175,13 @@ def main(default_section, argv=None):
         x, y = batch
         if (y < 0).any() or (y >= len(classes)).any():
             raise ValueError(f"record labels outside [0, {len(classes)}): {y}")
-        y = torch.from_numpy(y).cuda()
+        y = ops.mark_labels_validated(torch.from_numpy(y).cuda(), len(classes))      # range-checked above, on the host
         # training feeds the target class as the label of a targeted attack (single_class_gen.py:226-229); evaluation counts a
         # clip as valid when its CLEAN prediction equals the TRUE label (kinetics_i3d_utils.py:241-243)
         x = x if torch.is_tensor(x) else torch.from_numpy(x).cuda()        # (prefetch.DeviceBatches yields device tensors)
-        return x, (torch.full_like(y, target_id) if (c.TARGETED_ATTACK and not true_labels) else y)
+        if c.TARGETED_ATTACK and not true_labels:
+            return x, ops.mark_labels_validated(torch.full_like(y, target_id), len(classes))      # target_id = classes.index(...)
+        return x, y
 
     def evaluate():
         it = (to_dev(b, true_labels=True) for b in prefetch.DeviceBatches(val_files, B, T, rank, world))

@@ -2,7 +2,7 @@
 memory and streams only; every computation happens in libflicker_hip.so."""
 import ctypes as C
 import json
-import os
+import weakref
 
 import numpy as np
 import torch
@@ -264,22 +264,41 @@ def pack_batch_sums(per_clip, prob_scale, out3):
     return out3
 
 
-def check_labels(labels, batch, num_classes, check_range=False):
-    """labels must be a contiguous CUDA int64 tensor of shape (batch,): anything else would hand the loss kernel a host pointer
-    (GPU memory fault) or a wrong stride.  These checks are free and run on every call.  The RANGE 0 <= label < num_classes is
-    validated where labels originate, on the host (i3d_dataset_attack.to_dev, the scripts' label look-ups); the kernel clamps a
-    bad index and poisons that clip's outputs with NaN (head.hip), so an out-of-range label cannot fault and cannot go unnoticed.
-    ``check_range=True`` (or FLK_CHECK_LABEL_RANGE=1) adds the device read-back of min / max -- two syncs, for debugging, never
-    cached: a tensor's address and version do not identify its contents (the caching allocator recycles both)."""
+_labels_ok = {}      # id(LIVE label tensor object) -> (weakref to it, _version, num_classes) it was range-checked at
+
+
+def _labels_memo_get(labels):
+    ent = _labels_ok.get(id(labels))
+    return (ent[1], ent[2]) if ent is not None and ent[0]() is labels else None
+
+
+def mark_labels_validated(labels, num_classes):
+    """Record that ``labels`` (a CUDA tensor) was range-checked where it originated, on the host (the dataset driver checks the
+    numpy labels of every record batch before the copy): check_labels then skips its device read-back for this tensor object.
+    The entry is removed when the tensor object dies (weakref callback), so a recycled id / address can never inherit it."""
+    key = id(labels)
+    _labels_ok[key] = (weakref.ref(labels, lambda _r, k=key: _labels_ok.pop(k, None)), labels._version, num_classes)
+    return labels
+
+
+def check_labels(labels, batch, num_classes):
+    """labels must be a contiguous CUDA int64 tensor of shape (batch,) with 0 <= label < num_classes: anything else would hand the
+    loss kernel a host pointer (GPU memory fault), a wrong stride or an out-of-range class index.  Device / dtype / shape are checked
+    on every call (free).  The range check reads min / max back from the device (two syncs) ONCE per live tensor object and
+    version: the memo is keyed on the identity of the LIVE tensor object (weak reference) -- not on its address, which the caching allocator recycles for
+    the next batch's labels -- so an entry dies with its tensor and an in-place write invalidates it.  A loop that reuses its label
+    tensor pays the read-back once; a loop that builds labels per batch validates them on the host and says so
+    (mark_labels_validated).  Independently, the kernel clamps a bad index and poisons that clip's outputs with NaN (head.hip)."""
     if not torch.is_tensor(labels) or not labels.is_cuda or labels.dtype != torch.int64 or tuple(labels.shape) != (batch,):
         desc = f"{tuple(labels.shape)} {labels.dtype} {labels.device}" if torch.is_tensor(labels) else type(labels).__name__
         raise ValueError(f"labels must be a CUDA int64 tensor of shape ({batch},), got {desc}")
     if not labels.is_contiguous():
         raise ValueError("labels must be contiguous")
-    if check_range or os.environ.get("FLK_CHECK_LABEL_RANGE") == "1":
+    if _labels_memo_get(labels) != (labels._version, num_classes):
         lo, hi = int(labels.min()), int(labels.max())
         if lo < 0 or hi >= num_classes:
             raise ValueError(f"labels must lie in [0, {num_classes}), got [{lo}, {hi}]")
+        mark_labels_validated(labels, num_classes)
     return labels
 
 
