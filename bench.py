@@ -41,16 +41,17 @@ def _cpu_cores():
     return max(1, min(cores, int(os.environ.get("FLK_CPU_BASELINE_THREADS", "16"))))
 
 
-def _cpu_iterations(W, T, B, n_timed, budget_s):
-    """n_timed (+1 warm-up) iterations of the oracle's attack iteration on B synthetic clips; returns (seconds per iteration, n, last adv loss)"""
+def _cpu_iterations(W, xu, n_timed, budget_s):
+    """n_timed (+1 warm-up) iterations of the oracle's attack iteration from delta = 0 on the uint8 clips xu [B,T,224,224,3];
+    returns (seconds per iteration, n, first-iteration record {labels, logits, adv_loss}, last adv loss)"""
     from oracle import attack_math as am
     from oracle import i3d_ref
-    from flickering_adversarial_video_amd import i3d_spec
     Wt = {k: torch.from_numpy(v) for k, v in W.items()}
-    x = torch.from_numpy(i3d_spec.synthetic_clip_u8(B, T, seed=1234)).float() / 128 - 1
+    T = xu.shape[1]
+    x = xu.float() / 128 - 1
     d = torch.zeros(T, 1, 1, 3)
     m, v = torch.zeros_like(d), torch.zeros_like(d)
-    label, times, t_start, it = None, [], time.time(), 0
+    label, first, times, t_start, it = None, None, [], time.time(), 0
     while True:
         t0 = time.time()
         dv = d.clone().requires_grad_(True)
@@ -60,6 +61,8 @@ def _cpu_iterations(W, T, B, n_timed, budget_s):
         adv, _, _ = am.tf_improve_adversarial_loss(lg, label, 0.05, False, False)
         total, _ = am.tf_total_loss(adv, dv, 1.0, 0.5, 0.5, 0.5)
         (g,) = torch.autograd.grad(total, dv)
+        if first is None:
+            first = {"labels": label.clone(), "logits": lg.detach().clone(), "adv_loss": float(adv.detach())}
         d, m, v = am.tf_adam_step(d, g, m, v, it + 1)
         dt = time.time() - t0
         it += 1
@@ -67,23 +70,50 @@ def _cpu_iterations(W, T, B, n_timed, budget_s):
             times.append(dt)          # first iteration is the warm-up
         if len(times) >= n_timed or (time.time() - t_start > budget_s and len(times) >= 1):
             break
-    return float(np.mean(times)), len(times), float(adv.detach())
+    return float(np.mean(times)), len(times), first, float(adv.detach())
 
 
-def cpu_baseline(W, T, budget_s=30.0):
-    """The CPU restatement (oracle/, torch-CPU fp32, the host cores of the GPU box) timed on the SAME iteration: bs = 1 (3 timed
-    iterations) and the headline bs = 8 (2 timed iterations, ~8 s each).  This is the only place bench.py touches oracle/ besides
-    the parity check below: it is the baseline being reported, never the product path."""
+def _same_clip_parity(W, xu, first, device, dtypes=("f32", "bf16")):
+    """The GPU engine's FIRST iteration (delta = 0, the oracle's own labels) on the SAME uint8 clips the CPU baseline just ran,
+    at the benchmark geometry: logits and adversarial loss relative to the oracle's (fp32 mode: the north-star 1e-3; the timed bf16
+    mode: stated 5e-2).  oracle/ supplies the reference values here, nothing on the product path."""
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    B, T = xu.shape[0], xu.shape[1]
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-300))
+    out = {"clips": B, "frames": T, "from": "delta = 0, labels = the oracle's clean argmax"}
+    for dt in dtypes:
+        eng = FlickerI3D(W, batch_size=B, frames=T, dtype=dt, device=device)
+        r = eng.step(xu.cuda(), first["labels"].cuda(), update=False, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05)
+        out[dt] = {"logits_rel_err": rel(eng._logits.cpu(), first["logits"]),
+                   "adv_loss_rel_err": abs(float(r["adv_loss"]) - first["adv_loss"]) / max(abs(first["adv_loss"]), 1e-30),
+                   "adv_loss": float(r["adv_loss"]), "oracle_adv_loss": first["adv_loss"],
+                   "argmax_equal": bool(torch.equal(r["argmax"].cpu(), first["logits"].argmax(-1))),
+                   "tolerance": 1e-3 if dt == "f32" else 5e-2}
+        out[dt]["ok"] = bool(out[dt]["logits_rel_err"] < out[dt]["tolerance"] and out[dt]["adv_loss_rel_err"] < out[dt]["tolerance"])
+        del eng
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(W, xu, device, budget_s=30.0):
+    """The CPU restatement (oracle/, torch-CPU fp32, the host cores of the GPU box) timed on the SAME iteration and the SAME clips
+    as the GPU run (xu = the benchmark's uint8 batch): bs = 1 (clip 0; 3 timed iterations) and the headline bs = 8 (2 timed
+    iterations, ~10 s each).  The first oracle iteration of each doubles as the parity reference for a GPU step on the same clip
+    (`parity_same_clip`).  This is the only place bench.py touches oracle/ besides the parity check below: it is the baseline
+    being reported and the checker, never the product path."""
     cores = _cpu_cores()
     torch.set_num_threads(cores)
-    sec1, n1, adv1 = _cpu_iterations(W, T, 1, 3, budget_s)
+    T, B = xu.shape[1], xu.shape[0]
+    sec1, n1, first1, adv1 = _cpu_iterations(W, xu[:1], 3, budget_s)
     out = {"value": 1.0 / sec1, "unit": "clip-iters/s", "cores": cores, "kind": "port",
-           "sample": f"{n1} timed iterations (+1 warm-up) of the same I3D attack iteration at bs=1, T={T}, 224x224, torch-CPU fp32",
-           "sec_per_iter": sec1, "conv_gflops": conv_gflop_per_clip(T) / sec1, "adv_loss_last": adv1}
-    if sec1 * 8 <= 60.0:                                    # BASELINE.md 3: "and bs=8 if <= 60 s/iter"
-        sec8, n8, _ = _cpu_iterations(W, T, 8, 2, 3 * budget_s)
-        out["bs8"] = {"value": 8.0 / sec8, "unit": "clip-iters/s", "sec_per_iter": sec8, "conv_gflops": 8 * conv_gflop_per_clip(T) / sec8,
-                      "sample": f"{n8} timed iterations (+1 warm-up) at the headline bs=8, T={T}"}
+           "sample": f"{n1} timed iterations (+1 warm-up) of the same I3D attack iteration on clip 0 of the benchmark batch (bs=1), T={T}, 224x224, torch-CPU fp32",
+           "sec_per_iter": sec1, "conv_gflops": conv_gflop_per_clip(T) / sec1, "adv_loss_last": adv1,
+           "parity_same_clip": _same_clip_parity(W, xu[:1], first1, device)}
+    if B > 1 and sec1 * B <= 60.0:                                    # BASELINE.md 3: "and bs=8 if <= 60 s/iter"
+        sec8, n8, first8, _ = _cpu_iterations(W, xu, 2, 3 * budget_s)
+        out[f"bs{B}"] = {"value": B / sec8, "unit": "clip-iters/s", "sec_per_iter": sec8, "conv_gflops": B * conv_gflop_per_clip(T) / sec8,
+                         "sample": f"{n8} timed iterations (+1 warm-up) on the benchmark batch itself (bs={B}), T={T}",
+                         "parity_same_clip": _same_clip_parity(W, xu, first8, device)}
     return out
 
 
@@ -393,7 +423,8 @@ def main():
             out["pool_GBps"] = pk["bytes"] / (pk["ms"] * 1e-3) / 1e9
 
     if rank == 0 and world == 1:
-        del eng
+        x_host = x.cpu()
+        del eng, x
         torch.cuda.empty_cache()
         if not a.no_other_configs:
             out["other_configs"] = other_configs(local_rank)
@@ -402,8 +433,11 @@ def main():
             if not out["parity"]["ok"]:
                 print(f"[bench] PARITY CHECK FAILED: {out['parity']}", file=sys.stderr)
         if not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(W, T)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"].get("bs8", out["cpu_baseline"])["value"]
+            out["cpu_baseline"] = cb = cpu_baseline(W, x_host, local_rank)
+            out["gpu_over_cpu"] = out["value"] / cb.get(f"bs{B}", cb)["value"]
+            bad = [k for k in (cb, cb.get(f"bs{B}", {})) for dt in ("f32", "bf16") if "parity_same_clip" in k and not k["parity_same_clip"][dt]["ok"]]
+            if bad:
+                print(f"[bench] SAME-CLIP PARITY FAILED: {[b['parity_same_clip'] for b in bad]}", file=sys.stderr)
 
     if rank == 0:
         print(json.dumps(out))

@@ -54,13 +54,13 @@ class _RoundBF16(torch.autograd.Function):
         return g.to(torch.bfloat16).to(g.dtype)
 
 
-def oracle_links(W, bf16):
+def oracle_links(W, bf16, dt=torch.float64):
     """[(endpoint name, fn(previous endpoint NCDHW fp64, final_relu) -> this endpoint)] following i3d.py:144-455.  With
     final_relu=False the block's OUTPUT units skip their ReLU: the HIP gradient buffers hold d(loss)/d(pre-ReLU output), so the
     backward of a link starts exactly there.  In bf16 mode weights are bf16-rounded and every stored activation / gradient is
     rounded to bf16 (like-for-like with the HIP bf16 path)."""
     rnd = _RoundBF16.apply if bf16 else (lambda t: t)
-    Wd = {k: (torch.from_numpy(v).to(torch.bfloat16).double() if (bf16 and k.endswith("/w") and "Logits" not in k) else torch.from_numpy(v).double())
+    Wd = {k: (torch.from_numpy(v).to(torch.bfloat16).to(dt) if (bf16 and k.endswith("/w") and "Logits" not in k) else torch.from_numpy(v).to(dt))
           for k, v in W.items()}
 
     def u(x, name, k, s=(1, 1, 1), relu=True):
@@ -640,3 +640,125 @@ def test_reference_default_clip_length(frames):
     cos16 = float(torch.nn.functional.cosine_similarity(g16.double().flatten(), g.double().flatten(), 0))
     print(f"T={Tn} bf16: logits rel err {rel_err(got16[:1], logits.detach()):.2e}, gradient cosine {cos16:.4f}")
     assert cos16 > 0.85
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The BENCHMARKED geometry (BASELINE.json: I3D, 64 x 224 x 224, bs 1 and bs 8) against the ORACLE -- not against the HIP path itself
+# (tests/test_fullsize_gpu.py holds the self-consistency properties).  At this size the launch layouts differ from the 16-frame
+# tests: other tile shapes and wave grids, split-K at bs 1, 192-row tiles, the half-batch stem split on two streams at bs 8.
+# The torch-CPU fp32 oracle costs ~1 s (bs 1) / ~10 s (bs 8) per forward + backward on the GPU box's 16 host cores.
+T64 = 64
+
+
+def _oracle32(W, xu, delta, n_threads=16):
+    """torch-CPU fp32 oracle pass on a [B,T,224,224,3] uint8 clip: logits, every endpoint, summed margin loss, d(loss)/d(delta)"""
+    torch.set_num_threads(min(n_threads, torch.get_num_threads() if torch.get_num_threads() > 1 else n_threads))
+    Wt = {k: torch.from_numpy(v) for k, v in W.items()}
+    x = xu.float() / 128 - 1
+    d = delta.clone().requires_grad_(True)
+    logits, ep = i3d_ref.i3d_logits(am.tf_apply(x, d), Wt, return_endpoints=True)
+    label = logits.argmax(-1)
+    loss, _, _ = am.tf_improve_adversarial_loss(logits, label, 0.05, False, False)
+    (g,) = torch.autograd.grad(loss, d)
+    return dict(logits=logits.detach(), ep={k: v.detach() for k, v in ep.items()}, loss=float(loss), label=label, g=g)
+
+
+def _delta64(seed):
+    d = torch.from_numpy(np.random.default_rng(seed).uniform(-0.06, 0.06, (T64, 1, 1, 3)).astype(np.float32))
+    d[5] = 0.45          # beyond the +-0.4 clip: no gradient there
+    return d
+
+
+@pytest.mark.parametrize("batch", [1, 8])
+def test_benchmark_geometry_fp32_vs_oracle(batch):
+    """fp32 mode at 64 x 224 x 224, bs 1 and the headline bs 8 (distinct clips, ONE shared delta): every forward endpoint, the
+    logits and the summed adversarial loss at 1e-3 of the torch-CPU fp32 oracle, d(loss)/d(delta) by cosine > 0.999 and max-rel
+    < 3e-2 (the bars of the T = 90 test: on the random-sign weights two fp32 implementations differ in a few ReLU / max-pool
+    decisions, which moves single gradient entries by ~1e-2 -- see the module docstring)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W = i3d_spec.synthetic_i3d_weights(42)
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(batch, T64, seed=1234))        # bench.py's clips (seed 1234 + rank 0)
+    delta = _delta64(64)
+    ref = _oracle32(W, xu, delta)
+    eng = FlickerI3D(W, batch_size=batch, frames=T64, dtype="f32")
+    eng.reset_perturbation(delta.numpy())
+    r = eng.step(xu.cuda(), ref["label"].cuda(), update=False, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05)
+    worst = 0.0
+    for name, want in ref["ep"].items():
+        got = torch.from_numpy(eng.net.activation(name))
+        e = rel_err(got, want.permute(0, 2, 3, 4, 1))
+        worst = max(worst, e)
+        assert e < 1e-3, f"bs {batch}: endpoint {name}: {e:.3e}"
+        del got
+    e_l = rel_err(eng._logits.cpu(), ref["logits"])
+    e_loss = abs(float(r["adv_loss"]) - ref["loss"]) / abs(ref["loss"])
+    g = eng.delta_gradient().cpu().reshape(ref["g"].shape)
+    cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), ref["g"].double().flatten(), 0))
+    e_g = rel_err(g, ref["g"])
+    print(f"bs {batch}, T {T64}, fp32 vs torch-CPU fp32 oracle: worst endpoint {worst:.2e}, logits {e_l:.2e}, adv loss {e_loss:.2e} "
+          f"({float(r['adv_loss']):.6f} vs {ref['loss']:.6f}), d(loss)/d(delta) cosine {cos:.6f} max-rel {e_g:.2e}")
+    assert e_l < 1e-3 and e_loss < 1e-3
+    assert cos > 0.999 and e_g < 3e-2
+    assert g[5].abs().max() == 0
+    assert torch.equal(r["argmax"].cpu(), ref["logits"].argmax(-1))
+
+
+def test_benchmark_geometry_bf16_vs_rounded_oracle():
+    """The TIMED dtype at 64 x 224 x 224, bs 1, through the engine's own iteration (centred clip + position-bias stem forward, fused
+    stem delta-gradient, split-K plan), against the bf16-rounded oracle of oracle_links, link by link on the HIP path's own
+    inputs, at the bf16 tolerances of the 16-frame test: every forward link 1.6e-2 of the endpoint maximum; the final
+    d(loss)/d(delta) link (stem backward + clip masks + (b,h,w) reduction, fed the HIP path's own gradient of Conv3d_1a) 2e-2.
+    End to end against the fp32 oracle: logits and loss 5e-2 (stated), gradient cosine reported and asserted at its measured
+    value minus a margin."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W = i3d_spec.synthetic_i3d_weights(42)
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(1, T64, seed=1234))
+    delta = _delta64(64)
+    ref = _oracle32(W, xu, delta)
+    eng = FlickerI3D(W, batch_size=1, frames=T64, dtype="bf16")
+    assert eng.fused_delta_grad and eng.exact_delta_forward
+    eng.reset_perturbation(delta.numpy())
+    r = eng.step(xu.cuda(), ref["label"].cuda(), update=False, lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05)
+    logits = eng._logits.cpu()
+    hip_act = lambda n: torch.from_numpy(eng.net.activation(n)).permute(0, 4, 1, 2, 3).contiguous()
+    d0 = delta.clone().requires_grad_(True)
+    # the exact-delta forward hands the stem the UNROUNDED perturbed clip (bf16 clean pixel + fp32 perturbation): the link's input is
+    # the fp32 clip, not its bf16 rounding
+    prev_name, prev = "delta", am.tf_apply(xu.float() / 128 - 1, d0).permute(0, 4, 1, 2, 3).contiguous()
+    links = oracle_links(W, True, dt=torch.float32)
+    name0, fn0 = links[0]
+    Wd32 = {k: torch.from_numpy(v).to(torch.bfloat16).float() if (k.endswith("/w") and "Logits" not in k) else torch.from_numpy(v) for k, v in W.items()}
+    stem = lambda x, relu: i3d_ref.unit3d(x, Wd32, "Conv3d_1a_7x7", (7, 7, 7), (2, 2, 2), relu=relu)
+    worst = 0.0
+    for name, fn in links:
+        with torch.no_grad():
+            out = stem(prev, True).to(torch.bfloat16).float() if name == name0 else fn(prev, True)
+        got = logits if name == "Logits" else hip_act(name)
+        e_f = rel_err(out, got)
+        worst = max(worst, e_f)
+        print(f"[bf16 T={T64}] forward link {prev_name:>17s} -> {name:<17s} max-rel {e_f:.2e}")
+        assert e_f < 1.6e-2, f"forward link {prev_name} -> {name}: {e_f:.3e}"
+        if name == name0:
+            got_g = hip_act("grad:" + name0)                         # d(loss)/d(pre-ReLU stem output), HIP
+            (g_ref,) = torch.autograd.grad(stem(prev, False), d0, grad_outputs=got_g)
+            g_hip = eng.delta_gradient().cpu().reshape(g_ref.shape)
+            e_g = rel_err(g_hip, g_ref)
+            print(f"[bf16 T={T64}] d(loss)/d(delta) link (fused stem kernel): max-rel {e_g:.2e}")
+            assert e_g < 2e-2
+        prev_name = name
+        if name != "Logits":
+            prev = got
+    e_l = rel_err(logits, ref["logits"])
+    e_loss = abs(float(r["adv_loss"]) - ref["loss"]) / abs(ref["loss"])
+    g = eng.delta_gradient().cpu().reshape(ref["g"].shape)
+    cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), ref["g"].double().flatten(), 0))
+    print(f"[bf16 T={T64}] end to end vs fp32 oracle: logits {e_l:.2e}, adv loss {e_loss:.2e}, d(loss)/d(delta) cosine {cos:.4f}")
+    assert e_l < 5e-2 and e_loss < 5e-2
+    assert cos > 0.85
+    assert g[5].abs().max() == 0

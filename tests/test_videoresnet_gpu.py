@@ -113,7 +113,8 @@ def test_videoresnet_forward_backward(arch):
         del eng
 
 
-def test_videoresnet_attack_trajectory_well_conditioned():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_videoresnet_attack_trajectory_well_conditioned(dtype):
     """BASELINE config 3 (r2plus1d_18, bs 1, 16 x 112 x 112, torch dialect) at the north-star bar: logits, adversarial loss and the
     LEARNED DELTA of the fp32 mode within 1e-3 of the reference maths (fp64 oracle) over 6 iterations of the single-video loop
     (model.py:1073-1101: Perturbation -> net -> Losses -> backward -> torch-Adam) on the well-conditioned fixture
@@ -150,17 +151,59 @@ def test_videoresnet_attack_trajectory_well_conditioned():
     assert int(label) == int(label32) == 233
     for it in range(steps):
         assert rel_err(t32[it]["delta"], t64[it]["delta"]) < 1e-4, "fixture is not well-conditioned"
-    eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype="f32", l_inf_pert_norm=0.2)
+    # bf16 (the dtype config 3 is benchmarked in): the same trajectory at stated bf16 tolerances -- learned delta 2e-2, logits 5e-2,
+    # adversarial loss 5e-2 (the I3D bf16 bars, tests/test_i3d_gpu.py::test_bf16_trajectory_well_conditioned)
+    TOL_D, TOL_L, TOL_A = (1e-3, 1e-3, 1e-3) if dtype == "f32" else (2e-2, 5e-2, 5e-2)
+    eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype=dtype, l_inf_pert_norm=0.2)
     eng.pert_model.init_perturbation(np.zeros((3, T, 1, 1), np.float32))      # (the default start is U(-1,1)*1e-6, model.py:121-126)
     crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)
+    worst = [0.0, 0.0, 0.0]
     for it in range(steps):
         res = eng.step(x_cl.cuda(), label.cuda(), crit, lr=LR).host()
         delta = eng.pert_model.perturbation.cpu().t().reshape(3, T, 1, 1)
         e_d, e_l = rel_err(delta, t64[it]["delta"]), rel_err(eng._logits.cpu(), t64[it]["logits"])
-        print(f"iter {it + 1}: adv {res['adv_loss']:.7f} (fp64 oracle {t64[it]['adv']:.7f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e} "
+        e_a = abs(float(res["adv_loss"]) - t64[it]["adv"]) / max(abs(t64[it]["adv"]), 1e-7)
+        worst = [max(a, b) for a, b in zip(worst, (e_d, e_l, e_a))]
+        print(f"[{dtype}] iter {it + 1}: adv {res['adv_loss']:.7f} (fp64 oracle {t64[it]['adv']:.7f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e} "
               f"(torch-CPU fp32 oracle delta {rel_err(t32[it]['delta'], t64[it]['delta']):.2e})")
-        assert e_d < 1e-3 and e_l < 1e-3
-        assert res["adv_loss"] == pytest.approx(t64[it]["adv"], rel=1e-3, abs=1e-7)
+    print(f"[{dtype}] worst over {steps} iterations: delta {worst[0]:.2e}, logits {worst[1]:.2e}, adversarial loss {worst[2]:.2e}")
+    assert worst[0] < TOL_D and worst[1] < TOL_L and worst[2] < TOL_A
+
+
+def test_videoresnet_bf16_small_delta_reaches_the_logits():
+    """How small a flicker perturbation still moves the logits through the bf16 stem input?  The normalised clip (u8/255 - mean)/std
+    is NOT exactly representable in bf16 (unlike I3D's u8/128 - 1), so x + delta/std is rounded per pixel with the pixel's own offset
+    inside its ulp: a delta far below half an ulp still flips the fraction delta/ulp of the pixels, and the change of the logits
+    -- a sum over 2e5 pixels per frame -- follows the fp32 change.  Measured here for |delta| from 1e-4 up to the reference's start value
+    (U(+-0.005), model.py:946-948) and beyond: relative error of the bf16 logit CHANGE against the fp32 engine's, on the
+    well-conditioned fixture.  Asserted: at the reference's start amplitude 0.005 and above the change agrees within 25 %."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet
+    from oracle import fixtures
+    arch = "r2plus1d_18"
+    x_cl = torch.from_numpy(vs.synthetic_clip(1, T, HW, HW, seed=5))
+    W = fixtures.coherent_videoresnet_weights(vs.synthetic_weights(arch, 42), x_cl.permute(0, 4, 1, 2, 3).contiguous(), arch, label=233)
+    sign = np.sign(np.random.default_rng(8).standard_normal((3, T, 1, 1))).astype(np.float32)
+    amps = (1e-4, 3e-4, 1e-3, 5e-3, 2e-2)
+    change = {}
+    for dtype in ("f32", "bf16"):
+        eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype=dtype, l_inf_pert_norm=0.2)
+        eng.pert_model.init_perturbation(np.zeros((3, T, 1, 1), np.float32))
+        base = eng.logits(x_cl.cuda()).clone()
+        change[dtype] = []
+        for a in amps:
+            eng.pert_model.init_perturbation(a * sign)
+            change[dtype].append((eng.logits(x_cl.cuda(), adversarial=True) - base).cpu().double())
+        del eng
+    errs = []
+    for a, c32, c16 in zip(amps, change["f32"], change["bf16"]):
+        e = float((c16 - c32).norm() / c32.norm())
+        cos = float(torch.nn.functional.cosine_similarity(c16.flatten(), c32.flatten(), 0))
+        errs.append(e)
+        print(f"|delta| = {a:g}: logit change fp32 |.| {float(c32.norm()):.3e}, bf16 {float(c16.norm()):.3e}; rel-L2 error {e:.3f}, cosine {cos:.4f}")
+    assert errs[3] < 0.25 and errs[4] < 0.25
 
 
 @pytest.mark.gpu
