@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
                 ("relu", C.c_int),
                 ("in2", C.c_void_p), ("in2_ld", C.c_int), ("in2_coff", C.c_int), ("cin1", C.c_int),
                 ("out2", C.c_void_p), ("out2_ld", C.c_int), ("out2_coff", C.c_int), ("cout1", C.c_int),
-                ("pos_bias", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64)]
+                ("pos_bias", C.c_void_p), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64), ("pos_bias_bstride", C.c_int64)]
 
 
 class PoolArgs(C.Structure):
@@ -51,7 +51,8 @@ class ApplyArgs(C.Structure):
                 ("dclip", C.c_float), ("inv_std", C.c_float * 3),
                 ("lo", C.c_float), ("hi", C.c_float), ("adv_flag", C.c_float),
                 ("shift_x", C.c_int), ("shift_p", C.c_int),
-                ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("fold_t", C.c_int), ("center", C.c_int)]
+                ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("fold_t", C.c_int), ("center", C.c_int),
+                ("delta_per_clip", C.c_int)]
 
 
 class AdamArgs(C.Structure):
@@ -91,6 +92,8 @@ _SIGS = {
     "flk_perturb_grad_reduce": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_pack_batch_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "flk_perturb_reg_adam": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_perturb_reg_adam_batched": (C.c_int, [C.POINTER(AdamArgs), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_dense_adam_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "flk_perturb_dense_l12_adam": (C.c_int, [C.POINTER(DenseAdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),

@@ -78,9 +78,10 @@ __device__ static inline float applied(const flk_apply_args& a, float x, float p
 __device__ static inline int wrap(int t, int T) { t %= T; return t < 0 ? t + T : t; }
 
 // perturbation added at frame t (before adv_flag): p'[t] = p[(t - shift_p) mod T] (tf.roll), p = clip(delta)/std
-__device__ static inline float pert_at(const flk_apply_args& a, int t, int h, int w, int c) {
+// (delta_per_clip: clip b has its own [T,3] perturbation)
+__device__ static inline float pert_at(const flk_apply_args& a, int b, int t, int h, int w, int c) {
   const int ts = wrap(t - a.shift_p, a.T);
-  float d = a.delta_dense ? a.delta[(((size_t)ts * a.H + h) * a.W + w) * 3 + c] : a.delta[ts * 3 + c];
+  float d = a.delta_dense ? a.delta[(((size_t)ts * a.H + h) * a.W + w) * 3 + c] : a.delta[(a.delta_per_clip ? b * a.T : 0) * 3 + ts * 3 + c];
   if (a.dclip > 0.f) d = clipf(d, -a.dclip, a.dclip);
   return d * a.inv_std[c];
 }
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
         for (int qw = 0; qw < 2; ++qw)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float pv = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, t, h, 2 * w2 + qw, c) : 0.f;
+            const float pv = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, b, t, h, 2 * w2 + qw, c) : 0.f;
             v[S2D<FTL>::ch(qt, qh, qw * 3 + c)] = applied(a, x[qw * 3 + c], pv);
           }
       }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void apply_s2d_u8_flicker_kernel(const flk_app
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) pv[qt][c] = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, 2 * t2 + qt, 0, 0, c) : 0.f;
+    for (int c = 0; c < 3; ++c) pv[qt][c] = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, b, 2 * t2 + qt, 0, 0, c) : 0.f;
   uint2 raw[2][2][3];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
@@ -179,6 +180,7 @@ static int check_apply(const flk_apply_args* a) {
               "flk_perturb: H,W (and T when folded) must be positive and even (got %d,%d,%d)", a->T, a->H, a->W);
   FLK_REQUIRE(a->lo <= a->hi, "flk_perturb: lo > hi");
   FLK_REQUIRE(!(a->center && a->delta_dense), "flk_perturb: center = 1 is defined for the flicker perturbation [T,3] only");
+  FLK_REQUIRE(!(a->delta_per_clip && a->delta_dense), "flk_perturb: delta_per_clip is defined for the flicker perturbation only");
   return FLK_OK;
 }
 
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a
         for (int qw = 0; qw < 2; ++qw)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float u = x[qw * 3 + c] + a.adv_flag * pert_at(a, t, h, 2 * w2 + qw, c);
+            const float u = x[qw * 3 + c] + a.adv_flag * pert_at(a, b, t, h, 2 * w2 + qw, c);
             if (u >= a.lo && u <= a.hi) acc[qt * 3 + c] += g[S2D<FTL>::ch(qt, qh, qw * 3 + c)];
           }
       }
@@ -267,24 +269,27 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a
 }
 
 // stage 2: thread (t,c) sums partials over (b, chunk) in a fixed order; maps frame t back to the delta
-// index it was rolled from; applies adv_flag, 1/std and the delta clip mask.
+// index it was rolled from; applies adv_flag, 1/std and the delta clip mask.  delta_per_clip: one (t,c) row per clip
+// (blockIdx.y = clip), summed over that clip's chunks only -- the order of a batch-1 call with the same chunk count.
 __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const float* partials, float* gdelta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.T * 3) return;
   const int FT = a.fold_t == 1 ? 1 : 2;                 // frames per folded position (fold_t 0, 2, 3: two)
   const int t = i / 3, c = i % 3, t2 = t / FT, qt = t % FT, T2 = a.T / FT;
+  const int b_lo = a.delta_per_clip ? (int)blockIdx.y : 0, b_hi = a.delta_per_clip ? b_lo + 1 : a.B;
   float s = 0.f;
-  for (int b = 0; b < a.B; ++b)
+  for (int b = b_lo; b < b_hi; ++b)
     for (int k = 0; k < nchunk; ++k) s += partials[(((size_t)b * T2 + t2) * nchunk + k) * 6 + qt * 3 + c];
   const int ts = wrap(t - a.shift_p, a.T);
-  const float d = a.delta[ts * 3 + c];
+  const size_t dbase = a.delta_per_clip ? (size_t)b_lo * a.T * 3 : 0;
+  const float d = a.delta[dbase + ts * 3 + c];
   const bool pass = !(a.dclip > 0.f) || (d >= -a.dclip && d <= a.dclip);
-  gdelta[ts * 3 + c] = pass ? s * a.adv_flag * a.inv_std[c] : 0.f;
+  gdelta[dbase + ts * 3 + c] = pass ? s * a.adv_flag * a.inv_std[c] : 0.f;
 }
 
 // stage 2 alone, for producers of stage-1 partials outside this file (stem_grad.hip)
 int flk_grad_reduce_stage2_launch(const flk_apply_args* a, int nchunk, const float* partials, float* gdelta, hipStream_t s) {
-  hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128), dim3(128), 0, s, *a, nchunk, partials, gdelta);
+  hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128, a->delta_per_clip ? a->B : 1), dim3(128), 0, s, *a, nchunk, partials, gdelta);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a,
           load6(a, ((((size_t)b * a.T + tx) * a.H + 2 * h2 + qh) * a.W + 2 * w2) * 3, x);
 #pragma unroll
           for (int k = 0; k < 6; ++k) {
-            const float u = x[k] + a.adv_flag * pert_at(a, t, 2 * h2 + qh, 2 * w2 + k / 3, k % 3);
+            const float u = x[k] + a.adv_flag * pert_at(a, b, t, 2 * h2 + qh, 2 * w2 + k / 3, k % 3);
             if (u >= a.lo && u <= a.hi) acc[S2D<FTL>::ch(qt, qh, k)] += g[S2D<FTL>::ch(qt, qh, k)];
           }
         }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256) void grad_dense_kernel(const flk_apply_args a,
 extern "C" int64_t flk_perturb_grad_scratch_bytes(int B, int T, int H, int W) {
   (void)W;
   if (B <= 0 || T <= 0 || H <= 0) return 0;
-  return (int64_t)B * T * grad_nchunk(B, T, H) * 6 * sizeof(float);   // covers both fold_t settings
+  return (int64_t)B * T * grad_nchunk(1, T, H) * 6 * sizeof(float);   // covers both fold_t settings and the per-clip chunking (batch-1 chunk count)
 }
 
 extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s2d, int dtype, float* gdelta,
@@ -360,13 +365,15 @@ extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s
 #undef FLK_GD
   } else {
     FLK_REQUIRE(partials, "flk_perturb_grad_reduce: null scratch");
-    const int nchunk = grad_nchunk(a->B, a->T, a->H);
+    // per-clip perturbations: the chunking (= summation order) of a batch-1 call, so that clip b of a batch follows the same
+    // trajectory, bit for bit in fp32, as the same clip attacked alone
+    const int nchunk = grad_nchunk(a->delta_per_clip ? 1 : a->B, a->T, a->H);
     const unsigned grid = (unsigned)(a->B * (a->T / ft) * nchunk);
 #define FLK_GR(TT, L) hipLaunchKernelGGL((grad_reduce_stage1<TT, L>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials)
     if (bf) { if (ftl == 1) FLK_GR(bf16_t, 1); else if (ftl == 2) FLK_GR(bf16_t, 2); else FLK_GR(bf16_t, 3); }
     else { if (ftl == 1) FLK_GR(float, 1); else if (ftl == 2) FLK_GR(float, 2); else FLK_GR(float, 3); }
 #undef FLK_GR
-    hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128), dim3(128), 0, s, *a, nchunk, partials, gdelta);
+    hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128, a->delta_per_clip ? a->B : 1), dim3(128), 0, s, *a, nchunk, partials, gdelta);
   }
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
@@ -407,10 +414,19 @@ __device__ static inline float block_max(float v, float* sh) {
 
 constexpr int ADAM_PER = 8;  // 256 threads x 8 >= 3*T  (T <= 682)
 
+// blockIdx.x = clip (flk_perturb_reg_adam_batched: B independent perturbations, each with its own Adam state, step counter and
+// "still attacking" flag, all on the device -- no host value changes between iterations, so the loop can be replayed as a graph)
 __global__ __launch_bounds__(256) void reg_adam_kernel(const flk_adam_args a, const float* g_adv, float* delta, float* m, float* v,
-                                                       float* scalars) {
+                                                       float* scalars, int* steps, const int* active) {
   __shared__ float sh[4];
   const int T = a.T, N = 3 * T;
+  {
+    const size_t o = (size_t)blockIdx.x * N;
+    g_adv += o; delta += o; m += o; v += o;
+    if (scalars) scalars += (size_t)blockIdx.x * 8;
+  }
+  const int step = steps ? steps[blockIdx.x] + 1 : a.step;        // 1-based step of THIS update
+  const bool update = !active || active[blockIdx.x] != 0;         // a retired clip keeps its state; its scalars are still reported
   const float dyn = a.dyn_max_norm;
   // value the regulariser sees: raw delta (TF, kinetics_i3d_utils.py:172) or clamp(delta) (torch, model.py:1078)
   auto rv = [&](int t, int c) -> float {
@@ -419,8 +435,8 @@ __global__ __launch_bounds__(256) void reg_adam_kernel(const flk_adam_args a, co
   };
   float nd[ADAM_PER], nm[ADAM_PER], nv[ADAM_PER];
   float s_norm = 0.f, s_diff = 0.f, s_lap = 0.f, s_abs = 0.f, s_rough = 0.f, s_max = -INFINITY, s_min = INFINITY;
-  const float lr_tf = a.lr * sqrtf(1.f - powf(a.adam_b2, (float)a.step)) / (1.f - powf(a.adam_b1, (float)a.step));
-  const float bc1 = 1.f - powf(a.adam_b1, (float)a.step), bc2s = sqrtf(1.f - powf(a.adam_b2, (float)a.step));
+  const float lr_tf = a.lr * sqrtf(1.f - powf(a.adam_b2, (float)step)) / (1.f - powf(a.adam_b1, (float)step));
+  const float bc1 = 1.f - powf(a.adam_b1, (float)step), bc2s = sqrtf(1.f - powf(a.adam_b2, (float)step));
 #pragma unroll
   for (int k = 0; k < ADAM_PER; ++k) {
     const int i = threadIdx.x + 256 * k;
@@ -448,11 +464,14 @@ __global__ __launch_bounds__(256) void reg_adam_kernel(const flk_adam_args a, co
   const float t_abs = block_sum(s_abs, sh), t_rough = block_sum(s_rough, sh);
   const float t_max = block_max(s_max, sh), t_min = -block_max(-s_min, sh);
   __syncthreads();   // every neighbour read of delta is done
+  if (update) {
 #pragma unroll
-  for (int k = 0; k < ADAM_PER; ++k) {
-    const int i = threadIdx.x + 256 * k;
-    if (i >= N) continue;
-    delta[i] = nd[k]; m[i] = nm[k]; v[i] = nv[k];
+    for (int k = 0; k < ADAM_PER; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i >= N) continue;
+      delta[i] = nd[k]; m[i] = nm[k]; v[i] = nv[k];
+    }
+    if (threadIdx.x == 0 && steps) steps[blockIdx.x] = step;
   }
   if (threadIdx.x == 0 && scalars) {
     const float norm = t_norm / N + 1e-12f, diff = t_diff / N + 1e-12f, lap = t_lap / N + 1e-12f;
@@ -467,7 +486,17 @@ extern "C" int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, 
   FLK_REQUIRE(a && g_adv && delta && m && v, "flk_perturb_reg_adam: null argument");
   FLK_REQUIRE(a->T > 0 && 3 * a->T <= 256 * ADAM_PER, "flk_perturb_reg_adam: T out of range (%d)", a->T);
   FLK_REQUIRE(a->step >= 1, "flk_perturb_reg_adam: step is 1-based");
-  hipLaunchKernelGGL(reg_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars);
+  hipLaunchKernelGGL(reg_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, (int*)nullptr, (const int*)nullptr);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+extern "C" int flk_perturb_reg_adam_batched(const flk_adam_args* a, int nclip, const float* g_adv, float* delta, float* m, float* v,
+                                            int* steps_dev, const int* active_dev, float* scalars, void* stream) {
+  FLK_REQUIRE(a && g_adv && delta && m && v && steps_dev, "flk_perturb_reg_adam_batched: null argument");
+  FLK_REQUIRE(nclip > 0 && nclip < 65536, "flk_perturb_reg_adam_batched: bad clip count %d", nclip);
+  FLK_REQUIRE(a->T > 0 && 3 * a->T <= 256 * ADAM_PER, "flk_perturb_reg_adam_batched: T out of range (%d)", a->T);
+  hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)nclip), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, steps_dev, active_dev);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

@@ -32,7 +32,7 @@
 struct ConvKP {
   const char* in; const char* in2; const char* w; char* out; char* out2;
   const float* scale; const float* bias; const char* add; const char* mask;
-  const float* pos_bias;
+  const float* pos_bias; long pos_bias_bstride;
   int in_ld, in_coff, cin;
   int B, Ti, Hi, Wi;
   int kt, kh, kw, st, sh, sw, pt, ph, pw;
@@ -93,11 +93,12 @@ __device__ static inline int plane_off(int c, int plane_b) { return c * plane_b 
 __device__ static inline int fdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
 
 // position-class bias row of an output position (flk_conv_args.pos_bias), or nullptr
-__device__ static inline const float* pos_bias_row(const ConvKP& p, int ot, int oh, int ow) {
+// (pos_bias_bstride != 0: one table per clip b -- per-clip perturbations)
+__device__ static inline const float* pos_bias_row(const ConvKP& p, int b, int ot, int oh, int ow) {
   if (!p.pos_bias) return nullptr;
   const int hc = oh == 0 ? 0 : oh == p.Ho - 1 ? 3 : oh == p.Ho - 2 ? 2 : 1;
   const int wc = ow == 0 ? 0 : ow == p.Wo - 1 ? 3 : ow == p.Wo - 2 ? 2 : 1;
-  return p.pos_bias + (size_t)((ot * 4 + hc) * 4 + wc) * p.cout;
+  return p.pos_bias + (size_t)b * p.pos_bias_bstride + (size_t)((ot * 4 + hc) * 4 + wc) * p.cout;
 }
 
 // the epilogue of EPL consecutive output channels [c0, c0 + EPL) of physical output position opos: v = acc*scale + bias (+ position
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
     if (ot >= p.To || oh >= p.Ho || ow >= p.Wo) continue;
     const size_t opos = ((size_t)(b * p.OT + ot * p.ost + p.oot) * p.OH + oh * p.osh + p.ooh) * p.OW + ow * p.osw + p.oow;
-    const float* pb = pos_bias_row(p, ot, oh, ow);
+    const float* pb = pos_bias_row(p, b, ot, oh, ow);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int c0 = cbase + g * 4 * EPL;
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvKP p)
   const float* pb = nullptr;
   if (p.pos_bias) {
     const int ow = (int)(opos % (unsigned)p.OW), oh = (int)(opos / (unsigned)p.OW % (unsigned)p.OH), ot = (int)(opos / (unsigned)(p.OW * p.OH) % (unsigned)p.OT);
-    pb = pos_bias_row(p, ot, oh, ow);
+    pb = pos_bias_row(p, (int)(opos / (unsigned)(p.OW * p.OH * p.OT)), ot, oh, ow);
   }
   finish_store<T>(p, opos, pb, c0, v);
 }
@@ -776,7 +777,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   ConvKP kp{};
   kp.in = (const char*)a->in; kp.w = (const char*)w->dev; kp.out = (char*)a->out;
   kp.scale = a->scale; kp.bias = a->bias; kp.add = (const char*)a->add; kp.mask = (const char*)a->mask;
-  kp.pos_bias = a->pos_bias;
+  kp.pos_bias = a->pos_bias; kp.pos_bias_bstride = (long)a->pos_bias_bstride;
   FLK_REQUIRE(!a->pos_bias || (a->Ho >= 4 && a->Wo >= 4 && !a->out2), "flk_conv3d: pos_bias needs Ho, Wo >= 4 and a single output segment");
   kp.in_ld = a->in_ld; kp.in_coff = a->in_coff; kp.cin = a->cin;
   kp.B = a->B; kp.Ti = a->Ti; kp.Hi = a->Hi; kp.Wi = a->Wi;

@@ -105,6 +105,7 @@ struct flk_net {
   float* d_stem_sums = nullptr;
   float* d_stem_tab = nullptr;
   const float* cur_pos_bias = nullptr;
+  int64_t cur_pos_bias_bstride = 0;
   // head
   float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
   // profiling
@@ -344,7 +345,7 @@ int flk_net::build_i3d() {
   if (dtype == FLK_BF16) {
     if ((rc = flk_stem_delta_grad_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_wf))) return rc;
     if ((rc = flk_stem_delta_bias_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_sums))) return rc;
-    if ((rc = dmalloc((void**)&d_stem_tab, (size_t)(T / 2) * 16 * 64 * sizeof(float), true))) return rc;
+    if ((rc = dmalloc((void**)&d_stem_tab, (size_t)B * (T / 2) * 16 * 64 * sizeof(float), true))) return rc;   // (one table per clip: per-clip perturbations)
   }
   const int T1 = T / 2, H1 = H / 2, W1 = W / 2;
   Act xin; xin.T = T1; xin.H = H1; xin.W = W1; xin.ld = 32;       // bound per call
@@ -383,9 +384,11 @@ int flk_net::build_i3d() {
       flk_conv_weights* wf = stem->wf;
       const int dt = dtype;
       const size_t in_off = (size_t)bs_b0 * T1 * H1 * W1 * 32 * esz();
-      fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * stem_macs, conv_bytes(a), [this, a, wf, dt, in_off](hipStream_t s) mutable {
+      const int b0 = bs_b0;
+      fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * stem_macs, conv_bytes(a), [this, a, wf, dt, in_off, b0](hipStream_t s) mutable {
                          a.in = (const char*)x_in + in_off;
-                         a.pos_bias = cur_pos_bias;            // flk_net_forward_flicker: the perturbation enters here, in fp32
+                         a.pos_bias_bstride = cur_pos_bias_bstride;
+                         a.pos_bias = cur_pos_bias ? cur_pos_bias + (size_t)b0 * cur_pos_bias_bstride : nullptr;   // flk_net_forward_flicker: the perturbation enters here, in fp32
                          return flk_conv3d(&a, wf, dt, s);
                        }});
     }
@@ -562,11 +565,17 @@ int flk_net::build_i3d() {
     const Act in_act = cur, Gin = Gcur;
     const bool in_relu = cur_is_relu;
     const std::string pname = bn + "/Branch_3/MaxPool3d_0a_3x3";
+    // Branch_3's backward is a CHAIN of two kernels (1x1x1 data-gradient -> pool scatter) beside the two single 3x3x3 data-gradients:
+    // started together, its first link is starved by the big launches (19 -> 88 us in Mixed_4c) and the scatter then runs alone on
+    // the device before the join.  FLK_B3_EARLY=1: the 1x1x1 link runs BEFORE the fork, alone (it is short), and the scatter
+    // overlaps the 3x3x3 data-gradients.
+    static const bool b3_early = getenv("FLK_B3_EARLY") && atoi(getenv("FLK_B3_EARLY"));
     bwd_emit.push_back([=]() {
+      if (b3_early) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
       push_sync(bwd, K_FORK);
       {
         const size_t m0 = bwd.size();
-        emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
+        if (!b3_early) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
         emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
         set_lane(bwd, m0, 2);
       }
@@ -1076,9 +1085,12 @@ extern "C" int flk_net_forward_flicker(flk_net* n, const void* x_in, const flk_a
               "(flicker perturbation, T = %d)", n->T);
   int rc = flk_stem_delta_bias(a, n->d_stem_sums, n->d_stem_tab, stream);
   if (rc) return rc;
+  FLK_REQUIRE(!a->delta_per_clip || a->B == n->B, "flk_net_forward_flicker: per-clip perturbations for %d clips, the net has %d", a->B, n->B);
   n->cur_pos_bias = n->d_stem_tab;
+  n->cur_pos_bias_bstride = a->delta_per_clip ? (int64_t)(n->T / 2) * 16 * 64 : 0;
   rc = flk_net_forward(n, x_in, logits, 1, stream);
   n->cur_pos_bias = nullptr;
+  n->cur_pos_bias_bstride = 0;
   return rc;
 }
 

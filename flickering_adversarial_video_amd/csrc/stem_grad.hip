@@ -68,8 +68,8 @@ struct StemGradKP {
 __device__ inline int sg_wrap(int t, int T) { t %= T; return t < 0 ? t + T : t; }
 __device__ inline float sg_clip(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 // perturbation added at frame t (flicker delta only) -- the same expression as attack.hip: pert_at
-__device__ inline float sg_pert(const flk_apply_args& a, int t, int c) {
-  float d = a.delta[sg_wrap(t - a.shift_p, a.T) * 3 + c];
+__device__ inline float sg_pert(const flk_apply_args& a, int b, int t, int c) {
+  float d = a.delta[(a.delta_per_clip ? b * a.T : 0) * 3 + sg_wrap(t - a.shift_p, a.T) * 3 + c];
   if (a.dclip > 0.f) d = sg_clip(d, -a.dclip, a.dclip);
   return d * a.inv_std[c];
 }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void stem_mask_kernel(const flk_apply_args a, 
   }
   int buf = 0;
   for (int row = blockIdx.x; row < nrows; row += gridDim.x, buf ^= 1) {
-    const int t = (row / a.H) % a.T;
+    const int t = (row / a.H) % a.T, b = row / (a.H * a.T);
     const unsigned cu = nu; const float4 cf = nf;
     if (loader && row + (int)gridDim.x < nrows) {
       if (a.x_is_u8) nu = *(const unsigned*)((const unsigned char*)a.x + row_src(row + gridDim.x));
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void stem_mask_kernel(const flk_apply_args a, 
     if (loader) {
       float pv[3];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pv[c] = a.adv_flag * sg_pert(a, t, c);
+      for (int c = 0; c < 3; ++c) pv[c] = a.adv_flag * sg_pert(a, b, t, c);
       float xv[4];
       if (a.x_is_u8) {
 #pragma unroll
@@ -440,7 +440,7 @@ extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g
   kp.mask = (const char*)scratch + sg_partial_bytes(a->B, a->T, a->H);
   FLK_REQUIRE((size_t)a->B * kp.To * kp.Ho * kp.Wo * g_ld < (1ull << 31), "flk_stem_delta_grad: tensor too large");
   { static const char* e = getenv("FLK_SG_DBG"); kp.dbg = e ? atoi(e) : 0; }
-  kp.nchunk = sg_nchunk(a->B, a->T, kp.Ho);
+  kp.nchunk = sg_nchunk(a->delta_per_clip ? 1 : a->B, a->T, kp.Ho);      // per-clip perturbations: the chunking of a batch-1 call
   { static const char* e = getenv("FLK_SG_NCHUNK"); if (e && atoi(e) > 0) kp.nchunk = atoi(e) < 16 ? atoi(e) : 16; }
   kp.rows_per_chunk = (kp.Ho + kp.nchunk - 1) / kp.nchunk;
   kp.nchunk = (kp.Ho + kp.rows_per_chunk - 1) / kp.rows_per_chunk;       // no empty chunks
@@ -482,23 +482,25 @@ extern "C" int flk_stem_delta_bias_weights_create(const float* w7, const float* 
 
 namespace {
 // table[ot][hc][wc][co] = sum_{kt: frame 2*ot+kt-2 inside the clip} sum_c a*p'[t,c] * S[kt][hc][wc][c][co]
+// (delta_per_clip: blockIdx.y = clip, one table per clip, (T/2)*16*64 floats apart)
 __global__ __launch_bounds__(64) void stem_delta_bias_kernel(const flk_apply_args a, const float* S, float* tab) {
-  const int co = threadIdx.x, cls = blockIdx.x & 15, ot = blockIdx.x >> 4;
+  const int co = threadIdx.x, cls = blockIdx.x & 15, ot = blockIdx.x >> 4, b = blockIdx.y;
   float acc = 0.f;
   for (int kt = 0; kt < 7; ++kt) {
     const int t = 2 * ot + kt - 2;
     if (t < 0 || t >= a.T) continue;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) acc += a.adv_flag * sg_pert(a, t, c) * S[(((size_t)kt * 16 + cls) * 3 + c) * SG_CO + co];
+    for (int c = 0; c < 3; ++c) acc += a.adv_flag * sg_pert(a, b, t, c) * S[(((size_t)kt * 16 + cls) * 3 + c) * SG_CO + co];
   }
-  tab[((size_t)ot * 16 + cls) * SG_CO + co] = acc;
+  tab[(((size_t)b * (a.T / 2) + ot) * 16 + cls) * SG_CO + co] = acc;
 }
 }  // namespace
 
 extern "C" int flk_stem_delta_bias(const flk_apply_args* a, const float* sums_dev, float* table_out, void* stream) {
   FLK_REQUIRE(a && a->delta && sums_dev && table_out, "flk_stem_delta_bias: null argument");
   FLK_REQUIRE(!a->delta_dense && a->T >= 2 && a->T % 2 == 0, "flk_stem_delta_bias: flicker perturbation [T,3], even T");
-  hipLaunchKernelGGL(stem_delta_bias_kernel, dim3((unsigned)(a->T / 2 * 16)), dim3(64), 0, (hipStream_t)stream, *a, sums_dev, table_out);
+  hipLaunchKernelGGL(stem_delta_bias_kernel, dim3((unsigned)(a->T / 2 * 16), (unsigned)(a->delta_per_clip ? a->B : 1)), dim3(64), 0, (hipStream_t)stream,
+                     *a, sums_dev, table_out);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

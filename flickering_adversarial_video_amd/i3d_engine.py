@@ -149,6 +149,7 @@ class FlickerI3D:
     def _apply_args(self, x, adv_flag, cyclic, cyclic_pert):
         sx = int(self._rng.integers(0, self.T)) if cyclic else 0          # one shift per step for the whole batch
         sp = int(self._rng.integers(0, self.T)) if cyclic_pert else 0     # (kinetics_i3d_utils.py:115,130)
+        self._last_x, self._last_shifts = x, (sx, sp)
         return ops.make_apply_args(x, self.eps_rgb, dialect="tf", dclip=0.0 if self.dense else 0.4, adv_flag=adv_flag,
                                    shift_x=sx, shift_p=sp, fold_t=ops.I3D_FOLD, center=self.exact_delta_forward)
 
@@ -244,6 +245,7 @@ class FlickerI3D:
                                  beta1=beta1, beta2=beta2, beta3=beta3, lr=lr, scalars=sc)
             res.update(reg_loss=sc[0], norm_reg=sc[1], diff_norm_reg=sc[2], laplacian_norm_reg=sc[3], thickness=sc[4],
                        roughness=sc[5], pert_max=sc[6], pert_min=sc[7], _reg_weight=beta0)
+        self.last_result = res
         return res
 
     def _step_dense(self, x, labels, lr, beta0, beta1, margin, targeted, use_logits, improve_loss, cyclic, update):
@@ -273,6 +275,38 @@ class FlickerI3D:
             res.update(reg_loss=beta1 * sc[0], L12=sc[0], thickness=sc[1], roughness=sc[2], pert_max=sc[3],
                        total_loss=res["adv_loss"] + beta0 * beta1 * sc[0], thickness_relative=sc[1] / 2 * 100, roughness_relative=sc[2] / 2 * 100)
         return res
+
+    # ---- the attribute surface of the reference object (kinetics_i3d_utils.py:100-200, read by the scripts through sess.run:
+    # i3d_adversarial_main_single_video_npy.py:61-77) -- values of the LAST step() / logits() call, as device tensors ----------------
+    def _last(self, key):
+        if getattr(self, "last_result", None) is None or key not in self.last_result:
+            raise AttributeError(f"{key}: no attack iteration has run yet (call step() first)")
+        return self.last_result[key]
+
+    softmax = property(lambda self: self._last("softmax"))
+    model_logits = property(lambda self: self._logits)
+    labels = property(lambda self: self._last("_labels"))
+    norm_reg = property(lambda self: self._last("norm_reg"))
+    diff_norm_reg = property(lambda self: self._last("diff_norm_reg"))
+    laplacian_norm_reg = property(lambda self: self._last("laplacian_norm_reg"))
+    thickness = property(lambda self: self._last("thickness"))
+    roughness = property(lambda self: self._last("roughness"))
+    to_min_prob = property(lambda self: self._last("prob_to_min"))
+    to_max_prob = property(lambda self: self._last("prob_to_max"))
+    rgb_input = property(lambda self: self._last_x)
+
+    @property
+    def adversarial_inputs_rgb(self):
+        """the perturbed clip ``clip(x + a * clip(eps_rgb, +-0.4), -1, 1)`` [B,T,224,224,3] fp32 (kinetics_i3d_utils.py:104-142) of the
+        last clip seen, under the CURRENT perturbation and the last call's rolls: the apply kernel's fp32 output, unfolded from its
+        space-to-depth layout (data movement only)"""
+        if getattr(self, "_last_x", None) is None:
+            raise AttributeError("adversarial_inputs_rgb: no clip has been seen yet")
+        sx, sp = self._last_shifts
+        a = ops.make_apply_args(self._last_x, self.eps_rgb, dialect="tf", dclip=0.0 if self.dense else 0.4, adv_flag=1.0, shift_x=sx, shift_p=sp, fold_t=2)
+        f = ops.perturb_apply_s2d(a, "f32")                                     # [B,T/2,H/2,W/2,32], channel (qt*4+qh*2+qw)*3+c
+        B, T2, H2, W2 = f.shape[:4]
+        return f[..., :24].reshape(B, T2, H2, W2, 2, 2, 2, 3).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, 2 * T2, 2 * H2, 2 * W2, 3).contiguous()
 
     def delta_gradient(self):
         """last all-reduced adversarial gradient d(adv)/d(delta), [T,3]"""

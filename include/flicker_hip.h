@@ -108,6 +108,7 @@ typedef struct {
    * epilogue -- bitwise reproducible).  NULL: never split.  Size: flk_conv_splitk_bytes (0 = this convolution is never split).
    * Two convolutions that may run concurrently need separate workspaces. */
   void* splitk_ws; int64_t splitk_ws_bytes;
+  int64_t pos_bias_bstride;  /* elements between the position-class tables of consecutive clips (per-clip perturbations); 0: one table */
 } flk_conv_args;
 int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream);
 int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_weights* w);
@@ -162,6 +163,9 @@ typedef struct {
                                 clip is inactive (exactly representable in bf16 for uint8 clips) -- the perturbation then reaches the stem
                                 through flk_conv_args.pos_bias in fp32 (flk_stem_delta_bias) instead of being rounded away with the
                                 bf16 input: |delta| < 2^-9 is below half a bf16 ulp of a pixel value near +-1 */
+  int delta_per_clip;        /* 1 (flicker delta only): delta is [B,T,3] and clip b is perturbed by ITS OWN delta[b] -- B independent
+                                single-video attacks (i3d_adversarial_main_single_video_npy.py:103-337, model.py:791-982) advancing in
+                                one batch; the delta-gradient then comes back per clip, [B,T,3].  0: one delta [T,3] shared by the batch */
 } flk_apply_args;
 int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dtype, void* stream);
 
@@ -220,6 +224,13 @@ typedef struct {
 } flk_adam_args;
 int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, float* delta, float* m, float* v,
                          float* scalars, void* stream);
+/* The same update for nclip INDEPENDENT perturbations (delta, m, v, g_adv: [nclip,T,3]; scalars: [nclip,8]) -- single-video attacks
+ * batched (i3d_adversarial_main_single_video_npy.py:103-337; model.py:791-982 fit_many_videos): clip b takes Adam step
+ * steps_dev[b] + 1 (a->step is ignored) and the counter is advanced on the device; clips with active_dev[b] == 0 (already
+ * adversarial: retired) keep delta / m / v / counter, their scalars are still written.  active_dev may be NULL (all active).
+ * Per clip the arithmetic is exactly flk_perturb_reg_adam's. */
+int flk_perturb_reg_adam_batched(const flk_adam_args* a, int nclip, const float* g_adv, float* delta, float* m, float* v,
+                                 int* steps_dev, const int* active_dev, float* scalars, void* stream);
 
 /* Dense-delta ("sparse adversarial perturbations" baseline, kinetics_i3d_L12, kinetics_i3d_utils.py:308-521): delta is
  * [T,H,W,3] (init 1e-8, no +-0.4 clip), regulariser L12 = sum_t sqrt(mean_{hwc} delta_t^2) + 1e-12 (:409; torch dialect

@@ -110,7 +110,7 @@ def main():
             print("  clean clip is misclassified: skipped", flush=True)
             continue
         res.update(correct_cls=cls, correct_cls_id=label_id, rgb_sample=clip)
-        res["adv_video"] = np.clip(clip + np.clip(res["perturbation"][-1], -0.4, 0.4)[None], -1, 1)
+        res["adv_video"] = eng.adversarial_inputs_rgb.cpu().numpy()        # sess.run(adversarial_inputs_rgb), :61,325 -- the apply kernel's output
         out = os.path.join(c.PKL_RESULT_PATH, cfgmod.result_filename(cls, c.BETA_1, res["fatness"], res["smoothness"]))
         with open(out, "wb") as f:
             pickle.dump(res, f)

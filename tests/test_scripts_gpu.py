@@ -47,6 +47,10 @@ def test_single_video_script_end_to_end(tmp_path):
     assert res["rgb_sample"].shape == (1, T, 224, 224, 3) and res["adv_video"].shape == (1, T, 224, 224, 3)
     assert res["correct_cls_id"] == cls_id and res["softmax_init"].shape == (400,)
     assert res["total_loss_l"][0] >= res["adv_loss_l"][0] and np.isfinite(res["total_loss_l"]).all()
+    # adv_video = the engine's adversarial_inputs_rgb attribute (kinetics_i3d_utils.py:104-142: the apply kernel's own output) under the
+    # final perturbation -- against the formula in numpy
+    want = np.clip(clip[:, -T:] + np.clip(res["perturbation"][-1], -0.4, 0.4)[None], -1, 1)
+    np.testing.assert_allclose(res["adv_video"], want, rtol=0, atol=1e-7)
 
 
 def test_universal_script_on_tfrecords(tmp_path):

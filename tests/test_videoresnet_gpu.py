@@ -151,9 +151,11 @@ def test_videoresnet_attack_trajectory_well_conditioned(dtype):
     assert int(label) == int(label32) == 233
     for it in range(steps):
         assert rel_err(t32[it]["delta"], t64[it]["delta"]) < 1e-4, "fixture is not well-conditioned"
-    # bf16 (the dtype config 3 is benchmarked in): the same trajectory at stated bf16 tolerances -- learned delta 2e-2, logits 5e-2,
-    # adversarial loss 5e-2 (the I3D bf16 bars, tests/test_i3d_gpu.py::test_bf16_trajectory_well_conditioned)
-    TOL_D, TOL_L, TOL_A = (1e-3, 1e-3, 1e-3) if dtype == "f32" else (2e-2, 5e-2, 5e-2)
+    # bf16 (the dtype config 3 is benchmarked in): the same trajectory at stated bf16 tolerances
+    # measured on MI355X (r2plus1d_18): delta 2.5e-2, adversarial loss 1.2e-3; logits 9e-2 already at delta = 0 (the fixture's FC
+    # has random signs: the logits are cancelling sums of the positive features, which amplifies the bf16 rounding of 40 layers --
+    # the loss, a difference of two logits of the favoured classes, is 100x better conditioned)
+    TOL_D, TOL_L, TOL_A = (1e-3, 1e-3, 1e-3) if dtype == "f32" else (4e-2, 1.5e-1, 5e-3)
     eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype=dtype, l_inf_pert_norm=0.2)
     eng.pert_model.init_perturbation(np.zeros((3, T, 1, 1), np.float32))      # (the default start is U(-1,1)*1e-6, model.py:121-126)
     crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)
@@ -191,7 +193,7 @@ def test_videoresnet_bf16_small_delta_reaches_the_logits():
     for dtype in ("f32", "bf16"):
         eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype=dtype, l_inf_pert_norm=0.2)
         eng.pert_model.init_perturbation(np.zeros((3, T, 1, 1), np.float32))
-        base = eng.logits(x_cl.cuda()).clone()
+        base = eng.logits(x_cl.cuda(), adversarial=True).clone()          # delta = 0, same clamp of the clip to [min_v, max_v]
         change[dtype] = []
         for a in amps:
             eng.pert_model.init_perturbation(a * sign)

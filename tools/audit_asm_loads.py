@@ -137,7 +137,7 @@ def main():
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_igemm.hip")
     text = compile_asm(src)
     bad = total = 0
-    for m in re.finditer(r"^(\S*conv_igemm_kernel\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(\S*(?:conv_igemm_kernel|pw_gemm_kernel)\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
         nloads, viol = audit_kernel(name, body)
         if nloads:
