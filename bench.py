@@ -207,6 +207,18 @@ def other_configs(device, steps=10, warmup=3):
     out["config2_i3d_single_video_bs1_64x224x224_bf16"] = {"ms_per_iter": sec * 1e3, "iters_per_s": 1 / sec, "conv_tflops": conv_gflop_per_clip(64) / sec / 1e3,
                                                           "conv_frac_of_mfma_peak": conv_gflop_per_clip(64) / sec / 1e3 / PEAK_TFLOPS["bf16"]}
     del eng
+    # config 2 as the reference's users run it -- MANY videos, one after another (i3d_adversarial_main_single_video_npy.py:103-337) -- with 8
+    # independent single-video attacks advancing in one batch (per-clip perturbations / Adam states; each video's trajectory is the one
+    # it has alone): clip-iterations per second against the one-by-one loop above
+    engb = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=8, frames=64, dtype="bf16", device=device, per_clip_delta=True)
+    xb = torch.from_numpy(i3d_spec.synthetic_clip_u8(8, 64, seed=1234)).cuda()
+    lb = engb.logits(xb, adv_flag=0.0).argmax(-1).clone()
+    secb = timed(lambda: engb.step(xb, lb))
+    out["config2_batched_8_independent_single_video_attacks"] = {"ms_per_iter": secb * 1e3, "clip_iters_per_s": 8 / secb,
+                                                                  "speedup_over_one_by_one": (8 / secb) * sec,
+                                                                  "conv_tflops": 8 * conv_gflop_per_clip(64) / secb / 1e3}
+    del engb, xb
+    torch.cuda.empty_cache()
     W = vs.synthetic_weights("r2plus1d_18", 42)
     eng = FlickerVideoResNet("r2plus1d_18", W, batch_size=1, sample_length=16, image_size=112, dtype="bf16", device=device)
     xv = torch.from_numpy(vs.synthetic_clip(1, 16, seed=1234)).cuda()

@@ -81,23 +81,32 @@ class FlickerI3D:
 
     def __init__(self, weights, batch_size=1, frames=SAMPLE_VIDEO_FRAMES, dtype="bf16", device=0, dense_delta=False,
                  cyclic_flag_default_c=0.0, cyclic_pert_flag_default_c=0.0, default_adv_flag_c=1.0, process_group=None,
-                 seed=0, kinetics_classes=None):
+                 seed=0, kinetics_classes=None, per_clip_delta=False):
         if not torch.cuda.is_available():
             raise RuntimeError("FlickerI3D needs an MI355X (HIP) device; there is no CPU fallback")
         torch.cuda.set_device(device)
         self.B, self.T, self.H, self.W = batch_size, frames, IMAGE_SIZE, IMAGE_SIZE
         self.dtype = dtype
         self.dense = dense_delta
+        # per_clip_delta: B INDEPENDENT single-video attacks in one batch (the reference runs them one after another,
+        # i3d_adversarial_main_single_video_npy.py:103-337): eps_rgb, the Adam state, the step counter and the "still attacking" flag
+        # are per clip; clip b follows exactly the trajectory it would follow alone (bit for bit in fp32).  Replicas only: no collective.
+        self.per_clip = bool(per_clip_delta)
+        if self.per_clip and (dense_delta or parallel.world_size(process_group) > 1 or cyclic_flag_default_c or cyclic_pert_flag_default_c):
+            raise ValueError("per_clip_delta: flicker perturbation, one rank, no cyclic rolls")
         self.cyclic_flag, self.cyclic_pert_flag, self.adv_flag = cyclic_flag_default_c, cyclic_pert_flag_default_c, default_adv_flag_c
         self.pg = process_group
         self.world = parallel.world_size(process_group)
         self.net = ops.Net(FLK_NET_I3D, dtype, self.B, self.T, self.H, self.W, weights, device)
         dev = torch.device("cuda", device)
-        dshape = (self.T, self.H, self.W, 3) if dense_delta else (self.T, 3)
+        dshape = (self.T, self.H, self.W, 3) if dense_delta else (self.B, self.T, 3) if self.per_clip else (self.T, 3)
         # eps_rgb: zeros [T,1,1,3] (kinetics_i3d_utils.py:100); dense L12 variant: 1e-8 (:333)
         self.eps_rgb = torch.full(dshape, 1e-8 if dense_delta else 0.0, dtype=torch.float32, device=dev)
         self.adam_m, self.adam_v = torch.zeros_like(self.eps_rgb), torch.zeros_like(self.eps_rgb)
         self.adam_t = 0
+        if self.per_clip:
+            self.adam_steps = torch.zeros(self.B, dtype=torch.int32, device=dev)      # Adam step counters, advanced by the kernel
+            self.active = torch.ones(self.B, dtype=torch.int32, device=dev)           # 0: this clip's attack has ended (frozen)
         self._xs2d = torch.empty((self.B, self.T // 2, self.H // 2, self.W // 2, 32), dtype=self.net_torch_dtype, device=dev)
         self._gx = torch.empty_like(self._xs2d)
         self._logits = torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev)
@@ -115,7 +124,9 @@ class FlickerI3D:
         self._slots = [dict(payload=torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev),
                             sm=torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev),
                             pc=torch.empty((self.B, 4), dtype=torch.float32, device=dev),
-                            scalars=torch.zeros(8, dtype=torch.float32, device=dev)) for _ in range(RESULT_SLOTS)]
+                            scalars=torch.zeros((self.B, 8) if self.per_clip else 8, dtype=torch.float32, device=dev),
+                            gclip=torch.zeros((self.B, self.T, 3), dtype=torch.float32, device=dev) if self.per_clip else None)
+                       for _ in range(RESULT_SLOTS)]
         self._dl = torch.empty((self.B, NUM_CLASSES), dtype=torch.float32, device=dev)
         self._it = 0
         self._rng = np.random.default_rng(seed)
@@ -131,8 +142,25 @@ class FlickerI3D:
         return torch.bfloat16 if self.dtype in ("bf16", torch.bfloat16) else torch.float32
 
     # ---- state -------------------------------------------------------------------------------------
+    def reset_clip(self, b, delta=None):
+        """per-clip mode: slot b starts a NEW video -- its perturbation, Adam moments and step counter are re-initialised
+        (i3d_adversarial_main_single_video_npy.py:205-206) and it is active again; the other clips are untouched"""
+        if not self.per_clip:
+            raise ValueError("reset_clip: the engine was not built with per_clip_delta=True")
+        if delta is None:
+            self.eps_rgb[b].zero_()
+        else:
+            self.eps_rgb[b].copy_(torch.as_tensor(delta, dtype=torch.float32).reshape(self.T, 3))
+        self.adam_m[b].zero_()
+        self.adam_v[b].zero_()
+        self.adam_steps[b] = 0
+        self.active[b] = 1
+
     def reset_perturbation(self, delta=None):
         """sess.run(eps_rgb.initializer) + Adam slot re-init (i3d_adversarial_main_single_video_npy.py:205-206)"""
+        if self.per_clip:
+            self.adam_steps.zero_()
+            self.active.fill_(1)
         if delta is None:
             self.eps_rgb.fill_(1e-8 if self.dense else 0.0)
         else:
@@ -143,7 +171,9 @@ class FlickerI3D:
 
     @property
     def perturbation(self):
-        """[T,1,1,3] like the reference variable"""
+        """[T,1,1,3] like the reference variable ([B,T,1,1,3] in per-clip mode: one such variable per clip)"""
+        if self.per_clip:
+            return self.eps_rgb.view(self.B, self.T, 1, 1, 3)
         return self.eps_rgb if self.dense else self.eps_rgb.view(self.T, 1, 1, 3)
 
     def _apply_args(self, x, adv_flag, cyclic, cyclic_pert):
@@ -214,6 +244,8 @@ class FlickerI3D:
         PRE-update values, as the reference fetches them together with train_op."""
         if self.dense:
             return self._step_dense(x, labels, lr, beta0, beta1, margin, targeted, use_logits, improve_loss, cyclic, update)
+        if self.per_clip:
+            return self._step_per_clip(x, labels, lr, beta0, beta1, beta2, beta3, margin, targeted, use_logits, improve_loss, update)
         x = self._check_x(x)
         cyclic = self.cyclic_flag if cyclic is None else cyclic
         cyclic_pert = self.cyclic_pert_flag if cyclic_pert is None else cyclic_pert
@@ -245,6 +277,40 @@ class FlickerI3D:
                                  beta1=beta1, beta2=beta2, beta3=beta3, lr=lr, scalars=sc)
             res.update(reg_loss=sc[0], norm_reg=sc[1], diff_norm_reg=sc[2], laplacian_norm_reg=sc[3], thickness=sc[4],
                        roughness=sc[5], pert_max=sc[6], pert_min=sc[7], _reg_weight=beta0)
+        self.last_result = res
+        return res
+
+    def _step_per_clip(self, x, labels, lr, beta0, beta1, beta2, beta3, margin, targeted, use_logits, improve_loss, update):
+        """one iteration of B independent single-video attacks: every quantity of step() per clip ([B] / [B,...] tensors).  The loss of
+        clip b is its own adversarial term + the regulariser of ITS perturbation (a batch of one in the reference: the CE variants'
+        mean is over that one clip); d(loss_b)/d(delta_b) is the per-clip slice of the delta-gradient reduction.  Clips whose
+        ``active`` flag is 0 still run through the network (the batch is dense) but are not updated."""
+        x = self._check_x(x)
+        a = self._apply_args(x, 1.0, 0, 0)
+        slot = self._slots[self._it % RESULT_SLOTS]
+        self._it += 1
+        sm, pc, g = slot["sm"], slot["pc"], slot["gclip"]
+        self._forward(a)
+        ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
+                             targeted=targeted, margin=margin, mean_scale=1.0, out=(sm, self._dl, pc))
+        if self.fused_delta_grad:
+            self.net.backward_delta(self._dl, a, g, self._scratch)
+        else:
+            self.net.backward(self._dl, self._gx)
+            ops.perturb_grad_reduce(a, self._gx, g, self._scratch)
+        self._gclip = g
+        p_lab, p_non = pc[:, 1], pc[:, 2]
+        res = StepResult(adv_loss=pc[:, 0], prob_to_min=p_non if targeted else p_lab, prob_to_max=p_lab if targeted else p_non,
+                         softmax=sm, label_prob=pc[:, 1], _argmax_f=pc[:, 3], _labels=labels, _targeted=bool(targeted))
+        am = pc[:, 3].to(torch.int64)
+        res["argmax"] = am
+        res["is_adversarial"] = (am == labels) if targeted else (am != labels)          # per clip
+        if update:
+            sc = slot["scalars"]
+            ops.perturb_reg_adam_batched(g, self.eps_rgb, self.adam_m, self.adam_v, self.adam_steps, self.active, dialect="tf", beta0=beta0,
+                                         beta1=beta1, beta2=beta2, beta3=beta3, lr=lr, scalars=sc)
+            res.update(reg_loss=sc[:, 0], norm_reg=sc[:, 1], diff_norm_reg=sc[:, 2], laplacian_norm_reg=sc[:, 3], thickness=sc[:, 4],
+                       roughness=sc[:, 5], pert_max=sc[:, 6], pert_min=sc[:, 7], _reg_weight=beta0)
         self.last_result = res
         return res
 
@@ -309,7 +375,9 @@ class FlickerI3D:
         return f[..., :24].reshape(B, T2, H2, W2, 2, 2, 2, 3).permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(B, 2 * T2, 2 * H2, 2 * W2, 3).contiguous()
 
     def delta_gradient(self):
-        """last all-reduced adversarial gradient d(adv)/d(delta), [T,3]"""
+        """last all-reduced adversarial gradient d(adv)/d(delta), [T,3] ([B,T,3] in per-clip mode)"""
+        if self.per_clip:
+            return self._gclip
         return self._red[:self.T * 3].view(self.T, 3)
 
     # ---- fooling rate --------------------------------------------------------------------------------

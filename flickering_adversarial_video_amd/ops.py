@@ -150,7 +150,8 @@ I3D_FOLD = 3   # space-to-depth layout the I3D plan (flk_net, FLK_NET_I3D) expec
 
 def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=0, shift_p=0, inv_std=(1.0, 1.0, 1.0),
                     lo=-1.0, hi=1.0, fold_t=2, center=False):
-    """x: uint8 or fp32 [B,T,H,W,3] on the GPU; delta fp32 [T,3] or [T,H,W,3]."""
+    """x: uint8 or fp32 [B,T,H,W,3] on the GPU; delta fp32 [T,3] (flicker, shared by the batch), [B,T,3] (one flicker perturbation PER
+    CLIP: independent single-video attacks advancing in one batch) or [T,H,W,3] (dense)."""
     B, T, H, W, c3 = x.shape
     assert c3 == 3 and x.is_contiguous() and delta.is_contiguous() and delta.dtype == torch.float32
     a = ApplyArgs()
@@ -161,7 +162,9 @@ def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=
     a.x_scale, a.x_bias = (1.0 / 128.0, -1.0) if dialect == "tf" else (1.0, 0.0)
     a.delta = ptr(delta)
     a.delta_dense = int(delta.dim() == 4)
-    assert tuple(delta.shape) in ((T, 3), (T, H, W, 3)), delta.shape
+    a.delta_per_clip = int(delta.dim() == 3)
+    assert tuple(delta.shape) in ((T, 3), (B, T, 3), (T, H, W, 3)), delta.shape
+    assert not (a.delta_per_clip and (shift_x or shift_p)), "per-clip perturbations: cyclic rolls are drawn per run in the reference; not batched"
     a.dclip = float(dclip)
     a.inv_std = (C.c_float * 3)(*inv_std)
     a.lo, a.hi, a.adv_flag = float(lo), float(hi), float(adv_flag)
@@ -183,7 +186,7 @@ def perturb_apply_s2d(args, dtype, out=None):
 
 def perturb_grad_reduce(args, gx_s2d, gdelta=None, scratch=None):
     if gdelta is None:
-        shape = (args.T, args.H, args.W, 3) if args.delta_dense else (args.T, 3)
+        shape = (args.T, args.H, args.W, 3) if args.delta_dense else (args.B, args.T, 3) if args.delta_per_clip else (args.T, 3)
         gdelta = torch.empty(shape, dtype=torch.float32, device="cuda")
     if scratch is None and not args.delta_dense:
         n = load().flk_perturb_grad_scratch_bytes(args.B, args.T, args.H, args.W)
@@ -235,6 +238,27 @@ def perturb_reg_adam(g_adv, delta, m, v, step, *, dialect="tf", beta0=1.0, beta1
     if scalars is None:
         scalars = torch.empty(8, dtype=torch.float32, device="cuda")
     check(load().flk_perturb_reg_adam(C.byref(a), ptr(g_adv), ptr(delta), ptr(m), ptr(v), ptr(scalars), stream_ptr()))
+    return scalars
+
+
+def perturb_reg_adam_batched(g_adv, delta, m, v, steps, active=None, *, dialect="tf", beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5,
+                             dyn_max_norm=0.0, g_scale=1.0, lr=1e-3, adam=(0.9, 0.999, 1e-8), scalars=None):
+    """B independent perturbations [B,T,3], each with its own Adam state and DEVICE step counter ``steps`` (int32 [B], advanced by the
+    kernel); clips with ``active[b] == 0`` are frozen.  Returns scalars [B,8] of the pre-update perturbations."""
+    B, T, _ = delta.shape
+    assert steps.dtype == torch.int32 and steps.shape == (B,) and steps.is_cuda and (active is None or (active.dtype == torch.int32 and active.shape == (B,)))
+    for t in (g_adv, delta, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == B * T * 3
+    a = AdamArgs()
+    a.T = T
+    a.torch_dialect = int(dialect == "torch")
+    a.beta0, a.beta1, a.beta2, a.beta3 = beta0, beta1, beta2, beta3
+    a.dyn_max_norm, a.g_scale, a.lr = dyn_max_norm, g_scale, lr
+    a.adam_b1, a.adam_b2, a.adam_eps = adam
+    a.step = 0
+    if scalars is None:
+        scalars = torch.empty((B, 8), dtype=torch.float32, device="cuda")
+    check(load().flk_perturb_reg_adam_batched(C.byref(a), B, ptr(g_adv), ptr(delta), ptr(m), ptr(v), ptr(steps), ptr(active), ptr(scalars), stream_ptr()))
     return scalars
 
 
@@ -372,7 +396,7 @@ class Net:
 
     def backward_delta(self, dlogits, apply_args, gdelta, scratch):
         """backward straight to the flickering perturbation [T,3]: no per-pixel input gradient is materialised"""
-        assert gdelta.dtype == torch.float32 and gdelta.is_contiguous() and gdelta.numel() == 3 * self.T
+        assert gdelta.dtype == torch.float32 and gdelta.is_contiguous() and gdelta.numel() == 3 * self.T * (self.B if apply_args.delta_per_clip else 1)
         assert scratch.numel() * 4 >= load().flk_stem_delta_grad_scratch_bytes(self.B, self.T, self.H)
         check(load().flk_net_backward_delta(self.handle, ptr(dlogits), C.byref(apply_args), ptr(gdelta), ptr(scratch), stream_ptr()))
         return gdelta

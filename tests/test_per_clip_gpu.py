@@ -1,0 +1,204 @@
+"""Independent single-video attacks batched (per-clip perturbations): B clips, B perturbations, B Adam states, B step counters and
+B "still attacking" flags in one plan (the reference runs its single-video attacks one after another:
+i3d_adversarial_main_single_video_npy.py:103-337, model.py:791-982 fit_many_videos).
+
+The parity statement is against the ONE-BY-ONE path, which the other GPU tests pin to the oracle: clip b of a per-clip batch must
+follow exactly the trajectory it follows alone.  Kernel level (apply, delta-gradient reduction, regulariser + Adam) and engine
+level in fp32 (the parity mode) this is asserted BITWISE; in bf16 the batch-1 and batch-B plans choose different launch layouts
+(split-K), so agreement is asserted at the bf16 tolerances of the other tests."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = 16
+HP = dict(lr=1e-3, beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5, margin=0.05)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import ops as o
+    return o
+
+
+@pytest.mark.parametrize("fold_t", [1, 2, 3])
+@pytest.mark.parametrize("u8", [True, False], ids=["u8", "f32in"])
+def test_per_clip_apply_and_gradient_equal_the_one_clip_kernels(ops, fold_t, u8):
+    """flk_perturb_apply_s2d / flk_perturb_grad_reduce with delta [B,T,3]: slice b of the outputs is BITWISE what the shared-delta call
+    on clip b alone with delta[b] gives (fp32 and bf16 outputs; TF and centred forms)"""
+    B, Tn, H, W = 3, 8, 12, 16
+    rng = np.random.default_rng(11)
+    xu = torch.from_numpy(rng.integers(0, 256, (B, Tn, H, W, 3), dtype=np.uint8)).cuda()
+    x = xu if u8 else (xu.float() / 128 - 1).contiguous()
+    d = torch.from_numpy(rng.uniform(-0.6, 0.6, (B, Tn, 3)).astype(np.float32)).cuda()      # some entries beyond the +-0.4 clip
+    ft = 1 if fold_t == 1 else 2
+    gx = torch.from_numpy(rng.standard_normal((B, Tn // ft, H // 2, W // 2, 16 * ft)).astype(np.float32)).cuda()
+    for center in ((False, True) if fold_t == 3 else (False,)):
+        a = ops.make_apply_args(x, d, fold_t=fold_t, center=center)
+        assert a.delta_per_clip == 1
+        for dt in (torch.float32, torch.bfloat16):
+            out = ops.perturb_apply_s2d(a, dt)
+            for b in range(B):
+                a1 = ops.make_apply_args(x[b:b + 1].contiguous(), d[b].contiguous(), fold_t=fold_t, center=center)
+                assert torch.equal(out[b:b + 1], ops.perturb_apply_s2d(a1, dt)), (fold_t, center, dt, b)
+        if center:
+            continue
+        g = ops.perturb_grad_reduce(a, gx)
+        assert g.shape == (B, Tn, 3)
+        for b in range(B):
+            a1 = ops.make_apply_args(x[b:b + 1].contiguous(), d[b].contiguous(), fold_t=fold_t)
+            assert torch.equal(g[b], ops.perturb_grad_reduce(a1, gx[b:b + 1].contiguous())), (fold_t, b)
+    # and the slices really differ from one another (the fixture exercises per-clip indexing)
+    assert not torch.equal(g[0], g[1])
+
+
+@pytest.mark.parametrize("dialect", ["tf", "torch"])
+def test_batched_reg_adam_equals_the_one_clip_kernel(ops, dialect):
+    """flk_perturb_reg_adam_batched: per clip the arithmetic of flk_perturb_reg_adam (bitwise), with the step counter on the device:
+    clips at DIFFERENT Adam steps in one launch, a frozen clip (active = 0) keeps delta / m / v / counter and still reports scalars"""
+    B, Tn = 4, 16
+    rng = np.random.default_rng(2)
+    mk = lambda s: torch.from_numpy((rng.standard_normal((B, Tn, 3)) * s).astype(np.float32)).cuda()
+    g, d, m, v = mk(1.0), mk(0.1), mk(0.01), mk(0.001).abs()
+    steps = torch.tensor([0, 4, 9, 2], dtype=torch.int32, device="cuda")
+    active = torch.tensor([1, 1, 0, 1], dtype=torch.int32, device="cuda")
+    kw = dict(dialect=dialect, beta0=0.8, beta1=0.4, beta2=0.6, beta3=0.6, lr=2e-3, dyn_max_norm=0.15 if dialect == "torch" else 0.0)
+    ref = []
+    for b in range(B):
+        db, mb, vb = d[b].clone(), m[b].clone(), v[b].clone()
+        sc = ops.perturb_reg_adam(g[b].contiguous(), db, mb, vb, int(steps[b]) + 1, **kw).clone()
+        ref.append((db, mb, vb, sc))
+    d2, m2, v2, st2 = d.clone(), m.clone(), v.clone(), steps.clone()
+    sc = ops.perturb_reg_adam_batched(g, d2, m2, v2, st2, active, **kw)
+    for b in range(B):
+        assert torch.equal(sc[b], ref[b][3]), b
+        if int(active[b]):
+            assert torch.equal(d2[b], ref[b][0]) and torch.equal(m2[b], ref[b][1]) and torch.equal(v2[b], ref[b][2]), b
+        else:
+            assert torch.equal(d2[b], d[b]) and torch.equal(m2[b], m[b]) and torch.equal(v2[b], v[b]), b
+    assert st2.tolist() == [1, 5, 9, 3]
+
+
+def _engines(dtype, B):
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    W = i3d_spec.synthetic_i3d_weights(42)
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(B, T, seed=21)).cuda()
+    return W, xu, FlickerI3D(W, batch_size=B, frames=T, dtype=dtype, per_clip_delta=True), FlickerI3D(W, batch_size=1, frames=T, dtype=dtype)
+
+
+def test_per_clip_engine_fp32_trajectories_are_bitwise_those_of_single_runs():
+    """3 clips attacked together (per-clip mode) for 5 iterations vs each clip attacked alone: logits, per-clip adversarial loss,
+    delta-gradient, perturbation, Adam moments and regulariser scalars are bitwise equal at every iteration (fp32).  Clip 1 is retired
+    after iteration 2 (active = 0): it stops moving while the others go on; slot 1 is then given a fresh start (reset_clip) and
+    its new trajectory equals a fresh single run."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    B = 3
+    W, xu, engB, eng1 = _engines("f32", B)
+    labels = engB.logits(xu, adv_flag=0.0).argmax(-1).clone()
+    singles = []
+    for b in range(B):
+        eng1.reset_perturbation()
+        tr = []
+        for it in range(5):
+            r = eng1.step(xu[b:b + 1].contiguous(), labels[b:b + 1].contiguous(), **HP)
+            tr.append(dict(logits=eng1._logits.clone(), adv=r["adv_loss"].clone(), g=eng1.delta_gradient().clone(), d=eng1.eps_rgb.clone(),
+                           m=eng1.adam_m.clone(), v=eng1.adam_v.clone(), reg=r["reg_loss"].clone(), thick=r["thickness"].clone()))
+        singles.append(tr)
+    frozen = None
+    for it in range(5):
+        if it == 2:
+            engB.active[1] = 0
+            frozen = engB.eps_rgb[1].clone()
+        r = engB.step(xu, labels, **HP)
+        for b in range(B):
+            s = singles[b][it]
+            if b == 1 and it >= 2:
+                assert torch.equal(engB.eps_rgb[1], frozen) and int(engB.adam_steps[1]) == 2
+                continue
+            assert torch.equal(engB._logits[b], s["logits"][0]), (it, b)
+            assert torch.equal(r["adv_loss"][b], s["adv"].reshape(())), (it, b)
+            assert torch.equal(engB.delta_gradient()[b], s["g"]), (it, b)
+            assert torch.equal(engB.eps_rgb[b], s["d"]) and torch.equal(engB.adam_m[b], s["m"]) and torch.equal(engB.adam_v[b], s["v"]), (it, b)
+            assert torch.equal(r["reg_loss"][b], s["reg"].reshape(())) and torch.equal(r["thickness"][b], s["thick"].reshape(())), (it, b)
+            assert int(engB.adam_steps[b]) == it + 1
+        assert r["is_adversarial"].shape == (B,)
+    engB.reset_clip(1)
+    assert int(engB.active[1]) == 1 and int(engB.adam_steps[1]) == 0 and float(engB.eps_rgb[1].abs().max()) == 0
+    for it in range(2):
+        engB.step(xu, labels, **HP)
+        assert torch.equal(engB.eps_rgb[1], singles[1][it]["d"]), it
+
+
+def test_per_clip_engine_bf16_tracks_single_runs():
+    """the timed dtype: batch-1 and batch-4 plans differ in launch layout (split-K), so per-clip agreement is at bf16 accuracy: logits
+    2e-2 of the largest logit, adversarial loss 2e-2, delta-gradient cosine > 0.98 at the first iteration (same delta = 0 start)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    B = 4
+    W, xu, engB, eng1 = _engines("bf16", B)
+    assert engB.fused_delta_grad and engB.exact_delta_forward
+    labels = engB.logits(xu, adv_flag=0.0).argmax(-1).clone()
+    # a non-trivial, DIFFERENT perturbation per clip: exercises the per-clip position-bias tables and clip masks of the fused stem kernels
+    d0 = torch.from_numpy(np.random.default_rng(4).uniform(-0.05, 0.05, (B, T, 3)).astype(np.float32)).cuda()
+    engB.reset_perturbation(d0)
+    r = engB.step(xu, labels, update=False, **HP)
+    for b in range(B):
+        eng1.reset_perturbation(d0[b])
+        r1 = eng1.step(xu[b:b + 1].contiguous(), labels[b:b + 1].contiguous(), update=False, **HP)
+        e_l = float((engB._logits[b] - eng1._logits[0]).abs().max() / eng1._logits[0].abs().max())
+        e_a = abs(float(r["adv_loss"][b]) - float(r1["adv_loss"])) / max(abs(float(r1["adv_loss"])), 1e-6)
+        cos = float(torch.nn.functional.cosine_similarity(engB.delta_gradient()[b].flatten(), eng1.delta_gradient().flatten(), 0))
+        print(f"clip {b}: logits {e_l:.2e}, adversarial loss {e_a:.2e}, gradient cosine {cos:.5f}")
+        assert e_l < 2e-2 and e_a < 2e-2 and cos > 0.98
+
+
+def test_batched_script_equals_the_one_by_one_script(tmp_path):
+    """scripts/i3d_adversarial_main_single_video_npy.py --batch 2 over four .npy clips (one of them mislabelled -> skipped) against the
+    one-by-one loop (--batch 1), fp32: the same result files with bitwise-equal perturbation trajectories and step counts -- slots are
+    refilled as videos finish, so videos 3 and 4 start while others are mid-attack"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    u8 = i3d_spec.synthetic_clip_u8(4, T, seed=123)
+    clips = u8.astype(np.float32) / 128 - 1
+    eng = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=4, frames=T, dtype="f32")
+    ids = eng(torch.from_numpy(clips).cuda(), adv_flag=0).argmax(-1).tolist()
+    del eng
+    (tmp_path / "npy").mkdir()
+    (tmp_path / "labels.txt").write_text("\n".join(f"class {i}" for i in range(400)))
+    for i in range(4):
+        lab = ids[i] if i != 1 else (ids[i] + 1) % 400                  # video 1: wrong label -> skipped as clean-misclassified
+        np.save(tmp_path / "npy" / f"rgb_{i:04d}@class_{lab}.npy", clips[i:i + 1])
+    cfg = open(os.path.join(ROOT, "run_config.yml")).read()
+    cfg = cfg.replace("'data/label_map.txt'", f"'{tmp_path}/labels.txt'").replace("NPY_PATH: 'data/videos_for_tests/npy/'", f"NPY_PATH: '{tmp_path}/npy/'", 1)
+    outs = {}
+    for batch in (1, 2):
+        c2 = cfg.replace("PKL_RESULT_PATH: 'result/videos_for_tests/npy/'", f"PKL_RESULT_PATH: '{tmp_path}/out{batch}/'")
+        (tmp_path / f"cfg{batch}.yml").write_text(c2)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "i3d_adversarial_main_single_video_npy.py"), str(tmp_path / f"cfg{batch}.yml"),
+                            "--max-steps", "3", "--frames", str(T), "--dtype", "f32", "--batch", str(batch)], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        assert "skipped" in r.stdout
+        outs[batch] = {f: pickle.load(open(tmp_path / f"out{batch}" / f, "rb")) for f in sorted(os.listdir(tmp_path / f"out{batch}"))}
+    assert len(outs[1]) == 3 and sorted(outs[1]) == sorted(outs[2])
+    for f, a in outs[1].items():
+        b = outs[2][f]
+        assert a["total_steps"] == b["total_steps"] and a["correct_cls_id"] == b["correct_cls_id"]
+        assert len(a["perturbation"]) == len(b["perturbation"])
+        for pa, pb in zip(a["perturbation"], b["perturbation"]):
+            assert np.array_equal(pa.reshape(-1), pb.reshape(-1))
+        assert np.array_equal(np.array(a["adv_loss_l"], np.float32), np.array(b["adv_loss_l"], np.float32))
+        assert np.array_equal(a["adv_video"], b["adv_video"]) and len(a["softmax"]) == len(b["softmax"])
+        assert all(np.array_equal(np.asarray(u).reshape(-1), np.asarray(v).reshape(-1)) for u, v in zip(a["softmax"], b["softmax"]))
+        assert a["fatness"] == b["fatness"] and a["smoothness"] == b["smoothness"]
