@@ -228,6 +228,15 @@ def other_configs(device, steps=10, warmup=3):
     out["config3_r2plus1d_18_single_video_bs1_16x112x112_bf16"] = {"ms_per_iter": sec * 1e3, "iters_per_s": 1 / sec, "conv_tflops": VRN_GFLOP["r2plus1d_18"] / sec / 1e3,
                                                                   "conv_frac_of_mfma_peak": VRN_GFLOP["r2plus1d_18"] / sec / 1e3 / PEAK_TFLOPS["bf16"]}
     del eng
+    # config 3 with 8 independent single-video attacks per batch (fit_many_videos(batch): per-clip perturbation / clamp bound / Adam state)
+    engb = FlickerVideoResNet("r2plus1d_18", W, batch_size=8, sample_length=16, image_size=112, dtype="bf16", device=device, per_clip=True)
+    xb = torch.from_numpy(vs.synthetic_clip(8, 16, seed=1234)).cuda()
+    lb = engb.logits(xb).argmax(-1).clone()
+    secb = timed(lambda: engb.step(xb, lb, crit))
+    out["config3_batched_8_independent_single_video_attacks"] = {"ms_per_iter": secb * 1e3, "clip_iters_per_s": 8 / secb,
+                                                                  "speedup_over_one_by_one": (8 / secb) * sec,
+                                                                  "conv_tflops": 8 * VRN_GFLOP["r2plus1d_18"] / secb / 1e3}
+    del engb
     torch.cuda.empty_cache()
     return out
 

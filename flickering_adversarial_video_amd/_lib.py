@@ -52,7 +52,7 @@ class ApplyArgs(C.Structure):
                 ("lo", C.c_float), ("hi", C.c_float), ("adv_flag", C.c_float),
                 ("shift_x", C.c_int), ("shift_p", C.c_int),
                 ("B", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int), ("fold_t", C.c_int), ("center", C.c_int),
-                ("delta_per_clip", C.c_int)]
+                ("delta_per_clip", C.c_int), ("dclip_dev", C.c_void_p)]
 
 
 class AdamArgs(C.Structure):
@@ -93,7 +93,7 @@ _SIGS = {
     "flk_pack_batch_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "flk_perturb_reg_adam": (C.c_int, [C.POINTER(AdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_perturb_reg_adam_batched": (C.c_int, [C.POINTER(AdamArgs), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.c_void_p, C.c_void_p]),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_dense_adam_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "flk_perturb_dense_l12_adam": (C.c_int, [C.POINTER(DenseAdamArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),

@@ -82,7 +82,8 @@ __device__ static inline int wrap(int t, int T) { t %= T; return t < 0 ? t + T :
 __device__ static inline float pert_at(const flk_apply_args& a, int b, int t, int h, int w, int c) {
   const int ts = wrap(t - a.shift_p, a.T);
   float d = a.delta_dense ? a.delta[(((size_t)ts * a.H + h) * a.W + w) * 3 + c] : a.delta[(a.delta_per_clip ? b * a.T : 0) * 3 + ts * 3 + c];
-  if (a.dclip > 0.f) d = clipf(d, -a.dclip, a.dclip);
+  const float dc = a.dclip_dev ? a.dclip_dev[b] : a.dclip;       // (per-clip clamp bound)
+  if (dc > 0.f) d = clipf(d, -dc, dc);
   return d * a.inv_std[c];
 }
 
@@ -181,6 +182,7 @@ static int check_apply(const flk_apply_args* a) {
   FLK_REQUIRE(a->lo <= a->hi, "flk_perturb: lo > hi");
   FLK_REQUIRE(!(a->center && a->delta_dense), "flk_perturb: center = 1 is defined for the flicker perturbation [T,3] only");
   FLK_REQUIRE(!(a->delta_per_clip && a->delta_dense), "flk_perturb: delta_per_clip is defined for the flicker perturbation only");
+  FLK_REQUIRE(!a->dclip_dev || a->delta_per_clip, "flk_perturb: dclip_dev (per-clip clamp bounds) needs delta_per_clip");
   return FLK_OK;
 }
 
@@ -283,7 +285,8 @@ __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const flo
   const int ts = wrap(t - a.shift_p, a.T);
   const size_t dbase = a.delta_per_clip ? (size_t)b_lo * a.T * 3 : 0;
   const float d = a.delta[dbase + ts * 3 + c];
-  const bool pass = !(a.dclip > 0.f) || (d >= -a.dclip && d <= a.dclip);
+  const float dc = a.dclip_dev ? a.dclip_dev[b_lo] : a.dclip;
+  const bool pass = !(dc > 0.f) || (d >= -dc && d <= dc);
   gdelta[dbase + ts * 3 + c] = pass ? s * a.adv_flag * a.inv_std[c] : 0.f;
 }
 
@@ -417,7 +420,7 @@ constexpr int ADAM_PER = 8;  // 256 threads x 8 >= 3*T  (T <= 682)
 // blockIdx.x = clip (flk_perturb_reg_adam_batched: B independent perturbations, each with its own Adam state, step counter and
 // "still attacking" flag, all on the device -- no host value changes between iterations, so the loop can be replayed as a graph)
 __global__ __launch_bounds__(256) void reg_adam_kernel(const flk_adam_args a, const float* g_adv, float* delta, float* m, float* v,
-                                                       float* scalars, int* steps, const int* active) {
+                                                       float* scalars, int* steps, const int* active, const float* dyn_dev) {
   __shared__ float sh[4];
   const int T = a.T, N = 3 * T;
   {
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void reg_adam_kernel(const flk_adam_args a, co
   }
   const int step = steps ? steps[blockIdx.x] + 1 : a.step;        // 1-based step of THIS update
   const bool update = !active || active[blockIdx.x] != 0;         // a retired clip keeps its state; its scalars are still reported
-  const float dyn = a.dyn_max_norm;
+  const float dyn = dyn_dev ? dyn_dev[blockIdx.x] : a.dyn_max_norm;
   // value the regulariser sees: raw delta (TF, kinetics_i3d_utils.py:172) or clamp(delta) (torch, model.py:1078)
   auto rv = [&](int t, int c) -> float {
     const float d = delta[wrap(t, T) * 3 + c];
@@ -486,17 +489,17 @@ extern "C" int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, 
   FLK_REQUIRE(a && g_adv && delta && m && v, "flk_perturb_reg_adam: null argument");
   FLK_REQUIRE(a->T > 0 && 3 * a->T <= 256 * ADAM_PER, "flk_perturb_reg_adam: T out of range (%d)", a->T);
   FLK_REQUIRE(a->step >= 1, "flk_perturb_reg_adam: step is 1-based");
-  hipLaunchKernelGGL(reg_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, (int*)nullptr, (const int*)nullptr);
+  hipLaunchKernelGGL(reg_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, (int*)nullptr, (const int*)nullptr, (const float*)nullptr);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
 
 extern "C" int flk_perturb_reg_adam_batched(const flk_adam_args* a, int nclip, const float* g_adv, float* delta, float* m, float* v,
-                                            int* steps_dev, const int* active_dev, float* scalars, void* stream) {
+                                            int* steps_dev, const int* active_dev, const float* dyn_max_norm_dev, float* scalars, void* stream) {
   FLK_REQUIRE(a && g_adv && delta && m && v && steps_dev, "flk_perturb_reg_adam_batched: null argument");
   FLK_REQUIRE(nclip > 0 && nclip < 65536, "flk_perturb_reg_adam_batched: bad clip count %d", nclip);
   FLK_REQUIRE(a->T > 0 && 3 * a->T <= 256 * ADAM_PER, "flk_perturb_reg_adam_batched: T out of range (%d)", a->T);
-  hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)nclip), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, steps_dev, active_dev);
+  hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)nclip), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, steps_dev, active_dev, dyn_max_norm_dev);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

@@ -70,7 +70,8 @@ __device__ inline float sg_clip(float v, float lo, float hi) { return fminf(fmax
 // perturbation added at frame t (flicker delta only) -- the same expression as attack.hip: pert_at
 __device__ inline float sg_pert(const flk_apply_args& a, int b, int t, int c) {
   float d = a.delta[(a.delta_per_clip ? b * a.T : 0) * 3 + sg_wrap(t - a.shift_p, a.T) * 3 + c];
-  if (a.dclip > 0.f) d = sg_clip(d, -a.dclip, a.dclip);
+  const float dc = a.dclip_dev ? a.dclip_dev[b] : a.dclip;
+  if (dc > 0.f) d = sg_clip(d, -dc, dc);
   return d * a.inv_std[c];
 }
 

@@ -149,7 +149,7 @@ I3D_FOLD = 3   # space-to-depth layout the I3D plan (flk_net, FLK_NET_I3D) expec
 
 
 def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=0, shift_p=0, inv_std=(1.0, 1.0, 1.0),
-                    lo=-1.0, hi=1.0, fold_t=2, center=False):
+                    lo=-1.0, hi=1.0, fold_t=2, center=False, dclip_dev=None):
     """x: uint8 or fp32 [B,T,H,W,3] on the GPU; delta fp32 [T,3] (flicker, shared by the batch), [B,T,3] (one flicker perturbation PER
     CLIP: independent single-video attacks advancing in one batch) or [T,H,W,3] (dense)."""
     B, T, H, W, c3 = x.shape
@@ -172,7 +172,10 @@ def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=
     a.B, a.T, a.H, a.W = B, T, H, W
     a.fold_t = fold_t
     a.center = int(center)      # write x_adv - a*p' (the clean value where the clip is inactive); see Net.forward_flicker
-    a._keepalive = (x, delta)   # the struct holds raw pointers only
+    if dclip_dev is not None:   # per-clip clamp bounds (fp32 [B] on the device), per-clip perturbations only
+        assert a.delta_per_clip and dclip_dev.dtype == torch.float32 and dclip_dev.shape == (B,) and dclip_dev.is_cuda
+    a.dclip_dev = ptr(dclip_dev)
+    a._keepalive = (x, delta, dclip_dev)   # the struct holds raw pointers only
     return a
 
 
@@ -242,7 +245,7 @@ def perturb_reg_adam(g_adv, delta, m, v, step, *, dialect="tf", beta0=1.0, beta1
 
 
 def perturb_reg_adam_batched(g_adv, delta, m, v, steps, active=None, *, dialect="tf", beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5,
-                             dyn_max_norm=0.0, g_scale=1.0, lr=1e-3, adam=(0.9, 0.999, 1e-8), scalars=None):
+                             dyn_max_norm=0.0, g_scale=1.0, lr=1e-3, adam=(0.9, 0.999, 1e-8), scalars=None, dyn_max_norm_dev=None):
     """B independent perturbations [B,T,3], each with its own Adam state and DEVICE step counter ``steps`` (int32 [B], advanced by the
     kernel); clips with ``active[b] == 0`` are frozen.  Returns scalars [B,8] of the pre-update perturbations."""
     B, T, _ = delta.shape
@@ -258,7 +261,9 @@ def perturb_reg_adam_batched(g_adv, delta, m, v, steps, active=None, *, dialect=
     a.step = 0
     if scalars is None:
         scalars = torch.empty((B, 8), dtype=torch.float32, device="cuda")
-    check(load().flk_perturb_reg_adam_batched(C.byref(a), B, ptr(g_adv), ptr(delta), ptr(m), ptr(v), ptr(steps), ptr(active), ptr(scalars), stream_ptr()))
+    assert dyn_max_norm_dev is None or (dyn_max_norm_dev.dtype == torch.float32 and dyn_max_norm_dev.shape == (B,) and dyn_max_norm_dev.is_cuda)
+    check(load().flk_perturb_reg_adam_batched(C.byref(a), B, ptr(g_adv), ptr(delta), ptr(m), ptr(v), ptr(steps), ptr(active),
+                                              ptr(dyn_max_norm_dev), ptr(scalars), stream_ptr()))
     return scalars
 
 

@@ -19,12 +19,17 @@ class Perturbation:
     """model.py:58-129.  size = [3,T,1,1] (flickering) or [3,T,H,W] (the dense "L12" attack, model.py:380-384); the parameter
     is stored time-major / channels-last on the device: [T,3] or [T,H,W,3]."""
 
-    def __init__(self, size, requires_grad=True, device="cuda", max_value=None, min_value=None, max_norm=1.0, cyclic_pert=False):
+    def __init__(self, size, requires_grad=True, device="cuda", max_value=None, min_value=None, max_norm=1.0, cyclic_pert=False, batch=None):
         if len(size) != 4 or size[0] != 3:
             raise ValueError(f"perturbation size must be [3,T,1,1] or [3,T,H,W], got {tuple(size)}")
         self.size, self.device, self.requires_grad = tuple(size), device, requires_grad
         self.T = size[1]
         self.dense = not (size[2] == 1 and size[3] == 1)
+        # batch = B (flickering only): B INDEPENDENT perturbations [B,T,3], one per clip of the batch, each with its own clamp bound
+        # (``dyn_max_norm_dev`` [B]) -- single-video attacks advancing together (fit_many_videos, model.py:791-982)
+        self.batch = batch
+        if batch is not None and (self.dense or cyclic_pert):
+            raise ValueError("batch: flickering perturbations without cyclic roll only")
         # model.py:72-75: attributes are only set when the argument is None (SURVEY D.6) -- reproduced
         if max_value is None:
             self.max_value = float(np.min((1 - np.array(DEFAULT_MEAN)) / DEFAULT_STD))
@@ -34,11 +39,26 @@ class Perturbation:
         self.cyclic_pert = cyclic_pert
         self._rng = np.random.default_rng(0)
         self.perturbation = None
-        self.init_perturbation()
+        if batch is not None:
+            self.perturbation = torch.zeros((batch, self.T, 3), dtype=torch.float32, device="cuda")
+            self.dyn_max_norm_dev = torch.full((batch,), float(max_norm), dtype=torch.float32, device="cuda")
+            for b in range(batch):
+                self.init_clip(b)
+        else:
+            self.init_perturbation()
 
     @property
     def _dev_shape(self):
+        if self.batch is not None:
+            return (self.batch, self.T, 3)
         return (self.T, self.size[2], self.size[3], 3) if self.dense else (self.T, 3)
+
+    def init_clip(self, b, perturbation=(), max_norm=None):
+        """batch mode: (re)start slot b -- ``init_perturbation`` for that clip alone, clamp bound back to ``max_norm`` (model.py:938-947)"""
+        p = (self._rng.random(self.size, dtype=np.float32) * 2 - 1) * 1e-6 if len(perturbation) == 0 else perturbation
+        p = np.asarray(p, dtype=np.float32).reshape(self.size)
+        self.perturbation[b].copy_(torch.from_numpy(np.ascontiguousarray(np.transpose(p, (1, 2, 3, 0)).reshape(self.T, 3))))
+        self.dyn_max_norm_dev[b] = float(self.max_norm if max_norm is None else max_norm)
 
     def _to_dev(self, p_cthw):
         """[3,T,H,W] (reference layout) -> device layout"""
@@ -50,7 +70,11 @@ class Perturbation:
         return t.reshape(self.T, self.size[2], self.size[3], 3).permute(3, 0, 1, 2)
 
     def init_perturbation(self, perturbation=(), requires_grad=True, device="cuda"):
-        """model.py:121-126: U(-1,1)*1e-6 or the given numpy array [3,T,1,1] / [3,T,H,W]"""
+        """model.py:121-126: U(-1,1)*1e-6 or the given numpy array [3,T,1,1] / [3,T,H,W] (batch mode: every slot gets it)"""
+        if self.batch is not None:
+            for b in range(self.batch):
+                self.init_clip(b, perturbation, max_norm=float(self.dyn_max_norm_dev[b]))
+            return
         if len(perturbation) == 0:
             p = (self._rng.random(self.size, dtype=np.float32) * 2 - 1) * 1e-6
         else:
@@ -63,7 +87,8 @@ class Perturbation:
         return ops.make_apply_args(x, self.perturbation, dialect="torch", dclip=self.dynamic_max_norm,
                                    adv_flag=1.0 if adversarial else 0.0, shift_p=shift,
                                    inv_std=tuple(1.0 / s for s in DEFAULT_STD),
-                                   lo=self.min_value if adversarial else -inf, hi=self.max_value if adversarial else inf, fold_t=1)
+                                   lo=self.min_value if adversarial else -inf, hi=self.max_value if adversarial else inf, fold_t=1,
+                                   dclip_dev=self.dyn_max_norm_dev if self.batch is not None else None)
 
     def forward(self, input):
         """model.py:80-101: ``input = [x, adversarial]`` -> the perturbed (or, with adversarial False, the untouched) clip.  ``x`` is the
@@ -96,7 +121,14 @@ class Perturbation:
         return self.convert_adversarial_video_zero_one(self.forward([x, True]))
 
     def clamp_perturbation(self):
+        if self.batch is not None:
+            bound = self.dyn_max_norm_dev.view(-1, 1, 1)
+            return torch.minimum(torch.maximum(self.perturbation, -bound), bound)
         return self.perturbation.clamp(-self.dynamic_max_norm, self.dynamic_max_norm)
+
+    def clip_perturbation_ref(self, b):
+        """batch mode: (clamped) perturbation of slot b in the reference layout [3,T,1,1]"""
+        return self.clamp_perturbation()[b].t().reshape(3, self.T, 1, 1)
 
     def get_perturbation(self):
         """(clamped, raw) as [3,T,1,1] / [3,T,H,W] like the reference (model.py:128-129)"""
@@ -199,7 +231,7 @@ class FlickerVideoResNet:
     """Attack engine for torchvision-0.5.0 r2plus1d_18 / r3d_18 / mc3_18 (model.py:337-399,984-1205)."""
 
     def __init__(self, base_model, weights, batch_size=1, sample_length=16, image_size=112, dtype="bf16", device=0, l_inf_pert_norm=0.2,
-                 cyclic_pert=False, num_classes=400, process_group=None, attack_type="flickering"):
+                 cyclic_pert=False, num_classes=400, process_group=None, attack_type="flickering", per_clip=False):
         if base_model not in ARCH_CODES:
             raise ValueError(f"base_model must be one of {sorted(ARCH_CODES)} (model.py:47-56), got {base_model!r}")
         if not torch.cuda.is_available():
@@ -212,8 +244,13 @@ class FlickerVideoResNet:
             raise ValueError(f"attack_type must be 'flickering' or 'L12', got {attack_type!r}")
         self.attack_type = attack_type
         # model.py:380-384: [3,T,1,1] for the flickering attack, a dense [3,T,H,W] perturbation otherwise
+        # per_clip: batch_size INDEPENDENT single-video attacks in one batch (fit_many_videos(batch=...)): a perturbation, Adam state,
+        # step counter, clamp bound and "still attacking" flag per clip; replicas only (no collective)
+        self.per_clip = bool(per_clip)
+        if self.per_clip and (attack_type != "flickering" or cyclic_pert or self.world > 1):
+            raise ValueError("per_clip: flickering attack, no cyclic roll, one rank")
         self.pert_model = Perturbation((3, self.T, 1, 1) if attack_type == "flickering" else (3, self.T, self.H, self.W),
-                                       max_norm=l_inf_pert_norm, cyclic_pert=cyclic_pert)
+                                       max_norm=l_inf_pert_norm, cyclic_pert=cyclic_pert, batch=self.B if self.per_clip else None)
         dev = torch.device("cuda", device)
         tdt = torch.bfloat16 if dtype in ("bf16", torch.bfloat16) else torch.float32
         self._xs = torch.empty((self.B, self.T, self.H // 2, self.W // 2, 16), dtype=tdt, device=dev)
@@ -225,6 +262,9 @@ class FlickerVideoResNet:
         self.adam_m = torch.zeros(self.pert_model._dev_shape, device=dev)
         self.adam_v = torch.zeros(self.pert_model._dev_shape, device=dev)
         self.adam_t = 0      # the reference keeps ONE Adam instance across videos: not reset by init_perturbation
+        if self.per_clip:
+            self.adam_steps = torch.zeros(self.B, dtype=torch.int32, device=dev)
+            self.active = torch.ones(self.B, dtype=torch.int32, device=dev)
 
     def _check_x(self, x):
         if tuple(x.shape) != (self.B, self.T, self.H, self.W, 3) or x.dtype != torch.float32 or not x.is_cuda:
@@ -246,6 +286,8 @@ class FlickerVideoResNet:
             raise ValueError(f"criterion.attack_type {criterion.attack_type!r} != engine attack_type {self.attack_type!r}")
         if self.attack_type == "L12":
             return self._step_dense(x, labels, criterion, lr, update)
+        if self.per_clip:
+            return self._step_per_clip(x, labels, criterion, lr, update)
         a = self.pert_model.apply_args(self._check_x(x), True)
         if not hasattr(self, "_slots"):
             dev = self._logits.device
@@ -278,6 +320,42 @@ class FlickerVideoResNet:
             res.update(reg_loss=sc[0], _reg_weight=criterion.lambda_, _thickness=sc[4], _roughness=sc[5])
         else:
             res.update(reg_loss=criterion.regularization_loss(self.pert_model.get_perturbation()[0]), _reg_weight=criterion.lambda_)
+        return res
+
+    def _step_per_clip(self, x, labels, criterion, lr, update):
+        """one iteration of B independent single-video attacks (torch dialect): per-clip loss / gradient / Adam, everything [B]-shaped.
+        Per clip the arithmetic is that of ``step`` on a batch of one (bitwise in fp32)."""
+        from .i3d_engine import RESULT_SLOTS, StepResult
+        a = self.pert_model.apply_args(self._check_x(x), True)
+        if not hasattr(self, "_slots"):
+            dev = self._logits.device
+            self._slots = [dict(sm=torch.empty_like(self._logits), pc=torch.empty((self.B, 4), dtype=torch.float32, device=dev),
+                                scalars=torch.zeros((self.B, 8), dtype=torch.float32, device=dev),
+                                g=torch.zeros((self.B, self.T, 3), dtype=torch.float32, device=dev)) for _ in range(RESULT_SLOTS)]
+            self._dl = torch.empty_like(self._logits)
+            self._it = 0
+        slot = self._slots[self._it % RESULT_SLOTS]
+        self._it += 1
+        sm, pc, g = slot["sm"], slot["pc"], slot["g"]
+        ops.perturb_apply_s2d(a, self.dtype, self._xs)
+        self.net.forward(self._xs, self._logits)
+        criterion.adv(labels, self._logits, 1, out=(sm, self._dl, pc))            # every clip is its own batch of one
+        self.net.backward(self._dl, self._gx)
+        ops.perturb_grad_reduce(a, self._gx, g, self._scratch)
+        self._gclip = g
+        am = pc[:, 3].to(torch.int64)
+        res = StepResult(adv_loss=pc[:, 0], softmax=sm, label_prob=pc[:, 1], argmax=am, _labels=labels, _targeted=bool(criterion.targeted),
+                         _reg_weight=criterion.lambda_)
+        if update:
+            b1 = criterion.beta_1
+            sc = slot["scalars"]
+            ops.perturb_reg_adam_batched(g, self.pert_model.perturbation, self.adam_m, self.adam_v, self.adam_steps, self.active, dialect="torch",
+                                         beta0=criterion.lambda_, beta1=b1, beta2=1 - b1, beta3=1 - b1, lr=lr, scalars=sc,
+                                         dyn_max_norm_dev=self.pert_model.dyn_max_norm_dev)
+            res.update(reg_loss=sc[:, 0], _thickness=sc[:, 4], _roughness=sc[:, 5])
+        else:
+            pc_ = self.pert_model.clamp_perturbation()
+            res.update(reg_loss=torch.stack([criterion.regularization_loss(pc_[b].t().reshape(3, self.T, 1, 1)) for b in range(self.B)]))
         return res
 
     def _step_dense(self, x, labels, criterion, lr, update):
@@ -399,13 +477,117 @@ class FlickerVideoResNet:
                         allow_pickle=True)
         return results
 
+    def _fit_many_videos_batched(self, videos, criterion, lr, model_dir, label_id_to_text, save_model, n_iter, targeted_attack, target_class_id,
+                                 restart_after=3000, norm_growth=1.3, max_restarts=4, reset_optimizer_per_video=False, log_every=0):
+        """``fit_many_videos`` with B = batch_size videos attacked AT ONCE (engine built with ``per_clip=True``): every slot runs the loop of
+        ``fit_single_video_attack`` (model.py:1056-1101: while step < n_iter or not adversarial; restart with 1.3x clamp bound, give up
+        after 4) on its own video with its own perturbation / clamp bound / step counters; a finished slot takes the next video.  Per
+        video the iterations are those of the one-by-one loop (bitwise in fp32 when the optimiser state is reset per video; the
+        reference's single Adam instance carried from video to video, SURVEY D.5, becomes one carried state PER SLOT here)."""
+        import os
+        assert self.per_clip
+        B, T = self.B, self.T
+        dev = self._logits.device
+        x = torch.zeros((B, T, self.H, self.W, 3), dtype=torch.float32, device=dev)
+        labels = torch.zeros(B, dtype=torch.int64, device=dev)
+        rng = np.random.default_rng(0)
+        it = iter(videos)
+        slots, out = [None] * B, {}
+
+        def refill(b):
+            while True:
+                nxt = next(it, None)
+                if nxt is None:
+                    slots[b] = None
+                    self.active[b] = 0
+                    return
+                inputs, target, name = nxt
+                cls = (label_id_to_text[int(target[0])] if label_id_to_text is not None else str(int(target[0]))).replace(" ", "_")
+                dest = os.path.join(model_dir, f"{os.path.basename(str(name))}_@{cls}.npy") if model_dir else None
+                if dest and os.path.exists(dest):
+                    prev = np.load(dest, allow_pickle=True).tolist()
+                    if prev is None or np.array(prev["is_adversarial"]).any():
+                        continue
+                elif dest and save_model:
+                    os.makedirs(model_dir, exist_ok=True)
+                    np.save(dest, None)
+                self.pert_model.init_clip(b, (rng.random(self.pert_model.size, dtype=np.float32) * 2 - 1) * 0.005)     # model.py:938-947
+                if reset_optimizer_per_video:
+                    self.adam_m[b].zero_(); self.adam_v[b].zero_(); self.adam_steps[b] = 0
+                self.active[b] = 1
+                x[b].copy_(inputs[0])
+                labels[b] = int(target[0])
+                clean = self.logits(x, False)[b:b + 1].clone()
+                if int(clean.argmax(1)) != int(target[0]):
+                    out[str(name)] = None                                  # model.py:1030-1032
+                    continue
+                slots[b] = dict(name=str(name), dest=dest, target=target.clone(), clean=clean, step=0, new_chance=0, is_adv=False,
+                                tot=[], adv=[], reg=[], thick=[], rough=[], maxp=[], corr=[], isadv=[], pert=[])
+                return
+
+        def finish(b):
+            st = slots[b]
+            p = self.pert_model.clip_perturbation_ref(b).cpu().numpy()
+            res = {"loss/total": st["tot"], "loss/adv_loss": st["adv"], "loss/reg_loss": st["reg"], "perturbation/thickness": st["thick"],
+                   "perturbation/roughness": st["rough"], "perturbation/inf_norm": float(np.abs(p).max()), "perturbation": st["pert"],
+                   "prob_clean_input": st["clean"], "label": st["target"].cpu().numpy(), "is_adversarial": st["isadv"],
+                   "max_prob": st["maxp"], "correct_cls_prob": st["corr"], "restarts": st["new_chance"]}
+            out[st["name"]] = res
+            if st["dest"] and save_model:
+                np.save(st["dest"], dict(res, prob_clean_input=res["prob_clean_input"].cpu().numpy()), allow_pickle=True)
+            refill(b)
+
+        for b in range(B):
+            refill(b)
+        while any(st is not None for st in slots):
+            # the loop head of fit_single_video_attack, per slot (a refilled slot is checked again: its fresh state passes trivially)
+            for b in range(B):
+                while slots[b] is not None:
+                    st = slots[b]
+                    if not (st["step"] < n_iter or not st["is_adv"]):
+                        finish(b)
+                        continue
+                    if st["step"] > restart_after:
+                        st["new_chance"] += 1
+                        self.pert_model.dyn_max_norm_dev[b] *= norm_growth
+                        st["step"] = 0
+                    if st["new_chance"] == max_restarts:
+                        finish(b)
+                        continue
+                    break
+            if not any(st is not None for st in slots):
+                break
+            r = self.step(x, labels, criterion, lr=lr)
+            h = r.host()
+            pcl = self.pert_model.clamp_perturbation().cpu().numpy()               # [B,T,3] after the update (model.py:1110-1112)
+            for b, st in enumerate(slots):
+                if st is None:
+                    continue
+                adv_class = int(h["argmax"][b])
+                st["is_adv"] = (adv_class == target_class_id) if targeted_attack else (adv_class != int(st["target"][0]))
+                st["isadv"].append(st["is_adv"])
+                st["tot"].append(float(h["loss"][b])); st["adv"].append(float(h["adv_loss"][b])); st["reg"].append(float(h["reg_loss"][b]))
+                p = pcl[b].reshape(T, 1, 1, 3).transpose(3, 0, 1, 2)      # [3,T,1,1], the memory layout get_perturbation() hands the one-by-one loop
+                                                                          # (numpy's float32 mean depends on it in the last bit)
+                st["pert"].append(p)
+                st["thick"].append(float(np.abs(p).mean())); st["rough"].append(float(np.abs(np.roll(p, 1, 1) - p).mean()))
+                st["maxp"].append(float(h["softmax"][b].max())); st["corr"].append(float(h["label_prob"][b]))
+                if log_every and st["step"] % log_every == 0:
+                    print(f"[{st['name']}] batch {st['step']} of {n_iter} | loss = {st['tot'][-1]:.4f} | adv loss = {st['adv'][-1]:.4f} | "
+                          f"reg loss = {st['reg'][-1]:.4f}", flush=True)
+                st["step"] += 1
+        return out
+
     def fit_many_videos(self, videos, criterion, lr=1e-3, model_dir=None, label_id_to_text=None, save_model=True, n_iter=3000,
-                        targeted_attack=False, target_class_id=None, **kw):
+                        targeted_attack=False, target_class_id=None, reset_optimizer_per_video=False, **kw):
         """``VideoLearnerAdversarial.fit_many_videos`` (model.py:791-982): one single-video attack per (inputs, target, name);
         a video whose result file already shows a success is skipped, a placeholder (None) is written before the attack, the
         perturbation restarts from U(-1,1) * 0.005 and the clamp norm from ``max_norm`` (model.py:938-947).  Result files are
         ``<name>_@<class>.npy`` (model.py:917-921).  Returns {name: result dict or None}."""
         import os
+        if self.per_clip:
+            return self._fit_many_videos_batched(videos, criterion, lr, model_dir, label_id_to_text, save_model, n_iter, targeted_attack,
+                                                 target_class_id, reset_optimizer_per_video=reset_optimizer_per_video, **kw)
         out = {}
         rng = np.random.default_rng(0)
         for inputs, target, name in videos:
@@ -420,6 +602,8 @@ class FlickerVideoResNet:
                 np.save(dest, None)
             self.pert_model.init_perturbation(((rng.random(self.pert_model.size, dtype=np.float32) * 2 - 1) * 0.005))
             self.pert_model.dynamic_max_norm = self.pert_model.max_norm
+            if reset_optimizer_per_video:                       # (the reference carries ONE Adam state from video to video, SURVEY D.5: default)
+                self.adam_m.zero_(); self.adam_v.zero_(); self.adam_t = 0
             res = self.fit_single_video_attack(inputs, target, criterion, lr=lr, n_iter=n_iter, targeted_attack=targeted_attack,
                                                target_class_id=target_class_id, **kw)
             out[str(name)] = res

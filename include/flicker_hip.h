@@ -166,6 +166,8 @@ typedef struct {
   int delta_per_clip;        /* 1 (flicker delta only): delta is [B,T,3] and clip b is perturbed by ITS OWN delta[b] -- B independent
                                 single-video attacks (i3d_adversarial_main_single_video_npy.py:103-337, model.py:791-982) advancing in
                                 one batch; the delta-gradient then comes back per clip, [B,T,3].  0: one delta [T,3] shared by the batch */
+  const float* dclip_dev;    /* delta_per_clip only, or NULL: per-clip clamp bounds [B] on the device replacing `dclip` -- the torch loop grows a
+                                video's bound by 1.3 when it restarts (model.py:1061-1066), independently per video */
 } flk_apply_args;
 int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dtype, void* stream);
 
@@ -227,10 +229,11 @@ int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, float* delt
 /* The same update for nclip INDEPENDENT perturbations (delta, m, v, g_adv: [nclip,T,3]; scalars: [nclip,8]) -- single-video attacks
  * batched (i3d_adversarial_main_single_video_npy.py:103-337; model.py:791-982 fit_many_videos): clip b takes Adam step
  * steps_dev[b] + 1 (a->step is ignored) and the counter is advanced on the device; clips with active_dev[b] == 0 (already
- * adversarial: retired) keep delta / m / v / counter, their scalars are still written.  active_dev may be NULL (all active).
+ * adversarial: retired) keep delta / m / v / counter, their scalars are still written.  active_dev may be NULL (all active);
+ * dyn_max_norm_dev (torch dialect) may be NULL (a->dyn_max_norm for every clip) or hold one clamp bound per clip.
  * Per clip the arithmetic is exactly flk_perturb_reg_adam's. */
 int flk_perturb_reg_adam_batched(const flk_adam_args* a, int nclip, const float* g_adv, float* delta, float* m, float* v,
-                                 int* steps_dev, const int* active_dev, float* scalars, void* stream);
+                                 int* steps_dev, const int* active_dev, const float* dyn_max_norm_dev, float* scalars, void* stream);
 
 /* Dense-delta ("sparse adversarial perturbations" baseline, kinetics_i3d_L12, kinetics_i3d_utils.py:308-521): delta is
  * [T,H,W,3] (init 1e-8, no +-0.4 clip), regulariser L12 = sum_t sqrt(mean_{hwc} delta_t^2) + 1e-12 (:409; torch dialect

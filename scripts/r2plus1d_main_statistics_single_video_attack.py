@@ -40,6 +40,10 @@ def main():
     ap.add_argument("--n-iter", type=int, default=N_ITER)
     ap.add_argument("--restart-after", type=int, default=3000)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=1, help="videos attacked at once, each with its own perturbation / clamp bound / Adam state "
+                    "(flickering attack; 1 = the reference's one-by-one loop)")
+    ap.add_argument("--reset-optimizer-per-video", action="store_true", help="fresh Adam state for every video (the reference carries one "
+                    "state from video to video, model.py:946; with --batch > 1 the carried state is per batch slot)")
     a = ap.parse_args()
     z = np.load(a.videos_npz, allow_pickle=True)
     clips, labels = z["clips"], z["labels"].astype(np.int64)
@@ -49,13 +53,14 @@ def main():
     clips = np.ascontiguousarray(clips, dtype=np.float32)
     classes = [l.strip() for l in open(a.label_map)] if a.label_map else None
     W = vs.load_weights(a.weights_npz) if a.weights_npz else vs.synthetic_weights(a.base_model, 42)
-    learner = FlickerVideoResNet(a.base_model, W, batch_size=1, sample_length=clips.shape[1], image_size=clips.shape[2], dtype=a.dtype,
-                                 l_inf_pert_norm=L_INF_PERT_NORM, cyclic_pert=CYCLIC_PERT, attack_type=a.attack_type)
+    learner = FlickerVideoResNet(a.base_model, W, batch_size=a.batch, sample_length=clips.shape[1], image_size=clips.shape[2], dtype=a.dtype,
+                                 l_inf_pert_norm=L_INF_PERT_NORM, cyclic_pert=CYCLIC_PERT, attack_type=a.attack_type, per_clip=a.batch > 1)
     dest = os.path.join(a.results_root, learner.model_name, "single_video_attack", a.attack_type,
                         f"linf_{L_INF_PERT_NORM}_lambda_{LAMBDA}_beta1_{BETA_1}_")
     crit = Losses(beta_1=BETA_1, lambda_=LAMBDA, targeted=TARGETED_ATTACK, improve_loss=IMPROVE_LOSS, logits=USE_LOGITS, attack_type=a.attack_type)
     videos = ((torch.from_numpy(clips[i:i + 1]).cuda(), torch.from_numpy(labels[i:i + 1]).cuda(), names[i]) for i in range(len(clips)))
-    out = learner.fit_many_videos(videos, crit, lr=LR, model_dir=dest, label_id_to_text=classes, n_iter=a.n_iter, restart_after=a.restart_after)
+    out = learner.fit_many_videos(videos, crit, lr=LR, model_dir=dest, label_id_to_text=classes, n_iter=a.n_iter, restart_after=a.restart_after,
+                                  reset_optimizer_per_video=a.reset_optimizer_per_video)
     for name, r in out.items():
         if r is None:
             print(f"{name}: clean clip misclassified, skipped")
