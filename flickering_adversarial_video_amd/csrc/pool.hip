@@ -9,6 +9,7 @@
 //             FLK_POOL_GATHER=1 in bf16; the scatter form in fp32 (float LDS atomics, last-ulp run-to-run differences) only
 //             with FLK_POOL_SCATTER_F32=1.  Optional relu mask of the producing layer (mask > 0) fused in.
 #include <stdlib.h>
+#include <string.h>
 #include "flk_internal.h"
 
 struct PoolKP {
@@ -719,6 +720,144 @@ __global__ __launch_bounds__(256, 4) void maxpool_scatter_bwd(const PoolTP p, un
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Branch_3 backward of an Inception block in ONE kernel (i3d.py:211-216 backward; bf16): the data-gradient of the 1x1x1 unit
+// (a GEMM with K = 32..128) computed on MFMA inside the pool's scatter backward, instead of  1x1x1 data-gradient -> HBM ->
+// scatter  (two dependent launches, 2 x cur_c bytes per position through HBM, and the critical chain of every block's
+// backward phase: the two 3x3x3 data-gradients it runs beside are single launches).
+//   gin[cell, c] = sum_{windows w whose argmax for channel c is cell} ( sum_k g[w, k] * Wt[k, c] )
+// Workgroup = (tile of INPUT cells, slab of 32 channels), as maxpool_scatter_bwd.  A wave takes 16 window positions per pass:
+// their g rows are the MFMA B fragments (lane (q, m) loads g[pos m][32 ks + 8 q ..], 16 bytes, straight from global: K-contiguous),
+// the slab's weights the A fragments (packed by flk_pool_gemm_weights_create, kept in registers for the whole workgroup), so a lane
+// ends up with the 8 values  (position m) x (channels 16 f + 4 q + j)  in fp32 -- never rounded to bf16, never stored -- and adds
+// each to the cell its saved argmax names, in 32-bit fixed point with integer LDS atomics exactly like maxpool_scatter_bwd
+// (order-independent: bitwise reproducible).  The per-workgroup scale needs max |value| first: the product pass runs twice
+// (max, then scatter); its MFMAs are ~1 % of the kernel.
+struct PoolGemmP {
+  PoolTP t;
+  const char* g; int g_ld, g_coff, KS;       // KS = K / 32 k-steps
+  const char* wpack;                          // [slab][ks][f = 0,1][64 lanes][16 B]
+};
+
+template <int KS>
+__global__ __launch_bounds__(256, 4) void maxpool_scatter_gemm_bwd(const PoolGemmP pg, unsigned m_khkw, unsigned m_kw) {
+  typedef __bf16 frag8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* const acc = (unsigned*)smem;     // [32 channels][RS cells] fixed-point accumulators
+  const PoolTP& p = pg.t;
+  const PoolKP& k = p.k;
+  const int RS = p.plane_b;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, m = lane & 15;
+  int bid, cslab;
+  if (!tile_slab_of_block(p.ntiles, p.nslab, bid, cslab)) return;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int i_t0 = tt * p.Tt, i_h0 = th * p.Ht, i_w0 = tw * p.Wt;
+  const int o_t0 = max(0, (i_t0 + k.pt - k.kt + k.st) / k.st), o_t1 = min(k.To - 1, (i_t0 + p.Tt - 1 + k.pt) / k.st);
+  const int o_h0 = max(0, (i_h0 + k.ph - k.kh + k.sh) / k.sh), o_h1 = min(k.Ho - 1, (i_h0 + p.Ht - 1 + k.ph) / k.sh);
+  const int o_w0 = max(0, (i_w0 + k.pw - k.kw + k.sw) / k.sw), o_w1 = min(k.Wo - 1, (i_w0 + p.Wt - 1 + k.pw) / k.sw);
+  const int nt = max(0, o_t1 - o_t0 + 1), nh = max(0, o_h1 - o_h0 + 1), nw = max(0, o_w1 - o_w0 + 1);
+  const int nhw = nh * nw, P = nt * nhw;
+  const float inv_hw = 1.0f / (float)max(nhw, 1), inv_w = 1.0f / (float)max(nw, 1);
+  for (int i = tid; i < 32 * RS; i += 256) acc[i] = 0u;
+  unsigned* const smax = acc + 32 * RS;
+  if (tid == 0) *smax = 0u;
+
+  // A fragments of this slab: channels [32 cslab, +32), all K
+  frag8 af[KS][2];
+  {
+    const char* wp = pg.wpack + ((size_t)cslab * KS * 2 * 64 + lane) * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) af[ks][f] = *(const frag8*)(wp + (size_t)(ks * 2 + f) * 1024);
+  }
+  // window position hp -> linear output position and its origin relative to the tile
+  auto decode = [&](int hp, size_t& opos, int& lt0, int& lh0, int& lw0) {
+    const int a = (int)(((float)hp + 0.5f) * inv_hw), rem = hp - a * nhw;
+    const int bq = (int)(((float)rem + 0.5f) * inv_w), c = rem - bq * nw;
+    const int ot = o_t0 + a, oh = o_h0 + bq, ow = o_w0 + c;
+    opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+    lt0 = ot * k.st - k.pt - i_t0; lh0 = oh * k.sh - k.ph - i_h0; lw0 = ow * k.sw - k.pw - i_w0;
+  };
+  auto product = [&](size_t opos, f32x4 (&v)[2]) {
+    const char* gp = pg.g + (opos * pg.g_ld + pg.g_coff + q * 8) * 2;
+    frag8 bf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bf[ks] = *(const frag8*)(gp + ks * 64);
+    v[0] = f32x4{0.f, 0.f, 0.f, 0.f}; v[1] = v[0];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      v[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][0], bf[ks], v[0], 0, 0, 0);
+      v[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][1], bf[ks], v[1], 0, 0, 0);
+    }
+  };
+  __syncthreads();
+  // ---- pass 1: the largest |value| this workgroup will add (as an fp32 bit pattern: magnitudes order like unsigned integers) ----
+  unsigned mx = 0u;
+  for (int base = wave * 16; base < P; base += 64) {
+    const int hp = min(base + m, P - 1);
+    size_t opos; int lt0, lh0, lw0;
+    decode(hp, opos, lt0, lh0, lw0);
+    f32x4 v[2];
+    product(opos, v);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mx = max(mx, __float_as_uint(v[f][j]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+  if (lane == 0) atomicMax(smax, mx);
+  __syncthreads();
+  int ex = (int)(*smax >> 23);
+  ex = min(max(ex, 26), 254);
+  const float scale = __uint_as_float((unsigned)(127 + 24 + 127 - ex) << 23);
+  const float inv_scale = __uint_as_float((unsigned)(127 - 24 - 127 + ex) << 23);
+  // ---- pass 2: the same products, scattered ----
+  const int khkw = k.kh * k.kw;
+  for (int base = wave * 16; base < P; base += 64) {
+    const int hp = min(base + m, P - 1);
+    const bool live = base + m < P;
+    size_t opos; int lt0, lh0, lw0;
+    decode(hp, opos, lt0, lh0, lw0);
+    unsigned ib[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) ib[f] = *(const unsigned*)(k.idx + opos * k.C + cslab * 32 + f * 16 + q * 4);
+    f32x4 v[2];
+    product(opos, v);
+    if (!live) continue;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tap = (int)((ib[f] >> (8 * j)) & 255u);              // 255 ("no cell") decodes out of range below
+        const int dt = (int)(((unsigned)tap * m_khkw) >> 20), r2 = tap - dt * khkw;
+        const int dh = (int)(((unsigned)r2 * m_kw) >> 20), dw = r2 - dh * k.kw;
+        const int lt = lt0 + dt, lh = lh0 + dh, lw = lw0 + dw;
+        if ((unsigned)lt < (unsigned)p.Tt && (unsigned)lh < (unsigned)p.Ht && (unsigned)lw < (unsigned)p.Wt && dt < k.kt)
+          atomicAdd(&acc[(f * 16 + q * 4 + j) * RS + (lt * p.Ht + lh) * p.Wt + lw], (unsigned)__float2int_rn(v[f][j] * scale));
+      }
+  }
+  __syncthreads();
+  // ---- write the tile: thread = (cell, 16-byte channel chunk) ----
+  const int ch = tid & 3, c0 = cslab * 32 + ch * 8;
+  if (c0 >= k.C) return;
+  const int hw = p.Ht * p.Wt;
+  for (int r = tid >> 2; r < p.rows; r += 64) {
+    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
+    if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = (float)(int)acc[(ch * 8 + e) * RS + r] * inv_scale;
+    const size_t ipos = (((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw);
+    PV<bf16_t>::st(k.gin + (ipos * k.gin_ld + k.gin_coff + c0) * 2, g);
+  }
+}
+
 // input-cell tile for the scatter backward: minimise bytes moved per useful cell (tile writes + the windows read,
 // which overlap between neighbouring tiles) plus a fixed per-workgroup cost
 static flk_tile choose_scatter_tile(const flk_pool_args* a) {
@@ -874,6 +1013,78 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
   const dim3 grid((unsigned)((a->Wi * (a->C / epl) + 255) / 256), (unsigned)a->Hi, (unsigned)(a->B * a->Ti));
   if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
   else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+
+// ---- fused Branch_3 backward: weights + entry point -----------------------------------------------------------------------------
+// wt_kc: fp32 [K][C] = the 1x1x1 unit's weight transposed, batch-norm scale folded in (Wt[k][c] = w[c][k] * scale[k]); K % 32 == 0,
+// C % 8 == 0.  Packed as MFMA A fragments per (32-channel slab, 32-wide k-step, half): lane (q, m) holds Wt[32 ks + 8 q + j][32 s + 16 f + m].
+extern "C" int flk_pool_gemm_weights_create(const float* wt_kc, int K, int C, void** out_dev) {
+  FLK_REQUIRE(wt_kc && out_dev && K > 0 && K % 32 == 0 && K <= 128 && C > 0 && C % 8 == 0, "flk_pool_gemm_weights_create: K must be 32, 64, 96 or 128 and C a multiple of 8 "
+              "(got K %d, C %d)", K, C);
+  const int nslab = (C + 31) / 32, KS = K / 32;
+  std::vector<uint16_t> h((size_t)nslab * KS * 2 * 64 * 8, 0);
+  auto bf = [](float f) -> uint16_t {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  };
+  for (int s = 0; s < nslab; ++s)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int f = 0; f < 2; ++f)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int q = lane >> 4, m = lane & 15, c = s * 32 + f * 16 + m;
+          for (int j = 0; j < 8; ++j) {
+            const int kk = ks * 32 + q * 8 + j;
+            h[((((size_t)s * KS + ks) * 2 + f) * 64 + lane) * 8 + j] = c < C ? bf(wt_kc[(size_t)kk * C + c]) : 0;
+          }
+        }
+  void* d = nullptr;
+  hipError_t e = hipMalloc(&d, h.size() * 2);
+  if (e != hipSuccess) { flk_set_error("hipMalloc(%zu): %s", h.size() * 2, hipGetErrorString(e)); return FLK_ENOMEM; }
+  e = hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(d); flk_set_error("hipMemcpy: %s", hipGetErrorString(e)); return FLK_EHIP; }
+  *out_dev = d;
+  return FLK_OK;
+}
+extern "C" int flk_pool_gemm_weights_destroy(void* dev) {
+  if (dev) (void)hipFree(dev);
+  return FLK_OK;
+}
+
+extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int g_ld, int g_coff, int K, const void* wpack,
+                                      void* gin, int gin_ld, int gin_coff, int dtype, void* stream) {
+  int rc = check_pool(a);
+  if (rc) return rc;
+  FLK_REQUIRE(g && wpack && gin, "flk_maxpool3d_bwd_gemm: null argument");
+  FLK_REQUIRE(dtype == FLK_BF16, "flk_maxpool3d_bwd_gemm: bf16 only (fp32, the parity mode, keeps the two-launch gather path)");
+  FLK_REQUIRE(K > 0 && K % 32 == 0 && K <= 128, "flk_maxpool3d_bwd_gemm: K must be 32, 64, 96 or 128 (got %d)", K);
+  FLK_REQUIRE(g_ld % 8 == 0 && g_coff % 8 == 0 && g_coff + K <= g_ld && gin_ld % 8 == 0 && gin_coff % 8 == 0 && gin_coff + a->C <= gin_ld,
+              "flk_maxpool3d_bwd_gemm: bad ld / coff");
+  FLK_REQUIRE((size_t)a->B * a->To * a->Ho * a->Wo * (size_t)(g_ld > a->C ? g_ld : a->C) < (1ull << 31), "flk_maxpool3d_bwd_gemm: tensor too large");
+  PoolGemmP pg{};
+  fill(pg.t.k, a);
+  pg.t.k.gin = (char*)gin; pg.t.k.gin_ld = gin_ld; pg.t.k.gin_coff = gin_coff;
+  pg.g = (const char*)g; pg.g_ld = g_ld; pg.g_coff = g_coff; pg.KS = K / 32; pg.wpack = (const char*)wpack;
+  const flk_tile t = choose_scatter_tile(a);
+  PoolTP& tp = pg.t;
+  tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
+  tp.nTt = (a->Ti + t.Tt - 1) / t.Tt; tp.nTh = (a->Hi + t.Ht - 1) / t.Ht; tp.nTw = (a->Wi + t.Wt - 1) / t.Wt;
+  tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
+  const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
+  auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
+  tp.plane_b = (tp.rows + 47) / 64 * 64 + 16;
+  const size_t lds = (size_t)(32 * tp.plane_b + 64) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned m1 = magic(a->kh * a->kw), m2 = magic(a->kw);
+  switch (pg.KS) {
+    case 1: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<1>, grid, dim3(256), lds, s, pg, m1, m2); break;
+    case 2: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<2>, grid, dim3(256), lds, s, pg, m1, m2); break;
+    case 3: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<3>, grid, dim3(256), lds, s, pg, m1, m2); break;
+    default: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<4>, grid, dim3(256), lds, s, pg, m1, m2); break;
+  }
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

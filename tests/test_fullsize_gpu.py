@@ -203,7 +203,7 @@ def test_config2_single_video_iterations_full_size(env):
     """BASELINE config 2 (single-video attack, bs 1, 64 x 224 x 224, bf16) through the complete iteration -- apply, forward, loss,
     backward to delta (split-K plan, fused stem kernels), regulariser + Adam -- not only its forward: 40 iterations on one clip.
     The adversarial loss falls, every scalar stays finite, two runs give the same bits, and the first-step gradient agrees with the
-    fp32 engine on the same clip (cosine > 0.85, the bf16 / fp32 bar of tests/test_i3d_gpu.py, at full size; measured 0.908)."""
+    fp32 engine on the same clip (cosine > 0.88 at full size; measured 0.908)."""
     from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
     W, x = env
     x1 = x[3:4].contiguous()
@@ -233,4 +233,4 @@ def test_config2_single_video_iterations_full_size(env):
     g32 = e32.delta_gradient().flatten()
     cos = float(torch.nn.functional.cosine_similarity(outs[0][1].flatten(), g32, 0))
     print(f"first-step d(adv)/d(delta): bf16 vs fp32 cosine {cos:.4f}")
-    assert cos > 0.85
+    assert cos > 0.88

@@ -204,7 +204,7 @@ def test_forward_backward_vs_oracle(setup, dtype):
     e_hip, e_cpu = rel_err(g, r64["g"]), rel_err(r32["g"], r64["g"])
     cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), r64["g"].flatten(), 0))
     print(f"[{dtype}] d(adv)/d(delta) end to end vs fp64 oracle: HIP max-rel {e_hip:.3e} (fp32 CPU oracle {e_cpu:.3e}); cosine {cos:.6f}")
-    assert cos > (0.999 if f32 else 0.85)
+    assert cos > (0.999 if f32 else 0.92)      # bf16: measured 0.946 (the per-link bars above are the parity statement; this guards the sum)
     assert g[3].abs().max() == 0             # clipped delta entries get no gradient (kinetics_i3d_utils.py:104)
 
 
@@ -379,7 +379,8 @@ def test_bf16_trajectory_well_conditioned():
 
 def test_bf16_step_runs_and_tracks_fp32(setup):
     """bf16 performance mode: same iteration, looser agreement with the fp32 engine (stated: 5% on the loss,
-    first Adam step -- a pure sign step -- agreeing on >= 80% of the delta entries, gradient cosine > 0.85)."""
+    first Adam step -- a pure sign step -- agreeing on >= 82% of the delta entries, gradient cosine > 0.91; measured 85.4 % / 0.942:
+    on the random-sign weights the gradient is a cancelling sum, so two roundings of it disagree on the sign of its small entries)."""
     from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
     W, Wt, xu, _, ref = setup
     label = i3d_ref.i3d_logits(xu.float() / 128 - 1, Wt[torch.float32]).argmax(-1).cuda()
@@ -393,7 +394,7 @@ def test_bf16_step_runs_and_tracks_fp32(setup):
     agree = (torch.sign(out["bf16"][1]) == torch.sign(out["f32"][1])).float().mean().item()
     cos = float(torch.nn.functional.cosine_similarity(out["bf16"][2].flatten(), out["f32"][2].flatten(), 0))
     print(f"bf16 vs f32: adv {out['bf16'][0]:.5f} vs {out['f32'][0]:.5f}; first-step sign agreement {agree:.3f}; grad cosine {cos:.4f}")
-    assert agree >= 0.8 and cos > 0.85
+    assert agree >= 0.82 and cos > 0.91
 
 
 def test_dense_delta_step(setup):
@@ -639,7 +640,7 @@ def test_reference_default_clip_length(frames):
     g16 = e16.delta_gradient().cpu().reshape(g.shape) / 2          # the margin loss is a SUM over the (identical) clips
     cos16 = float(torch.nn.functional.cosine_similarity(g16.double().flatten(), g.double().flatten(), 0))
     print(f"T={Tn} bf16: logits rel err {rel_err(got16[:1], logits.detach()):.2e}, gradient cosine {cos16:.4f}")
-    assert cos16 > 0.85
+    assert cos16 > 0.90                          # measured 0.930 (T = 90), 0.958 (T = 18)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -760,5 +761,5 @@ def test_benchmark_geometry_bf16_vs_rounded_oracle():
     cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), ref["g"].double().flatten(), 0))
     print(f"[bf16 T={T64}] end to end vs fp32 oracle: logits {e_l:.2e}, adv loss {e_loss:.2e}, d(loss)/d(delta) cosine {cos:.4f}")
     assert e_l < 5e-2 and e_loss < 5e-2
-    assert cos > 0.85
+    assert cos > 0.88                            # measured 0.910
     assert g[5].abs().max() == 0
