@@ -87,6 +87,10 @@ _SIGS = {
     "flk_maxpool3d_fwd": (C.c_int, [C.POINTER(PoolArgs), C.c_int, C.c_void_p]),
     "flk_maxpool3d_bwd": (C.c_int, [C.POINTER(PoolArgs), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "flk_pool_gemm_weights_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "flk_pool_gemm_weights_destroy": (C.c_int, [C.c_void_p]),
+    "flk_maxpool3d_bwd_gemm": (C.c_int, [C.POINTER(PoolArgs), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_int, C.c_void_p]),
     "flk_perturb_apply_s2d": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_int, C.c_void_p]),
     "flk_perturb_grad_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "flk_perturb_grad_reduce": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -89,6 +89,7 @@ struct flk_net {
   std::map<std::string, std::vector<float>> weights;
   std::vector<std::unique_ptr<ConvLayer>> convs;
   std::vector<void*> allocs;
+  std::vector<void*> pool_gemm_weights;      // flk_pool_gemm_weights_create handles (fused Branch_3 backward)
   size_t alloc_bytes = 0;
   std::vector<Op> fwd, bwd;
   std::map<std::string, std::pair<Act, int>> named;   // endpoint name -> (tensor, channels)
@@ -570,13 +571,36 @@ int flk_net::build_i3d() {
     // the device before the join.  FLK_B3_EARLY=1: the 1x1x1 link runs BEFORE the fork, alone (it is short), and the scatter
     // overlaps the 3x3x3 data-gradients.
     static const bool b3_early = getenv("FLK_B3_EARLY") && atoi(getenv("FLK_B3_EARLY"));
+    // bf16: Branch_3's backward (1x1x1 data-gradient -> pool scatter) as ONE kernel (FLK_B3_FUSED=0: the two-launch chain)
+    const bool b3_fused = dtype == FLK_BF16 && c3 % 32 == 0 && c3 <= 128 && !(getenv("FLK_B3_FUSED") && atoi(getenv("FLK_B3_FUSED")) == 0);
+    void* wpg = nullptr;
+    if (b3_fused) {
+      std::vector<float> wt((size_t)c3 * cur_c);                     // Wt[k][c] = w[c][k] * bn_scale[k]
+      for (int k = 0; k < c3; ++k)
+        for (int c = 0; c < cur_c; ++c) wt[(size_t)k * cur_c + c] = L3->w[(size_t)c * c3 + k] * L3->scale[k];
+      if ((rc = flk_pool_gemm_weights_create(wt.data(), c3, cur_c, &wpg))) return rc;
+      pool_gemm_weights.push_back(wpg);
+    }
+    const int cur_c_blk = cur_c;
     bwd_emit.push_back([=]() {
-      if (b3_early) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
+      if (b3_early && !b3_fused) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
       push_sync(bwd, K_FORK);
       {
         const size_t m0 = bwd.size();
-        if (!b3_early) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
-        emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
+        if (b3_fused) {
+          // ONE kernel: the 1x1x1 data-gradient on MFMA inside the pool's scatter backward (pool.hip: maxpool_scatter_gemm_bwd)
+          const flk_pool_args pa = pr3.a;
+          const void* gp = Gout.p; void* gip = gxa.p;
+          const int gld = Gout.ld, gco = c0 + c1b + c2b_, gild = gxa.ld, K = c3;
+          const double macs = (double)B * Gout.T * Gout.H * Gout.W * cur_c_blk * c3;
+          const double bytes = ((double)B * Gout.T * Gout.H * Gout.W * (c3 + cur_c_blk)) * esz() + (double)B * Gout.T * Gout.H * Gout.W * cur_c_blk;
+          bwd.push_back(Op{pname + "/grad+Conv3d_0b_1x1/dgrad", K_POOL, 2.0 * macs, bytes, [pa, gp, gld, gco, K, wpg, gip, gild](hipStream_t s) {
+                             return flk_maxpool3d_bwd_gemm(&pa, gp, gld, gco, K, wpg, gip, gild, 0, FLK_BF16, s);
+                           }});
+        } else {
+          if (!b3_early) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
+          emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
+        }
         set_lane(bwd, m0, 2);
       }
       { const size_t m0 = bwd.size(); emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a); set_lane(bwd, m0, 1); }
@@ -965,6 +989,7 @@ extern "C" int flk_net_destroy(flk_net* n) {
   flk_stem_delta_grad_weights_destroy(n->d_stem_wf);
   flk_stem_delta_grad_weights_destroy(n->d_stem_sums);
   for (void* p : n->allocs) (void)hipFree(p);
+  for (void* p : n->pool_gemm_weights) flk_pool_gemm_weights_destroy(p);
   for (auto& L : n->convs) {
     flk_conv_weights_destroy(L->wf); flk_conv_weights_destroy(L->wb);
     for (auto& c : L->bcls) flk_conv_weights_destroy(c.w);

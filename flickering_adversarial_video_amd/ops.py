@@ -145,6 +145,32 @@ def maxpool3d_bwd(ctx, gout, mask=None):
     return gin
 
 
+class PoolGemmWeights:
+    """MFMA-packed Wt [K][C] (a 1x1x1 unit's weight transposed x batch-norm scale) for maxpool3d_bwd_gemm"""
+
+    def __init__(self, wt_kc):
+        w = np.ascontiguousarray(wt_kc, dtype=np.float32)
+        self.K, self.C = w.shape
+        self.handle = C.c_void_p()
+        check(load().flk_pool_gemm_weights_create(w.ctypes.data_as(C.c_void_p), self.K, self.C, C.byref(self.handle)))
+
+    def __del__(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            load().flk_pool_gemm_weights_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def maxpool3d_bwd_gemm(ctx, g, weights, g_coff=0):
+    """Branch_3 backward in one kernel (bf16): gin = MaxPool3DGrad(idx, g[..., g_coff:g_coff+K] @ Wt); ctx from maxpool3d"""
+    x, C_, k, s, pad, out, idx = ctx
+    assert x.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and weights.C == C_
+    gin = torch.empty((*x.shape[:4], C_), dtype=x.dtype, device=x.device)
+    a = _pool_args(x, C_, k, s, pad, out, idx)
+    check(load().flk_maxpool3d_bwd_gemm(C.byref(a), ptr(g), g.shape[4], g_coff, weights.K, weights.handle, ptr(gin), C_, 0,
+                                        dtype_code(x.dtype), stream_ptr()))
+    return gin
+
+
 I3D_FOLD = 3   # space-to-depth layout the I3D plan (flk_net, FLK_NET_I3D) expects: chunk-aligned (t,h,w) fold
 
 

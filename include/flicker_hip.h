@@ -137,6 +137,18 @@ int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int gout_ld, int
                       void* gin, int gin_ld, int gin_coff,
                       const void* mask, int mask_ld, int mask_coff, int dtype, void* stream);
 
+/* Branch_3 backward of an Inception block in ONE kernel (i3d.py:211-216 backward; bf16 only): the data-gradient of the 1x1x1 unit that
+ * follows the stride-1 3x3x3 max-pool is computed on MFMA inside the pool's scatter backward,
+ *   gin[cell, c] = sum_{windows w whose saved argmax for channel c is cell} ( sum_k g[w, k] * Wt[k, c] ),
+ * instead of flk_conv3d (transposed 1x1x1) -> HBM -> flk_maxpool3d_bwd.  `a` describes the FORWARD pool (a->C = C channels, a->idx its
+ * argmax bytes); g: [B,To,Ho,Wo,g_ld] gradient of the unit's pre-ReLU output (K = 32, 64, 96 or 128 channels at g_coff); wpack: from
+ * flk_pool_gemm_weights_create(Wt [K][C] = unit weight transposed x batch-norm scale).  Products stay in fp32 (no bf16 rounding of the
+ * intermediate), the scatter sums in 32-bit fixed point like flk_maxpool3d_bwd: bitwise reproducible. */
+int flk_pool_gemm_weights_create(const float* wt_kc, int K, int C, void** out_dev);
+int flk_pool_gemm_weights_destroy(void* dev);
+int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int g_ld, int g_coff, int K, const void* wpack,
+                           void* gin, int gin_ld, int gin_coff, int dtype, void* stream);
+
 /* Perturbation apply fused with the stem's space-to-depth staging.
  * kinetics_i3d_utils.py:100-142:  x_adv = clip(x + a * clip(delta[t,c], +-dclip), lo, hi)
  * model.py:80-101 (torch dialect): same with delta/std[c] and scalar clamp bounds.

@@ -249,6 +249,33 @@ def test_maxpool_fwd_bwd(ops, dtype, k, s, dims):
     torch.testing.assert_close(nomask, masked, rtol=1e-5, atol=1e-6 * float(g.abs().max()))
 
 
+@pytest.mark.parametrize("dims,C_,K", [((4, 14, 14), 72, 64), ((3, 7, 9), 32, 32), ((4, 7, 7), 832, 128), ((5, 11, 6), 96, 96)])
+def test_maxpool_bwd_gemm_fused(ops, dims, C_, K):
+    """flk_maxpool3d_bwd_gemm (Branch_3 backward of an Inception block in one kernel, i3d.py:211-216 backward): gin =
+    MaxPool3DGrad(idx, g @ Wt) against (a) torch-CPU autograd of max_pool3d fed the fp32 product -- the kernel keeps the product in
+    fp32, so only the bf16 rounding of the stored gin separates them -- and (b) the two-launch chain it replaces (1x1x1 data-gradient ->
+    bf16 -> scatter), at bf16 tolerance; two runs give the same bits (integer LDS atomics)."""
+    dtype = torch.bfloat16
+    B = 2
+    T, H, W = dims
+    x = torch.relu(q(rnd((B, T, H, W, C_), 31), dtype))
+    xr = cf(x).requires_grad_(True)
+    yr = F.max_pool3d(F.pad(xr, [1, 1, 1, 1, 1, 1], value=float("-inf")), (3, 3, 3), (1, 1, 1))
+    out, idx, ctx = ops.maxpool3d(x.to(dtype).cuda(), (3, 3, 3), (1, 1, 1))
+    g = q(rnd((B, T, H, W, K + 8), 32), dtype)                       # the gradient lives at channel offset 8 of a wider buffer
+    wt = q(rnd((K, C_), 33, 0.2), dtype)                             # Wt[k][c], bf16-representable
+    gpl = (g[..., 8:8 + K].reshape(-1, K) @ wt).reshape(B, T, H, W, C_)          # fp32 product
+    (gr,) = torch.autograd.grad(yr, xr, cf(gpl))
+    gref = cl(gr)
+    wp = ops.PoolGemmWeights(wt.numpy())
+    gin = ops.maxpool3d_bwd_gemm(ctx, g.to(dtype).cuda(), wp, g_coff=8)
+    r, a = tol(dtype, gref)
+    torch.testing.assert_close(gin.float().cpu(), gref, rtol=r, atol=a)
+    assert torch.equal(gin, ops.maxpool3d_bwd_gemm(ctx, g.to(dtype).cuda(), wp, g_coff=8))
+    chain = ops.maxpool3d_bwd(ctx, gpl.to(dtype).cuda())              # the two-launch form: the product rounded to bf16 first
+    torch.testing.assert_close(gin.float().cpu(), chain.float().cpu(), rtol=2e-2, atol=2e-2 * float(gref.abs().max()))
+
+
 BLOCKS = {"small": (1, 2, 7, 7, 64, (32, 24, 48, 16, 32, 16)),
           "Mixed_5c": (1, 2, 7, 7, 832, (384, 192, 384, 48, 128, 128)),
           "Mixed_3b": (1, 4, 28, 28, 192, (64, 96, 128, 16, 32, 32)),
