@@ -116,6 +116,7 @@ _SIGS = {
     "flk_comm_destroy": (C.c_int, [C.c_void_p]),
     "flk_net_has_forward_flicker": (C.c_int, [C.c_void_p]),
     "flk_net_forward_flicker": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p]),
+    "flk_net_forward_apply": (C.c_int, [C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_stem_delta_bias_weights_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "flk_stem_delta_bias": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_net_has_backward_delta": (C.c_int, [C.c_void_p]),

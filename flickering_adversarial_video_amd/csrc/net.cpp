@@ -107,6 +107,19 @@ struct flk_net {
   float* d_stem_tab = nullptr;
   const float* cur_pos_bias = nullptr;
   int64_t cur_pos_bias_bstride = 0;
+  const flk_apply_args* cur_apply = nullptr;      // flk_net_forward_apply: the stem operators apply their batch slice first
+  // the perturbation apply of clips [b0, b0 + nb) into the plan's input tensor, on stream s (no-op outside flk_net_forward_apply)
+  int apply_slice(int b0, int nb, void* dst, hipStream_t s) const {
+    if (!cur_apply) return FLK_OK;
+    flk_apply_args sl = *cur_apply;
+    sl.x = (const char*)sl.x + (size_t)b0 * sl.T * sl.H * sl.W * 3 * (sl.x_is_u8 ? 1 : 4);
+    sl.B = nb;
+    if (sl.delta_per_clip) {
+      sl.delta += (size_t)b0 * sl.T * 3;
+      if (sl.dclip_dev) sl.dclip_dev += b0;
+    }
+    return flk_perturb_apply_s2d(&sl, dst, dtype, s);
+  }
   // head
   float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
   // profiling
@@ -388,6 +401,7 @@ int flk_net::build_i3d() {
       const int b0 = bs_b0;
       fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * stem_macs, conv_bytes(a), [this, a, wf, dt, in_off, b0](hipStream_t s) mutable {
                          a.in = (const char*)x_in + in_off;
+                         if (int rc = apply_slice(b0, a.B, (char*)x_in + in_off, s)) return rc;
                          a.pos_bias_bstride = cur_pos_bias_bstride;
                          a.pos_bias = cur_pos_bias ? cur_pos_bias + (size_t)b0 * cur_pos_bias_bstride : nullptr;   // flk_net_forward_flicker: the perturbation enters here, in fp32
                          return flk_conv3d(&a, wf, dt, s);
@@ -814,7 +828,11 @@ int flk_net::build_videoresnet() {
     const double macs = (double)B * T * H2 * W2 * skt * 49.0 * 3 * sc_out;
     flk_conv_weights* wf = stem->wf;
     const int dt = dtype;
-    fwd.push_back(Op{"stem.0", K_CONV, 2.0 * macs, conv_bytes(a), [this, a, wf, dt](hipStream_t s) mutable { a.in = x_in; return flk_conv3d(&a, wf, dt, s); }});
+    fwd.push_back(Op{"stem.0", K_CONV, 2.0 * macs, conv_bytes(a), [this, a, wf, dt](hipStream_t s) mutable {
+                       a.in = x_in;
+                       if (int rc = apply_slice(0, a.B, (void*)x_in, s)) return rc;
+                       return flk_conv3d(&a, wf, dt, s);
+                     }});
     const ConvLayer::BwdClass bc = stem->bcls[0];
     flk_conv_args g{};
     g.in = G_st.p; g.in_ld = G_st.ld; g.cin = stem->cout; g.B = B; g.Ti = T; g.Hi = H2; g.Wi = W2;
@@ -1116,6 +1134,17 @@ extern "C" int flk_net_forward_flicker(flk_net* n, const void* x_in, const flk_a
   rc = flk_net_forward(n, x_in, logits, 1, stream);
   n->cur_pos_bias = nullptr;
   n->cur_pos_bias_bstride = 0;
+  return rc;
+}
+
+extern "C" int flk_net_forward_apply(flk_net* n, const flk_apply_args* a, void* x_s2d_out, float* logits, void* stream) {
+  FLK_REQUIRE(n && n->finalized && a && x_s2d_out && logits, "flk_net_forward_apply: bad argument / not finalized");
+  FLK_REQUIRE(a->B == n->B && a->T == n->T && a->H == n->H && a->W == n->W, "flk_net_forward_apply: apply args (%d,%d,%d,%d) do not match the "
+              "net (%d,%d,%d,%d)", a->B, a->T, a->H, a->W, n->B, n->T, n->H, n->W);
+  FLK_REQUIRE(a->fold_t == (n->arch == FLK_NET_I3D ? 3 : 1), "flk_net_forward_apply: fold_t %d is not this plan's input layout", a->fold_t);
+  n->cur_apply = a;
+  const int rc = a->center ? flk_net_forward_flicker(n, x_s2d_out, a, logits, stream) : flk_net_forward(n, x_s2d_out, logits, 1, stream);
+  n->cur_apply = nullptr;
   return rc;
 }
 

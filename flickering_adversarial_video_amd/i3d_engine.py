@@ -16,6 +16,9 @@ import torch
 from . import ops, parallel
 from ._lib import FLK_NET_I3D
 
+import os
+
+_APPLY_INSIDE = os.environ.get("FLK_APPLY_INSIDE", "1") != "0"
 NUM_CLASSES = 400          # kinetics_i3d_utils.py:19
 SAMPLE_VIDEO_FRAMES = 90   # kinetics_i3d_utils.py:12 (reference default; the benchmark shape is 64)
 IMAGE_SIZE = 224           # kinetics_i3d_utils.py:9
@@ -184,7 +187,11 @@ class FlickerI3D:
                                    shift_x=sx, shift_p=sp, fold_t=ops.I3D_FOLD, center=self.exact_delta_forward)
 
     def _forward(self, a):
-        """apply + network forward into self._logits"""
+        """apply + network forward into self._logits: one call -- the plan applies each half of the batch on the stream that half's
+        stem convolution runs on, so the second half's apply overlaps the first half's stem (FLK_APPLY_INSIDE=0: apply first, then
+        forward -- the round-2 order; same results)"""
+        if _APPLY_INSIDE:
+            return self.net.forward_apply(a, self._xs2d, self._logits)
         ops.perturb_apply_s2d(a, self.dtype, self._xs2d)
         if a.center:
             return self.net.forward_flicker(self._xs2d, a, self._logits)

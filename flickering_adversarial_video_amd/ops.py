@@ -414,6 +414,15 @@ class Net:
         check(load().flk_net_forward_flicker(self.handle, ptr(x_in), C.byref(apply_args), ptr(logits), stream_ptr()))
         return logits
 
+    def forward_apply(self, apply_args, x_s2d, logits=None):
+        """perturbation apply + forward in one call: the plan applies each batch slice on the stream its stem convolution runs on
+        (x_s2d receives the space-to-depth clip, as perturb_apply_s2d would have written it)"""
+        if logits is None:
+            logits = torch.empty((self.B, self.num_classes), dtype=torch.float32, device=x_s2d.device)
+        assert x_s2d.is_contiguous() and x_s2d.numel() == self.input_numel and dtype_code(x_s2d.dtype) == self.dtype
+        check(load().flk_net_forward_apply(self.handle, C.byref(apply_args), ptr(x_s2d), ptr(logits), stream_ptr()))
+        return logits
+
     def backward(self, dlogits, gx=None):
         if gx is None:
             gx = torch.empty(self.input_numel, dtype=torch_dtype(self.dtype), device="cuda")

@@ -153,6 +153,22 @@ static void plan(int arch, int dtype, int B, int T, int HW, const std::map<std::
     EXPECT(flk_perturb_apply_s2d(&a, x.data(), FLK_BF16, nullptr) == FLK_OK, "%s apply", tag);
     EXPECT(flk_net_forward_flicker(n, x.data(), &a, lg.data(), nullptr) == FLK_OK, "%s forward_flicker", tag);
     EXPECT(flk_net_backward_delta(n, dl.data(), &a, gd.data(), scratch.data(), nullptr) == FLK_OK, "%s backward_delta", tag);
+    EXPECT(flk_net_forward_apply(n, &a, x.data(), lg.data(), nullptr) == FLK_OK, "%s forward_apply (apply inside the plan, per batch slice)", tag);
+    {   // per-clip perturbations: one delta, one position-bias table and one clamp bound per clip
+      std::vector<float> dpc((size_t)B * T * 3, 0.02f), gpc((size_t)B * T * 3), bounds(B, 0.3f);
+      flk_apply_args pc = a; pc.delta = dpc.data(); pc.delta_per_clip = 1; pc.dclip_dev = bounds.data();
+      EXPECT(flk_net_forward_apply(n, &pc, x.data(), lg.data(), nullptr) == FLK_OK, "%s forward_apply per clip", tag);
+      EXPECT(flk_net_backward_delta(n, dl.data(), &pc, gpc.data(), scratch.data(), nullptr) == FLK_OK, "%s backward_delta per clip", tag);
+      std::vector<int> steps(B, 0), active(B, 1);
+      std::vector<float> m((size_t)B * T * 3, 0.f), v((size_t)B * T * 3, 0.f), sc((size_t)B * 8);
+      flk_adam_args ad{}; ad.T = T; ad.beta0 = 1.f; ad.beta1 = ad.beta2 = ad.beta3 = 0.5f; ad.lr = 1e-3f; ad.adam_b1 = 0.9f; ad.adam_b2 = 0.999f; ad.adam_eps = 1e-8f; ad.g_scale = 1.f;
+      EXPECT(flk_perturb_reg_adam_batched(&ad, B, gpc.data(), dpc.data(), m.data(), v.data(), steps.data(), active.data(), nullptr, sc.data(), nullptr) == FLK_OK,
+             "%s batched reg + Adam launch", tag);
+      EXPECT(flk_perturb_reg_adam_batched(&ad, 0, gpc.data(), dpc.data(), m.data(), v.data(), steps.data(), active.data(), nullptr, sc.data(), nullptr) == FLK_EINVAL,
+             "%s batched reg + Adam: bad clip count", tag);
+    }
+    flk_apply_args wrong = a; wrong.fold_t = 2;
+    EXPECT(flk_net_forward_apply(n, &wrong, x.data(), lg.data(), nullptr) == FLK_EINVAL, "%s forward_apply layout check", tag);
     flk_apply_args bad = a; bad.T = T + 2;
     EXPECT(flk_net_backward_delta(n, dl.data(), &bad, gd.data(), scratch.data(), nullptr) == FLK_EINVAL, "%s backward_delta geometry check", tag);
   }

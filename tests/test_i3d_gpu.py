@@ -763,3 +763,27 @@ def test_benchmark_geometry_bf16_vs_rounded_oracle():
     assert e_l < 5e-2 and e_loss < 5e-2
     assert cos > 0.88                            # measured 0.910
     assert g[5].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype,batch", [("bf16", 4), ("bf16", 1), ("f32", 2)])
+def test_forward_apply_equals_apply_then_forward(dtype, batch):
+    """flk_net_forward_apply (the plan launches the perturbation apply itself, per half of the batch on that half's stream) against
+    flk_perturb_apply_s2d followed by flk_net_forward[_flicker]: the space-to-depth clip and the logits are bitwise equal -- shared and
+    per-clip perturbations"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec, ops
+    from flickering_adversarial_video_amd._lib import FLK_NET_I3D
+    W = i3d_spec.synthetic_i3d_weights(42)
+    net = ops.Net(FLK_NET_I3D, dtype, batch, T, 224, 224, W)
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(batch, T, seed=8)).cuda()
+    rng = np.random.default_rng(1)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    for shape in ((T, 3), (batch, T, 3)):
+        d = torch.from_numpy(rng.uniform(-0.3, 0.3, shape).astype(np.float32)).cuda()
+        a = ops.make_apply_args(xu, d, fold_t=ops.I3D_FOLD, center=bool(net.has_forward_flicker))
+        x1 = ops.perturb_apply_s2d(a, dtype, torch.empty((batch, T // 2, 112, 112, 32), dtype=tdt, device="cuda"))
+        l1 = (net.forward_flicker(x1, a) if a.center else net.forward(x1)).clone()
+        x2 = torch.zeros_like(x1)
+        l2 = net.forward_apply(a, x2)
+        assert torch.equal(x1, x2) and torch.equal(l1, l2), shape
