@@ -5,7 +5,9 @@ import collections, csv, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r["Queue_Id"])) for r in rows)
-starts = [i for i, e in enumerate(ev) if "apply_s2d_u8" in e[2] or "apply_s2d_kernel" in e[2]]
+# a step ends with its reg_adam launch (the perturbation apply no longer marks its start: the plan launches one per half-batch)
+ends = [i for i, e in enumerate(ev) if "reg_adam" in e[2]]
+starts = [i + 1 for i in ends if i + 1 < len(ev)]
 
 
 def short(n):
@@ -18,7 +20,8 @@ def short(n):
     return n[:24]
 
 
-a, b = starts[-2], starts[-1]
+# the shortest span between consecutive step starts = a steady-state step (spans that cross the benchmark's barriers / read-backs are longer)
+a, b = min(zip(starts[:-1], starts[1:]), key=lambda ab: ev[ab[1]][0] - ev[ab[0]][0])
 step = ev[a:b]
 t0 = step[0][0]
 print("step: %.3f ms from its first kernel to the next step's first kernel, %d kernels" % ((ev[b][0] - t0) / 1e6, len(step)))
