@@ -124,6 +124,7 @@ struct flk_net {
   float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
   // profiling
   hipStream_t side[kSideStreams] = {nullptr, nullptr};
+  hipStream_t mask_stream = nullptr;   // the stem clip-mask pre-pass has a stream of its own: on a branch lane it delayed that lane's first kernels
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[kSideStreams] = {nullptr, nullptr};
   hipEvent_t ev_mask_fork = nullptr, ev_mask_done = nullptr;     // the stem clip-mask pre-pass runs beside the backward pass
   bool multi_stream = true;
@@ -1001,6 +1002,7 @@ extern "C" int flk_net_destroy(flk_net* n) {
     if (n->side[l]) (void)hipStreamDestroy(n->side[l]);
     if (n->ev_join[l]) (void)hipEventDestroy(n->ev_join[l]);
   }
+  if (n->mask_stream) (void)hipStreamDestroy(n->mask_stream);
   for (auto e : n->ev_fork) if (e) (void)hipEventDestroy(e);
   if (n->ev_mask_fork) (void)hipEventDestroy(n->ev_mask_fork);
   if (n->ev_mask_done) (void)hipEventDestroy(n->ev_mask_done);
@@ -1045,6 +1047,7 @@ extern "C" int flk_net_finalize(flk_net* n) {
     FLK_CHECK_HIP(hipStreamCreateWithPriority(&n->side[l], hipStreamNonBlocking, high ? prio_hi : 0));
     FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_join[l], evf));
   }
+  FLK_CHECK_HIP(hipStreamCreateWithFlags(&n->mask_stream, hipStreamNonBlocking));
   for (auto& e : n->ev_fork) FLK_CHECK_HIP(hipEventCreateWithFlags(&e, evf));
   FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_fork, evf));
   FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_done, evf));
@@ -1185,13 +1188,15 @@ extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const fl
   // right in front of the GEMM that consumes it (serial mode: inline)
   // (per-layer profiling is serial: the mask pre-pass then runs inline, inside the stem slot it belongs to, instead of stretching the
   // first backward operators it would otherwise run beside)
-  const bool beside = n->multi_stream && n->side[0] && !n->profile;
+  // (its own stream: on side stream 0 -- an in-order queue -- the 0.19 ms pre-pass held back Branch_2's first data-gradients, and with
+  // them the first joins of the backward pass, profiles/r3m_timeline.txt: 6.82 -> 6.79 ms per step)
+  const bool beside = n->multi_stream && n->mask_stream && !n->profile;
   if (beside) {
     FLK_CHECK_HIP(hipEventRecord(n->ev_mask_fork, s));
-    FLK_CHECK_HIP(hipStreamWaitEvent(n->side[0], n->ev_mask_fork, 0));
-    int rc = flk_stem_delta_grad_mask(&ac, partials, n->side[0]);
+    FLK_CHECK_HIP(hipStreamWaitEvent(n->mask_stream, n->ev_mask_fork, 0));
+    int rc = flk_stem_delta_grad_mask(&ac, partials, n->mask_stream);
     if (rc) return rc;
-    FLK_CHECK_HIP(hipEventRecord(n->ev_mask_done, n->side[0]));
+    FLK_CHECK_HIP(hipEventRecord(n->ev_mask_done, n->mask_stream));
   }
   const std::function<int(hipStream_t)> fused = [n, ac, gdelta, partials, beside](hipStream_t st) {
     if (beside) FLK_CHECK_HIP(hipStreamWaitEvent(st, n->ev_mask_done, 0));
