@@ -214,3 +214,16 @@ def test_r2plus1d_single_video_statistics_script(tmp_path):
     ra = np.load(files[0], allow_pickle=True).tolist()
     assert len(ra["loss/total"]) >= 3 and ra["perturbation"][0].shape == (3, T, 1, 1) and ra["prob_clean_input"].shape == (1, 400)
     assert np.load(files[1], allow_pickle=True).tolist() is None
+    # the same videos two at a time (--batch 2: per-clip perturbations / clamp bounds / Adam states, model.py:791-982 batched): the
+    # same files with bitwise-equal trajectories (fp32; fresh optimiser state per video in both runs)
+    for tag, extra in (("one", []), ("two", ["--batch", "2"])):
+        cmd2 = cmd[:cmd.index("--results-root") + 1] + [str(tmp_path / tag)] + cmd[cmd.index("--results-root") + 2:] + ["--reset-optimizer-per-video"] + extra
+        r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=600)
+        assert r2.returncode == 0, r2.stdout + r2.stderr
+    fa = sorted(glob.glob(str(tmp_path / "one" / "r3d_18" / "single_video_attack" / "flickering" / "*" / "*.npy")))
+    fb = sorted(glob.glob(str(tmp_path / "two" / "r3d_18" / "single_video_attack" / "flickering" / "*" / "*.npy")))
+    assert [os.path.basename(f) for f in fa] == [os.path.basename(f) for f in fb] == [os.path.basename(f) for f in files]
+    a, b = np.load(fa[0], allow_pickle=True).tolist(), np.load(fb[0], allow_pickle=True).tolist()
+    assert a["loss/total"] == b["loss/total"] and a["is_adversarial"] == b["is_adversarial"]
+    assert all(np.array_equal(p_, q_) for p_, q_ in zip(a["perturbation"], b["perturbation"]))
+    assert np.load(fb[1], allow_pickle=True).tolist() is None
