@@ -286,3 +286,59 @@ def test_fit_many_videos_batched_equals_one_by_one(tmp_path):
         fa = np.load(tmp_path / "one" / f"{k}_@{lab[int(k[3])]}.npy", allow_pickle=True).tolist()
         fb = np.load(tmp_path / "two" / f"{k}_@{lab[int(k[3])]}.npy", allow_pickle=True).tolist()
         assert fa["restarts"] == fb["restarts"] and np.array_equal(fa["prob_clean_input"], fb["prob_clean_input"])
+
+
+def test_per_clip_engine_odd_clip_length_fp32():
+    """the reference's clip lengths give odd intermediate sizes (T = 90 -> 45, 23, 12; here T = 18 -> 9, 5, 3): temporal SAME paddings
+    with a pad-before and the fallback pool kernels.  Per-clip batch of 2 vs single runs, fp32, 2 iterations: bitwise"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    Tn, B = 18, 2
+    W = i3d_spec.synthetic_i3d_weights(42)
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(B, Tn, seed=5)).cuda()
+    engB = FlickerI3D(W, batch_size=B, frames=Tn, dtype="f32", per_clip_delta=True)
+    eng1 = FlickerI3D(W, batch_size=1, frames=Tn, dtype="f32")
+    labels = engB.logits(xu, adv_flag=0.0).argmax(-1).clone()
+    ref = []
+    for b in range(B):
+        eng1.reset_perturbation()
+        for _ in range(2):
+            eng1.step(xu[b:b + 1].contiguous(), labels[b:b + 1].contiguous(), **HP)
+        ref.append((eng1.eps_rgb.clone(), eng1._logits.clone()))
+    for _ in range(2):
+        engB.step(xu, labels, **HP)
+    for b in range(B):
+        assert torch.equal(engB.eps_rgb[b], ref[b][0]) and torch.equal(engB._logits[b], ref[b][1][0]), b
+
+
+def test_per_clip_r2plus1d_bf16_tracks_single_runs():
+    """BASELINE config 3's architecture and dtype in per-clip mode: 3 clips with different perturbations and clamp bounds against each
+    clip alone (the batch-1 and batch-3 plans choose different split-K layouts): logits 2e-2 of the largest logit, adversarial loss
+    2e-2, delta-gradient cosine > 0.97 (measured 2e-3, 5e-3, 0.987)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import videoresnet_spec as vs
+    from flickering_adversarial_video_amd.torch_attack import Losses
+    B, Tn, HW = 3, 8, 64
+    engB, eng1 = _vrn("bf16", B, True, arch="r2plus1d_18"), _vrn("bf16", 1, False, arch="r2plus1d_18")
+    x = torch.from_numpy(vs.synthetic_clip(B, Tn, HW, HW, seed=9)).cuda()
+    labels = engB.logits(x).argmax(-1).clone()
+    rng = np.random.default_rng(12)
+    d0 = [rng.uniform(-0.15, 0.15, (3, Tn, 1, 1)).astype(np.float32) for _ in range(B)]
+    bounds = [0.2, 0.1, 0.26]
+    crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)
+    for b in range(B):
+        engB.pert_model.init_clip(b, d0[b], max_norm=bounds[b])
+    r = engB.step(x, labels, crit, update=False)
+    for b in range(B):
+        eng1.pert_model.init_perturbation(d0[b])
+        eng1.pert_model.dynamic_max_norm = bounds[b]
+        r1 = eng1.step(x[b:b + 1].contiguous(), labels[b:b + 1].contiguous(), crit, update=False)
+        g1 = eng1._red[:3 * Tn]
+        e_l = float((engB._logits[b] - eng1._logits[0]).abs().max() / eng1._logits[0].abs().max())
+        e_a = abs(float(r["adv_loss"][b]) - float(r1["adv_loss"])) / max(abs(float(r1["adv_loss"])), 1e-6)
+        cos = float(torch.nn.functional.cosine_similarity(engB._gclip[b].flatten(), g1.flatten(), 0))
+        print(f"clip {b}: logits {e_l:.2e}, adversarial loss {e_a:.2e}, gradient cosine {cos:.5f}")
+        assert e_l < 2e-2 and e_a < 2e-2 and cos > 0.97
