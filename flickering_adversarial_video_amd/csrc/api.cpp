@@ -28,7 +28,7 @@ int flk_conv_weights_create_impl(const float* w, int kt, int kh, int kw, int cin
                                  flk_conv_weights** out) {
   FLK_REQUIRE(w && out, "flk_conv_weights_create: null argument");
   FLK_REQUIRE(dtype == FLK_F32 || dtype == FLK_BF16, "flk_conv_weights_create: bad dtype %d", dtype);
-  FLK_REQUIRE(nf == 2 || nf == 4 || nf == 8, "flk_conv_weights_create: nf must be 2, 4 or 8 (got %d)", nf);
+  FLK_REQUIRE(nf == 2 || nf == 4 || nf == 8 || (nf == 6 && dtype == FLK_BF16), "flk_conv_weights_create: nf must be 2, 4, 8 (or 6 in bf16: 96-channel tiles) (got %d)", nf);
   FLK_REQUIRE(kt > 0 && kh > 0 && kw > 0 && cin > 0 && cout > 0, "flk_conv_weights_create: bad shape");
   const int ocin = transpose ? cout : cin;    // operator input channels (GEMM K per tap)
   const int ocout = transpose ? cin : cout;   // operator output channels

@@ -165,7 +165,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   typedef typename PR::frag frag;
   constexpr int EPL = PR::EPL;
   constexpr int SLABC = 4 * EPL;
-  constexpr int WCH = NF >= 4 ? NF / 4 : 1;   // 16-byte weight chunks per thread per (slab, tap)
+  constexpr int WCH = NF >= 4 ? (NF + 3) / 4 : 1;   // 16-byte weight chunks per thread per (slab, tap)
+  // NF = 6 (96-channel tiles): the step's 6 KiB are 384 chunks -- threads 0..127 move a second one, the others re-read their first
+  // (a valid address) and do not store it
+  const bool w2ok = NF % 4 == 0 || threadIdx.x + 256 < NF * 64;
+  const int w2off = w2ok ? 4096 : 0;
   constexpr int WM = 4 / WN, NFW = NF / WN;   // waves along M; channel fragments per wave
   static_assert(NF % WN == 0 && 4 * NFW >= EPL, "wave tile too narrow for 16-byte epilogue groups");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     const int wchunk = NF >= 4 ? tid : (tid & 127);
     const char* wsrc = wbase + (size_t)ntile * NF * 1024 + wchunk * 16;
     uint4 wreg0 = *(const uint4*)wsrc, wreg1 = make_uint4(0, 0, 0, 0);   // named scalars: an array here is demoted to scratch
-    if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+    if (WCH == 2) wreg1 = *(const uint4*)(wsrc + w2off);
     wsrc += wstep;
 
     int it_w = 0;
@@ -329,11 +333,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
           for (int dw = 0; dw < p.kw; ++dw, tapoff += 16) {
             char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
             *(uint4*)(wcur + wchunk * 16) = wreg0;
-            if (WCH == 2) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
+            if (WCH == 2 && w2ok) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
             ++it_w;
             if (it_w < nsteps) {
               wreg0 = *(const uint4*)wsrc;
-              if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+              if (WCH == 2) wreg1 = *(const uint4*)(wsrc + w2off);
               wsrc += wstep;
             }
             __syncthreads();
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     const int wchunk = NF >= 4 ? tid : (tid & 127);
     const char* wsrc = p.w + (size_t)ntile * NF * 1024 + wchunk * 16;
     uint4 wreg0 = *(const uint4*)wsrc, wreg1 = make_uint4(0, 0, 0, 0);
-    if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+    if (WCH == 2) wreg1 = *(const uint4*)(wsrc + w2off);
     wsrc += wstep;
     {
       const char* src; int ld;
@@ -396,11 +400,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         for (int dw = 0; dw < 4; dw += wstride, tapoff += wstride * 16) {
           char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
           *(uint4*)(wcur + wchunk * 16) = wreg0;
-          if (WCH == 2) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
+          if (WCH == 2 && w2ok) *(uint4*)(wcur + wchunk * 16 + 4096) = wreg1;
           ++it_w;
           if (it_w < nsteps) {
             wreg0 = *(const uint4*)wsrc;
-            if (WCH == 2) wreg1 = *(const uint4*)(wsrc + 4096);
+            if (WCH == 2) wreg1 = *(const uint4*)(wsrc + w2off);
             wsrc += wstep;
           }
           __syncthreads();
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       ws = ws < wlast ? ws : wlast;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[0]) : "v"(ws) : "memory");
       if constexpr (WCH == 2) {
-        const char* ws1 = ws + 4096;                                    // (beyond the 13-bit immediate offset)
+        const char* ws1 = ws + w2off;                                   // (beyond the 13-bit immediate offset)
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[1]) : "v"(ws1) : "memory");
       }
     };
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         }
         char* const wcur = wbuf + (kk & 1) * (NF * 1024);
         *(u32x4*)(wcur + wchunk * 16) = w2[0];
-        if (WCH == 2) *(u32x4*)(wcur + wchunk * 16 + 4096) = w2[1];
+        if (WCH == 2 && w2ok) *(u32x4*)(wcur + wchunk * 16 + 4096) = w2[1];
         // unconditional (clamped past the end): every queue register has ONE definition per step on every path, so the
         // compiler has no reason to copy a register whose load is still in flight (tools/audit_asm_loads.py checks this)
         wload(w2, kk + 2);
@@ -818,7 +822,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   const int max_rows = (w->stem4 || nf == 2) ? 192 : FLK_ROWS;
   flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, max_rows, max_halo);
   {
-    const int wn_max = dtype == FLK_BF16 ? nf / 2 : nf;      // NFW >= 2 (bf16) / 1 (fp32)
+    const int wn_max = nf == 6 ? 1 : dtype == FLK_BF16 ? nf / 2 : nf;      // NFW >= 2 (bf16) / 1 (fp32); 96-channel tiles: ring kernels, wn = 1 only
     static const char* force_env = getenv("FLK_CONV_WN");
     const int force = force_wn > 0 ? force_wn : force_env ? atoi(force_env) : 0;
     while (true) {
@@ -883,11 +887,11 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   int mode = 0;
   {
     static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
-    const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);
+    const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);      // (nf = 6 is never narrow)
     const bool k1 = kp.ntaps == 1 && kp.P <= 256;
     // direct A needs <= 4 fragments per wave (and >= 2 in bf16); the ring kernels are instantiated for wn == 1 only
     const int nfw = nf / wn;
-    const bool da_ok = nfw <= 4 && (dtype != FLK_BF16 || nfw >= 2), ring_ok = wn == 1;
+    const bool da_ok = nf != 6 && nfw <= 4 && (dtype != FLK_BF16 || nfw >= 2), ring_ok = wn == 1;
     bool da = wn >= 2 || narrow_small;
     if (force_da == 0 && ring_ok) da = false;
     if (force_da == 1 && da_ok) da = true;
@@ -929,7 +933,7 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
     if (mode == 4 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 4>(kp, grid, lds, s);
-    FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1);
+    FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1); FLK_LAUNCH0(bf16_t, 6, 1);
     FLK_LAUNCHD(bf16_t, 2, 1); FLK_LAUNCHD(bf16_t, 4, 1); FLK_LAUNCHD(bf16_t, 4, 2);
     FLK_LAUNCHD(bf16_t, 8, 2); FLK_LAUNCHD(bf16_t, 8, 4);
   } else if (dtype == FLK_F32) {
@@ -962,14 +966,14 @@ extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int
   hipEvent_t e0, e1;
   FLK_CHECK_HIP(hipEventCreate(&e0));
   FLK_CHECK_HIP(hipEventCreate(&e1));
-  const int nf = w->nf, wn_max = dtype == FLK_BF16 ? nf / 2 : nf;
+  const int nf = w->nf, wn_max = nf == 6 ? 1 : dtype == FLK_BF16 ? nf / 2 : nf;
   struct Cand { int wn, da; };
   std::vector<Cand> cands;
   cands.push_back({0, -1});                                       // the heuristic's choice
   for (int wn = 1; wn <= 4 && wn <= (wn_max < 1 ? 1 : wn_max); wn *= 2) {
     const int nfw = nf / wn;
     if (wn == 1) cands.push_back({1, 0});
-    if (nfw <= 4 && (dtype != FLK_BF16 || nfw >= 2)) cands.push_back({wn, 1});
+    if (nf != 6 && nfw <= 4 && (dtype != FLK_BF16 || nfw >= 2)) cands.push_back({wn, 1});
   }
   float best_ms = 1e30f;
   Cand best = cands[0];

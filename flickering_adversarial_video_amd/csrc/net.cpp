@@ -65,16 +65,22 @@ inline void same_pad(int n, int k, int s, int& out, int& before) {
   before = tot / 2;
 }
 
-int choose_nf(int cout, int taps) {
+// nf6: 96-channel tiles (bf16 ring kernels, wn = 1 only: launches with >= 256 position tiles) are a candidate -- they remove the padding
+// of 96- and 176-channel outputs (25 % of the MFMAs of a 96-channel layer in a 128-wide tile).  Measured per layer (bs 8): they win
+// where they replace a padded 128-wide tile (Mixed_3b/Branch_1 data-gradient, N = 96: 0.177 -> 0.165 ms; 3b fused GEMM, N = 176:
+// 0.075 -> 0.068; 3c/Branch_2, N = 96: 0.067 -> 0.060) and LOSE against three exact 64-wide tiles (Conv3d_2c, N = 192: 0.510 ->
+// 0.588 ms) -- hence the 1.15 weight, which keeps N = 192 on nf = 4
+int choose_nf(int cout, int taps, bool nf6 = false) {
   int best = 8;
   double best_cost = 1e30;
-  const int cand[3] = {8, 4, 2};
+  const int cand[4] = {8, 6, 4, 2};
   for (int nf : cand) {
+    if (nf == 6 && !nf6) continue;
     const int padded = (cout + 16 * nf - 1) / (16 * nf) * (16 * nf);
     const int ntiles = padded / (16 * nf);
     // MFMA work ~ padded*taps (narrow tiles re-read the activation fragments more often per MFMA);
     // every extra N tile re-stages the halo
-    const double cost = (double)padded * taps * (nf == 2 ? 1.35 : nf == 4 ? 1.1 : 1.0) + 64.0 * ntiles;
+    const double cost = (double)padded * taps * (nf == 2 ? 1.35 : nf == 4 ? 1.1 : nf == 6 ? 1.15 : 1.0) + 64.0 * ntiles;
     if (cost < best_cost - 1e-9) { best_cost = cost; best = nf; }
   }
   return best;
@@ -198,13 +204,17 @@ struct flk_net {
     return FLK_OK;
   }
   // pack forward + data-gradient operators and upload the epilogue vectors
-  int pack(ConvLayer* L) {
+  // 96-channel tiles are candidates for launches of `rows` output positions that keep 256-row workgroups (>= 256 position tiles), bf16
+  bool nf6_ok(long rows) const {
+    return dtype == FLK_BF16 && rows >= 256L * 256 && !(getenv("FLK_NF6") && atoi(getenv("FLK_NF6")) == 0);
+  }
+  int pack(ConvLayer* L, long rows = 0) {
     const int taps = L->kt * L->kh * L->kw;
     int rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, nullptr, 0, dtype,
-                                          choose_nf(L->cout, taps), 0, &L->wf);
+                                          choose_nf(L->cout, taps, nf6_ok(rows)), 0, &L->wf);
     if (rc) return rc;
     rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, L->scale.data(), 1, dtype,
-                                      choose_nf(L->cin, taps), 0, &L->wb);
+                                      choose_nf(L->cin, taps, nf6_ok(rows)), 0, &L->wb);
     if (rc) return rc;
     if ((rc = upload(&L->d_scale, L->scale))) return rc;
     if ((rc = upload(&L->d_bias, L->bias))) return rc;
@@ -371,8 +381,9 @@ int flk_net::build_i3d() {
   stem_G = G1;
   // ---- Conv3d_2b_1x1, Conv3d_2c_3x3 and the buffers of the segment ----
   ConvLayer *c2b = nullptr, *c2c = nullptr;
-  if ((rc = make_unit3d("Conv3d_2b_1x1", 1, 1, 1, 64, 64, &c2b)) || (rc = pack(c2b))) return rc;
-  if ((rc = make_unit3d("Conv3d_2c_3x3", 3, 3, 3, 64, 192, &c2c)) || (rc = pack(c2c))) return rc;
+  const long rows2 = (long)(B >= 4 && B % 2 == 0 ? B / 2 : B) * T1 * (H1 / 2) * (W1 / 2);      // per launch (half-batches)
+  if ((rc = make_unit3d("Conv3d_2b_1x1", 1, 1, 1, 64, 64, &c2b)) || (rc = pack(c2b, rows2))) return rc;
+  if ((rc = make_unit3d("Conv3d_2c_3x3", 3, 3, 3, 64, 192, &c2c)) || (rc = pack(c2c, rows2))) return rc;
   Act p2a, Gp2a, a2b, G2b, a2c, G2c, p3a, Gp3a;
   // The segment up to Mixed_3b alternates MFMA-bound convolutions (Conv3d_1a, Conv3d_2c) with HBM-bound pools and a 1x1x1, one
   // kernel at a time.  With an even batch >= 4 it is emitted once per HALF of the batch, the halves on two streams: the pools of one
@@ -501,7 +512,8 @@ int flk_net::build_i3d() {
     const std::string b2name = bn == "Mixed_5b" ? "Conv3d_0a_3x3" : "Conv3d_0b_3x3";   // i3d.py:418
     if ((rc = make_unit3d(bn + "/Branch_0/Conv3d_0a_1x1", 1, 1, 1, cur_c, c0, &L0))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0a_1x1", 1, 1, 1, cur_c, c1a, &L1a))) return rc;
-    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0b_3x3", 3, 3, 3, c1a, c1b, &L1b)) || (rc = pack(L1b))) return rc;
+    const long rows_blk = (long)B * cur.T * cur.H * cur.W;
+    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0b_3x3", 3, 3, 3, c1a, c1b, &L1b)) || (rc = pack(L1b, rows_blk))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_2/Conv3d_0a_1x1", 1, 1, 1, cur_c, c2a, &L2a))) return rc;
     // The three 1x1x1 units reading the block input (i3d.py:197-207) run as ONE GEMM [b0 | b1a | b2a]: one launch, the
     // input read once; columns [0,c0) land in the concat buffer, the rest in `mid`.  Its data-gradient is one GEMM too,
@@ -525,14 +537,14 @@ int flk_net::build_i3d() {
       std::vector<float> wT((size_t)cf * cur_c);
       for (int ci = 0; ci < cur_c; ++ci)
         for (int k = 0; k < cf; ++k) wT[(size_t)k * cur_c + ci] = L->w[(size_t)ci * cf + k];
-      if ((rc = flk_conv_weights_create_impl(L->w.data(), 1, 1, 1, cur_c, cf, nullptr, 0, dtype, choose_nf(cf, 1), 0, &L->wf))) return rc;
-      if ((rc = flk_conv_weights_create_impl(wT.data(), 1, 1, 1, cf, cur_c, L->scale.data(), 0, dtype, choose_nf(cur_c, 1), c0, &L->wb))) return rc;
+      if ((rc = flk_conv_weights_create_impl(L->w.data(), 1, 1, 1, cur_c, cf, nullptr, 0, dtype, choose_nf(cf, 1, nf6_ok(rows_blk)), 0, &L->wf))) return rc;
+      if ((rc = flk_conv_weights_create_impl(wT.data(), 1, 1, 1, cf, cur_c, L->scale.data(), 0, dtype, choose_nf(cur_c, 1, nf6_ok(rows_blk)), c0, &L->wb))) return rc;
       if ((rc = upload(&L->d_scale, L->scale)) || (rc = upload(&L->d_bias, L->bias))) return rc;
       Lf = L.get();
       convs.push_back(std::move(L));
     }
-    if ((rc = make_unit3d(bn + "/Branch_2/" + b2name, 3, 3, 3, c2a, c2b_, &L2b)) || (rc = pack(L2b))) return rc;
-    if ((rc = make_unit3d(bn + "/Branch_3/Conv3d_0b_1x1", 1, 1, 1, cur_c, c3, &L3)) || (rc = pack(L3))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_2/" + b2name, 3, 3, 3, c2a, c2b_, &L2b)) || (rc = pack(L2b, rows_blk))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_3/Conv3d_0b_1x1", 1, 1, 1, cur_c, c3, &L3)) || (rc = pack(L3, rows_blk))) return rc;
     Act out, Gout, mid, Gmid, pl, Gpl, gxa;
     if ((rc = new_act(out, cur.T, cur.H, cur.W, cout_total)) || (rc = new_act(Gout, cur.T, cur.H, cur.W, cout_total))) return rc;
     if ((rc = new_act(mid, cur.T, cur.H, cur.W, c1a + c2a)) || (rc = new_act(Gmid, cur.T, cur.H, cur.W, c1a + c2a))) return rc;

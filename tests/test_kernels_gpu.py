@@ -67,6 +67,12 @@ CONV_CASES = [
     ("1x3x3_s2", 1, 4, 15, 16, 64, 144, (1, 3, 3), (1, 2, 2), 8),
     ("3x1x1_s2", 1, 9, 8, 8, 144, 64, (3, 1, 1), (2, 1, 1), 4),
     ("1x1x1_s2_ds", 1, 4, 14, 14, 64, 128, (1, 1, 1), (2, 2, 2), 8),
+    # 96-channel tiles (nf = 6, bf16 ring kernels only): two full tiles; one tile + a partial one; a 1x1x1 with >= 4 slabs (mode 3) and one
+    # with 2 (mode 0)
+    ("3x3x3_64_192_nf6", 2, 4, 14, 14, 64, 192, (3, 3, 3), (1, 1, 1), 6),
+    ("3x3x3_32_136_nf6", 1, 3, 7, 9, 32, 136, (3, 3, 3), (1, 1, 1), 6),
+    ("1x1x1_192_176_nf6", 2, 2, 28, 28, 192, 176, (1, 1, 1), (1, 1, 1), 6),
+    ("1x1x1_64_96_nf6", 1, 2, 14, 14, 64, 96, (1, 1, 1), (1, 1, 1), 6),
 ]
 
 
@@ -74,6 +80,8 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_forward(ops, case, dtype):
     _, B, T, H, W, cin, cout, k, s, nf = case
+    if nf == 6 and dtype != torch.bfloat16:
+        pytest.skip("96-channel tiles exist in bf16 only")
     x = q(rnd((B, T, H, W, cin), 1), dtype)
     w = q(rnd((*k, cin, cout), 2, (2.0 / (cin * k[0] * k[1] * k[2])) ** 0.5), dtype)
     og, pad = zip(*(ops.same_pad(n, kk, ss) for n, kk, ss in zip((T, H, W), k, s)))
@@ -191,9 +199,11 @@ def test_conv_epilogue_slices(ops, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("k,cin,cout,nf", [((3, 3, 3), 64, 96, 4), ((1, 1, 1), 256, 64, 8), ((4, 4, 4), 32, 64, 2),
-                                           ((3, 3, 3), 16, 48, 2)], ids=["3x3x3", "1x1x1", "4x4x4stem", "3x3x3_16"])
+                                           ((3, 3, 3), 16, 48, 2), ((3, 3, 3), 96, 128, 6)], ids=["3x3x3", "1x1x1", "4x4x4stem", "3x3x3_16", "3x3x3_nf6"])
 def test_conv_data_gradient(ops, dtype, k, cin, cout, nf):
     """transposed operator == torch autograd's conv3d backward-input (stride 1), BN scale folded"""
+    if nf == 6 and dtype != torch.bfloat16:
+        pytest.skip("96-channel tiles exist in bf16 only")
     B, T, H, W = 1, 4, 9, 10
     pad = tuple((kk - 1) // 2 for kk in k)
     w = q(rnd((*k, cin, cout), 11, 0.05), dtype)
