@@ -119,6 +119,8 @@ _SIGS = {
     "flk_net_forward_apply": (C.c_int, [C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_stem_delta_bias_weights_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "flk_stem_delta_bias": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_stem_fwd_u8_weights_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "flk_stem_fwd_u8": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_has_backward_delta": (C.c_int, [C.c_void_p]),
     "flk_net_backward_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_stem_delta_grad_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflicker_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "pool.hip", "head.hip", "attack.hip", "stem_grad.hip", "net.cpp", "comm.cpp"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "pool.hip", "head.hip", "attack.hip", "stem_grad.hip", "stem_fwd.hip", "net.cpp", "comm.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-x", "hip"]
 
@@ -36,7 +36,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + os.environ.get("FLK_HIPCC_EXTRA", "").split() + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

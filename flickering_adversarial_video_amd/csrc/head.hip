@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256) void softmax_adv_loss_kernel(const flk_loss_ar
   float P, Z; int mp, mz;
   block_argmax(bp, bpi, sv, si, P, mp);
   block_argmax(bz, bzi, sv, si, Z, mz);
+  // NaN logits never win a comparison, so the arg-max indices keep their "none" value: they must not index z[] (a NaN anywhere in
+  // the network -- corrupt weights -- would otherwise end in a memory fault here instead of in a NaN loss)
+  if ((unsigned)mp >= (unsigned)C) mp = 0;
+  if ((unsigned)mz >= (unsigned)C) mz = 0;
+  if ((unsigned)amax >= (unsigned)C) amax = 0;
   if (tid == 0) {
     const float zy = z[y], py = __expf(zy - zmax) * inv;
     const float Pm = __expf(z[mp] - zmax) * inv;   // p at the arg of the max (P may carry the TF "-1")

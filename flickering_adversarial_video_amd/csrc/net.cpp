@@ -115,8 +115,7 @@ struct flk_net {
   int64_t cur_pos_bias_bstride = 0;
   const flk_apply_args* cur_apply = nullptr;      // flk_net_forward_apply: the stem operators apply their batch slice first
   // the perturbation apply of clips [b0, b0 + nb) into the plan's input tensor, on stream s (no-op outside flk_net_forward_apply)
-  int apply_slice(int b0, int nb, void* dst, hipStream_t s) const {
-    if (!cur_apply) return FLK_OK;
+  flk_apply_args apply_args_slice(int b0, int nb) const {
     flk_apply_args sl = *cur_apply;
     sl.x = (const char*)sl.x + (size_t)b0 * sl.T * sl.H * sl.W * 3 * (sl.x_is_u8 ? 1 : 4);
     sl.B = nb;
@@ -124,7 +123,20 @@ struct flk_net {
       sl.delta += (size_t)b0 * sl.T * 3;
       if (sl.dclip_dev) sl.dclip_dev += b0;
     }
+    return sl;
+  }
+  int apply_slice(int b0, int nb, void* dst, hipStream_t s) const {
+    if (!cur_apply) return FLK_OK;
+    const flk_apply_args sl = apply_args_slice(b0, nb);
     return flk_perturb_apply_s2d(&sl, dst, dtype, s);
+  }
+  // I3D in bf16, flk_net_forward_apply on a uint8 clip with the centred flicker perturbation: the stem reads the clip itself
+  // (stem_fwd.hip: perturbation apply + 7x7x7 / 2 convolution in one kernel, 37 K steps instead of apply + 49); the space-to-depth
+  // tensor is then neither written nor read.  FLK_STEM_U8=0 (read per call): the two-kernel path.
+  flk_conv_weights* stem_u8_w = nullptr;
+  bool stem_from_u8() const {
+    return stem_u8_w && cur_apply && cur_pos_bias && cur_apply->x_is_u8 && cur_apply->center == 1 && !cur_apply->delta_dense &&
+           !(getenv("FLK_STEM_U8") && atoi(getenv("FLK_STEM_U8")) == 0);
   }
   // head
   float *d_fcw = nullptr, *d_fcb = nullptr, *d_wt = nullptr, *d_feat = nullptr, *d_dfeat = nullptr;
@@ -370,6 +382,7 @@ int flk_net::build_i3d() {
   if (dtype == FLK_BF16) {
     if ((rc = flk_stem_delta_grad_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_wf))) return rc;
     if ((rc = flk_stem_delta_bias_weights_create(stem7->w.data(), stem7->scale.data(), &d_stem_sums))) return rc;
+    if (H == 224 && W == 224 && (rc = flk_stem_fwd_u8_weights_create(stem7->w.data(), &stem_u8_w))) return rc;
     if ((rc = dmalloc((void**)&d_stem_tab, (size_t)B * (T / 2) * 16 * 64 * sizeof(float), true))) return rc;   // (one table per clip: per-clip perturbations)
   }
   const int T1 = T / 2, H1 = H / 2, W1 = W / 2;
@@ -413,9 +426,13 @@ int flk_net::build_i3d() {
       const int b0 = bs_b0;
       fwd.push_back(Op{"Conv3d_1a_7x7", K_CONV, 2.0 * stem_macs, conv_bytes(a), [this, a, wf, dt, in_off, b0](hipStream_t s) mutable {
                          a.in = (const char*)x_in + in_off;
-                         if (int rc = apply_slice(b0, a.B, (char*)x_in + in_off, s)) return rc;
                          a.pos_bias_bstride = cur_pos_bias_bstride;
                          a.pos_bias = cur_pos_bias ? cur_pos_bias + (size_t)b0 * cur_pos_bias_bstride : nullptr;   // flk_net_forward_flicker: the perturbation enters here, in fp32
+                         if (stem_from_u8()) {
+                           const flk_apply_args sl = apply_args_slice(b0, a.B);
+                           return flk_stem_fwd_u8(&sl, stem_u8_w, a.scale, a.bias, a.pos_bias, a.pos_bias_bstride, a.out, a.out_ld, s);
+                         }
+                         if (int rc = apply_slice(b0, a.B, (char*)x_in + in_off, s)) return rc;
                          return flk_conv3d(&a, wf, dt, s);
                        }});
     }
@@ -1020,6 +1037,7 @@ extern "C" int flk_net_destroy(flk_net* n) {
   if (n->ev_mask_done) (void)hipEventDestroy(n->ev_mask_done);
   flk_stem_delta_grad_weights_destroy(n->d_stem_wf);
   flk_stem_delta_grad_weights_destroy(n->d_stem_sums);
+  flk_conv_weights_destroy(n->stem_u8_w);
   for (void* p : n->allocs) (void)hipFree(p);
   for (void* p : n->pool_gemm_weights) flk_pool_gemm_weights_destroy(p);
   for (auto& L : n->convs) {

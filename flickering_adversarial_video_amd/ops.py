@@ -65,7 +65,7 @@ class ConvWeights:
 
 def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
            out_stride=(1, 1, 1), out_offset=(0, 0, 0), scale=None, bias=None, add=None, add_coff=0, mask=None,
-           mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0, splitk=False):
+           mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0, splitk=False, pos_bias=None):
     """x: [B,T,H,W,ld] channels-last; returns / fills out [B,OT,OH,OW,ld_out].  pad = pad-before per dim
     (default: TF SAME).  out_grid = logical output grid (default: SAME output size)."""
     B, Ti, Hi, Wi, in_ld = x.shape
@@ -95,6 +95,9 @@ def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, o
     if mask is not None:
         a.mask, a.mask_ld, a.mask_coff = ptr(mask), mask.shape[4], mask_coff
     a.relu = int(relu)
+    if pos_bias is not None:     # fp32 [1 or B, To, 4, 4, cout] position-class bias (flk_stem_delta_bias)
+        a.pos_bias = ptr(pos_bias)
+        a.pos_bias_bstride = pos_bias[0].numel() if pos_bias.shape[0] > 1 else 0
     if in2 is not None:
         a.in2, a.in2_ld, a.in2_coff, a.cin1 = ptr(in2), in2.shape[4], in2_coff, w.cin_split
     if out2 is not None:
@@ -253,6 +256,54 @@ def stem_delta_grad(args, G, weights, gdelta=None, scratch=None):
         scratch = torch.empty(max(1, load().flk_stem_delta_grad_scratch_bytes(args.B, args.T, args.H) // 4), dtype=torch.float32, device="cuda")
     check(load().flk_stem_delta_grad(C.byref(args), ptr(G), G.shape[4], weights.handle, ptr(gdelta), ptr(scratch), 0, stream_ptr()))
     return gdelta
+
+
+class StemFwdU8Weights:
+    """MFMA fragments of flk_stem_fwd_u8 from the canonical stem weights [7,7,7,3,64] (37 K steps x 2 column parities)"""
+
+    def __init__(self, w7_dhwio):
+        w = np.ascontiguousarray(w7_dhwio, dtype=np.float32)
+        assert w.shape == (7, 7, 7, 3, 64)
+        h = C.c_void_p()
+        check(load().flk_stem_fwd_u8_weights_create(ptr(w), C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().flk_conv_weights_destroy(self.handle)
+                self.handle = None
+        except Exception:      # interpreter shutdown
+            pass
+
+
+def stem_delta_bias_table(args, w7_dhwio, bn_scale):
+    """position-class bias table of the stem for the perturbation of `args` (flk_stem_delta_bias): fp32 [1 or B, T/2, 4, 4, 64]"""
+    w = np.ascontiguousarray(w7_dhwio, dtype=np.float32)
+    sc = np.ascontiguousarray(bn_scale, dtype=np.float32)
+    h = C.c_void_p()
+    check(load().flk_stem_delta_bias_weights_create(ptr(w), ptr(sc), C.byref(h)))
+    try:
+        tab = torch.zeros((args.B if args.delta_per_clip else 1, args.T // 2, 4, 4, 64), dtype=torch.float32, device="cuda")
+        check(load().flk_stem_delta_bias(C.byref(args), h, ptr(tab), stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        load().flk_stem_delta_grad_weights_destroy(h)
+    return tab
+
+
+def stem_fwd_u8(args, weights, bn_scale, bn_bias, pos_bias=None, out=None):
+    """Conv3d_1a_7x7 + batch norm + ReLU straight from the uint8 clip of `args` (center = 1): bf16 [B,T/2,112,112,64]"""
+    assert bn_scale.dtype == torch.float32 and bn_bias.dtype == torch.float32 and bn_scale.is_cuda and bn_bias.is_cuda
+    if out is None:
+        out = torch.empty((args.B, args.T // 2, 112, 112, 64), dtype=torch.bfloat16, device="cuda")
+    bstride = 0
+    if pos_bias is not None:
+        assert pos_bias.dtype == torch.float32 and pos_bias.is_contiguous() and pos_bias.shape[1:] == (args.T // 2, 4, 4, 64)
+        bstride = pos_bias[0].numel() if pos_bias.shape[0] > 1 else 0
+    check(load().flk_stem_fwd_u8(C.byref(args), weights.handle, ptr(bn_scale), ptr(bn_bias), ptr(pos_bias), bstride, ptr(out),
+                                 out.shape[4], stream_ptr()))
+    return out
 
 
 def perturb_reg_adam(g_adv, delta, m, v, step, *, dialect="tf", beta0=1.0, beta1=0.5, beta2=0.5, beta3=0.5,

@@ -214,6 +214,18 @@ int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g_ld, const 
 int flk_stem_delta_bias_weights_create(const float* w7_dhwio, const float* bn_scale, float** out_dev);
 int flk_stem_delta_bias(const flk_apply_args* a, const float* sums_dev, float* table_out, void* stream);
 
+/* Conv3d_1a_7x7 (i3d.py:168-170: 7x7x7 / 2 SAME, 3 -> 64, batch norm + ReLU) computed straight from the uint8 clip with the flickering
+ * perturbation applied on the way in (kinetics_i3d_utils.py:100-142) -- ONE kernel (csrc/stem_fwd.hip) in place of
+ * flk_perturb_apply_s2d + flk_conv3d over the space-to-depth tensor: K packed along the pixel row (37 MFMA K steps instead of 49),
+ * the applied clip never written to HBM.  `a`: uint8 clip [B,T,224,224,3], flicker perturbation, center = 1 (the value fed to the
+ * convolution is clamp(x, lo - p, hi - p) = clip(x + p, lo, hi) - p; the perturbation's own contribution comes from pos_bias =
+ * flk_stem_delta_bias's table, per clip when pos_bias_bstride != 0, or NULL).  weights: flk_stem_fwd_u8_weights_create from the
+ * canonical [7,7,7,3,64] array (destroy with flk_conv_weights_destroy); bn_scale / bn_bias: fp32 [64];
+ * out: bf16 [B,T/2,112,112,out_ld], channels [0,64).  bf16 only (the fp32 parity mode keeps the two-kernel path). */
+int flk_stem_fwd_u8_weights_create(const float* w7_dhwio, flk_conv_weights** out);
+int flk_stem_fwd_u8(const flk_apply_args* a, const flk_conv_weights* w, const float* bn_scale, const float* bn_bias,
+                    const float* pos_bias, int64_t pos_bias_bstride, void* out, int out_ld, void* stream);
+
 /* Tail of the data-parallel payload (flickering_adversarial_video_amd/parallel.py; replaces the per-iteration
  * reduce_sum / reduce_mean fetches of i3d_adversarial_main_single_video_npy.py:213-217): from the per-clip
  * outputs of flk_softmax_adv_loss ([B,4] = loss, p_label, p_max_other, argmax)

@@ -139,6 +139,18 @@ def test_loss_head_vs_golden(ops, golden):
         torch.testing.assert_close(dl.cpu(), torch.from_numpy(g[f"loss_flk_{mode}_dlogits"]), rtol=2e-4, atol=1e-7)
 
 
+def test_loss_head_nan_logits_do_not_index_out_of_bounds(ops):
+    """NaN logits (corrupt weights upstream) never win an arg-max comparison: the kernel must still read z[] inside the row -- the clip's
+    loss and gradient come out NaN, the other clip is untouched (this was a GPU memory fault)"""
+    lg = torch.randn(2, 400)
+    lg[0] = float("nan")
+    labels = torch.tensor([3, 7])
+    for dialect, improve, use_logits in (("tf", True, False), ("tf", True, True), ("torch", True, False), ("tf", False, False)):
+        sm, dl, pc = ops.softmax_adv_loss(lg.cuda(), labels.cuda(), dialect=dialect, improve_loss=improve, use_logits=use_logits, margin=0.05)
+        torch.cuda.synchronize()
+        assert torch.isnan(dl[0]).all() and torch.isfinite(dl[1]).all() and torch.isfinite(pc[1]).all()
+
+
 def test_torch_targeted_improve_loss_refused(ops):
     from flickering_adversarial_video_amd._lib import FlickerHipError
     with pytest.raises(FlickerHipError):

@@ -766,12 +766,14 @@ def test_benchmark_geometry_bf16_vs_rounded_oracle():
 
 
 @pytest.mark.parametrize("dtype,batch", [("bf16", 4), ("bf16", 1), ("f32", 2)])
-def test_forward_apply_equals_apply_then_forward(dtype, batch):
+def test_forward_apply_equals_apply_then_forward(dtype, batch, monkeypatch):
     """flk_net_forward_apply (the plan launches the perturbation apply itself, per half of the batch on that half's stream) against
     flk_perturb_apply_s2d followed by flk_net_forward[_flicker]: the space-to-depth clip and the logits are bitwise equal -- shared and
-    per-clip perturbations"""
+    per-clip perturbations.  (FLK_STEM_U8=0: in bf16 the plan's default reads the uint8 clip in the stem itself and leaves the
+    space-to-depth tensor unwritten -- tests/test_stem_fwd_gpu.py.)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    monkeypatch.setenv("FLK_STEM_U8", "0")
     from flickering_adversarial_video_amd import i3d_spec, ops
     from flickering_adversarial_video_amd._lib import FLK_NET_I3D
     W = i3d_spec.synthetic_i3d_weights(42)
