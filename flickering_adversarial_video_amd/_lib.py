@@ -123,6 +123,7 @@ _SIGS = {
     "flk_stem_fwd_u8": (C.c_int, [C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_has_backward_delta": (C.c_int, [C.c_void_p]),
     "flk_net_backward_delta": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "flk_net_prepare_backward_delta": (C.c_int, [C.c_void_p, C.POINTER(ApplyArgs), C.c_void_p, C.c_void_p]),
     "flk_stem_delta_grad_scratch_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "flk_stem_delta_grad_weights_create": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "flk_stem_delta_grad_weights_destroy": (C.c_int, [C.c_void_p]),

@@ -514,7 +514,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     // near-complete drain at the loop's merge points, which puts one full memory latency into every K step.  Loads
     // the compiler issues itself (halo prefetch) only make the hand-written counts wait longer, never shorter.
     //   * K1 (one tap per slab): the activation slabs are prefetched D slabs ahead as well.
+#ifdef FLK_DA_D
+    constexpr int D = FLK_DA_D;
+#else
     constexpr int D = (NFW <= 2 && !K1) ? 8 : 4;   // K1 also keeps D activation slabs (16 VGPRs each) in flight
+#endif
     // fragment f of this wave at step k = w + (k*cout_frags + ntile*NF + wn*NFW + f) KiB + lane*16
     const char* const wfirst = wbase + (size_t)ntile * NF * 1024 + (wn * NFW * 64 + lane) * 16;
     const char* const wlast = wfirst + (size_t)(nsteps - 1) * wstep;

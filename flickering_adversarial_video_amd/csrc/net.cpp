@@ -145,6 +145,11 @@ struct flk_net {
   hipStream_t mask_stream = nullptr;   // the stem clip-mask pre-pass has a stream of its own: on a branch lane it delayed that lane's first kernels
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[kSideStreams] = {nullptr, nullptr};
   hipEvent_t ev_mask_fork = nullptr, ev_mask_done = nullptr;     // the stem clip-mask pre-pass runs beside the backward pass
+  // flk_net_prepare_backward_delta: the clip mask of the coming flk_net_backward_delta is already being computed (into `premask_scratch`,
+  // for these arguments) on mask_stream
+  bool premask = false;
+  float* premask_scratch = nullptr;
+  flk_apply_args premask_args{};
   bool multi_stream = true;
   bool tuning = false;
   bool profile = false;
@@ -1203,6 +1208,15 @@ extern "C" int flk_net_has_backward_delta(const flk_net* n) {
   return n && n->finalized && n->d_stem_wf && n->stem_dgrad_op >= 0 && !off;
 }
 
+// do two argument sets define the same clip mask? (field by field: the struct has padding)
+static bool same_mask_args(const flk_apply_args& p, const flk_apply_args& q) {
+  return p.x == q.x && p.x_is_u8 == q.x_is_u8 && p.x_scale == q.x_scale && p.x_bias == q.x_bias && p.delta == q.delta &&
+         p.delta_dense == q.delta_dense && p.dclip == q.dclip && p.inv_std[0] == q.inv_std[0] && p.inv_std[1] == q.inv_std[1] &&
+         p.inv_std[2] == q.inv_std[2] && p.lo == q.lo && p.hi == q.hi && p.adv_flag == q.adv_flag && p.shift_x == q.shift_x &&
+         p.shift_p == q.shift_p && p.B == q.B && p.T == q.T && p.H == q.H && p.W == q.W && p.delta_per_clip == q.delta_per_clip &&
+         p.dclip_dev == q.dclip_dev;
+}
+
 // backward to the flickering perturbation: the stem's data-gradient op is replaced by the fused delta-gradient kernel
 // (stem_grad.hip), which runs in its place in the plan (same stream, same profile slot "Conv3d_1a_7x7/dgrad")
 extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const flk_apply_args* a, float* gdelta, float* partials, void* stream) {
@@ -1221,7 +1235,10 @@ extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const fl
   // (its own stream: on side stream 0 -- an in-order queue -- the 0.19 ms pre-pass held back Branch_2's first data-gradients, and with
   // them the first joins of the backward pass, profiles/r3m_timeline.txt: 6.82 -> 6.79 ms per step)
   const bool beside = n->multi_stream && n->mask_stream && !n->profile;
-  if (beside) {
+  // (flk_net_prepare_backward_delta with the same arguments and scratch: the mask has been on its way since before the forward pass)
+  const bool prepared = n->premask && beside && n->premask_scratch == partials && same_mask_args(n->premask_args, ac);
+  n->premask = false;
+  if (beside && !prepared) {
     FLK_CHECK_HIP(hipEventRecord(n->ev_mask_fork, s));
     FLK_CHECK_HIP(hipStreamWaitEvent(n->mask_stream, n->ev_mask_fork, 0));
     int rc = flk_stem_delta_grad_mask(&ac, partials, n->mask_stream);
@@ -1233,6 +1250,25 @@ extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const fl
     return flk_stem_delta_grad(&ac, n->stem_G.p, n->stem_G.ld, n->d_stem_wf, gdelta, partials, beside ? 1 : 0, st);
   };
   return run_ops(n, n->bwd, n->ev_bwd, n->ev_bwd_valid, s, n->stem_dgrad_op, &fused);
+}
+
+// Optional: start the clip-mask pre-pass of the coming flk_net_backward_delta(a, scratch) NOW, on the net's own side stream -- called
+// before the forward pass it runs beside the MFMA-bound stem instead of beside the first (small, latency-bound) kernels of the backward
+// pass, which it slowed down (profiles/r3z_timeline.txt: the head's backward 37 us instead of 8).  The mask depends on the clip and on
+// delta only.  A no-op when the plan runs serially; flk_net_backward_delta falls back to its own pre-pass when the arguments differ.
+extern "C" int flk_net_prepare_backward_delta(flk_net* n, const flk_apply_args* a, float* scratch, void* stream) {
+  FLK_REQUIRE(n && n->finalized && a && scratch, "flk_net_prepare_backward_delta: bad argument / not finalized");
+  FLK_REQUIRE(n->d_stem_wf && n->stem_dgrad_op >= 0, "flk_net_prepare_backward_delta: only the I3D plan in bf16 has the fused stem delta-gradient");
+  n->premask = false;
+  static const bool off = getenv("FLK_PREMASK") && atoi(getenv("FLK_PREMASK")) == 0;
+  if (off || !(n->multi_stream && n->mask_stream && !n->profile)) return FLK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  FLK_CHECK_HIP(hipEventRecord(n->ev_mask_fork, s));          // behind everything queued so far: the previous update of delta, the previous GEMM's reads
+  FLK_CHECK_HIP(hipStreamWaitEvent(n->mask_stream, n->ev_mask_fork, 0));
+  if (int rc = flk_stem_delta_grad_mask(a, scratch, n->mask_stream)) return rc;
+  FLK_CHECK_HIP(hipEventRecord(n->ev_mask_done, n->mask_stream));
+  n->premask = true; n->premask_scratch = scratch; n->premask_args = *a;
+  return FLK_OK;
 }
 
 // one serial forward + backward with conv autotuning switched on (conv_igemm.hip): every convolution of the plan times its

@@ -261,6 +261,8 @@ class FlickerI3D:
         self._it += 1
         red, sm, pc = slot["payload"], slot["sm"], slot["pc"]
         self._red = red
+        if self.fused_delta_grad:
+            self.net.prepare_backward_delta(a, self._scratch)      # the clip mask of this iteration's backward pass: beside the stem
         self._forward(a)
         gbatch = self.B * self.world
         ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
@@ -297,6 +299,8 @@ class FlickerI3D:
         slot = self._slots[self._it % RESULT_SLOTS]
         self._it += 1
         sm, pc, g = slot["sm"], slot["pc"], slot["gclip"]
+        if self.fused_delta_grad:
+            self.net.prepare_backward_delta(a, self._scratch)
         self._forward(a)
         ops.softmax_adv_loss(self._logits, labels, dialect="tf", improve_loss=improve_loss, use_logits=use_logits,
                              targeted=targeted, margin=margin, mean_scale=1.0, out=(sm, self._dl, pc))

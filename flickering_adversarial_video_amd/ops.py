@@ -485,6 +485,10 @@ class Net:
         """the fused stem delta-gradient (csrc/stem_grad.hip) is available: I3D plan, bf16 (FLK_STEM_FUSED=0 switches it off)"""
         return bool(load().flk_net_has_backward_delta(self.handle))
 
+    def prepare_backward_delta(self, apply_args, scratch):
+        """start the clip-mask pre-pass of the coming backward_delta(…, apply_args, …, scratch) now (beside the forward pass)"""
+        check(load().flk_net_prepare_backward_delta(self.handle, C.byref(apply_args), ptr(scratch), stream_ptr()))
+
     def backward_delta(self, dlogits, apply_args, gdelta, scratch):
         """backward straight to the flickering perturbation [T,3]: no per-pixel input gradient is materialised"""
         assert gdelta.dtype == torch.float32 and gdelta.is_contiguous() and gdelta.numel() == 3 * self.T * (self.B if apply_args.delta_per_clip else 1)

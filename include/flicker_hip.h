@@ -327,6 +327,11 @@ int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream
  * (flk_net_has_backward_delta() tells); `a` = the flk_apply_args the clip of this forward pass was applied with. */
 int flk_net_has_backward_delta(const flk_net* n);
 int flk_net_backward_delta(flk_net* n, const float* dlogits, const flk_apply_args* a, float* gdelta, float* scratch, void* stream);
+/* optional, before the forward pass of the same iteration: start the clip-mask pre-pass of the coming flk_net_backward_delta(a, scratch)
+ * on the plan's own side stream (the mask depends on the clip and on delta only: kinetics_i3d_utils.py:100-142's clip_by_value
+ * gradient), so that it runs beside the stem instead of beside the first kernels of the backward pass.  Same `a` contents and same
+ * `scratch` as the backward call, which otherwise computes the mask itself. */
+int flk_net_prepare_backward_delta(flk_net* n, const flk_apply_args* a, float* scratch, void* stream);
 /* per-layer HIP-event timing of the next forward/backward (bench.py roofline leg).  While enabled the plan runs serially on
  * the caller's stream (normally independent Inception branches run on parallel streams; FLK_SINGLE_STREAM=1 disables that). */
 int flk_net_profile(flk_net* n, int enable);
