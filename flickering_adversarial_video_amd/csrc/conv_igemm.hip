@@ -428,7 +428,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     // asm in a FIXED order (every step: W(k+2) then A(k+D); the prologue replays that order from step -D), so one
     // hand-counted s_waitcnt vmcnt(N) per step retires exactly what the step consumes.
     static_assert(WN == 1, "mode 3 shares the weights through LDS");
+#ifdef FLK_M3_D
+    constexpr int D = FLK_M3_D;
+#else
     constexpr int D = NF >= 8 ? 2 : 4;
+#endif
     constexpr int NWAIT = D == 2 ? WCH + 4 : 8 + WCH;      // loads younger than the youngest load step k consumes
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int wchunk = NF >= 4 ? tid : (tid & 127);
@@ -698,6 +702,142 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvKP p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// 1x1x1 convolution (a plain GEMM over the positions) with BOTH operands streamed into LDS by the DMA path (global_load_lds_dwordx4):
+// R ring slots of [256 positions x 64 bytes | NF KiB of weight fragments], R - 1 K steps in flight per workgroup WITHOUT holding them
+// in registers.  Mode 3 keeps its activation slabs in a register queue and NF = 8 leaves room for two of them: ~37 KB in flight per
+// CU, which a 2 us HBM miss turns into ~4.7 TB/s for the whole chip -- the measured rate of the fused Inception GEMMs.  Here two
+// resident workgroups keep 2 x (R - 1) x (16 + NF) KiB on their way.
+//   * tile = 256 CONSECUTIVE positions of the flattened [B,T,H,W] grid (stride 1, logical == physical grid) x 16 NF channels;
+//   * a DMA wave-instruction moves 64 lanes x 16 bytes to 1 KiB of contiguous LDS: lane l of piece j = (position 16 j + (l >> 2),
+//     LDS slot l & 3 of that position's 64 bytes).  The slots are swizzled, slot = chunk ^ g[(position >> 2) & 3], g = {0,3,2,1},
+//     by choosing which chunk a lane FETCHES: with it the 16 lanes a ds_read_b128 serves per cycle ({0-3,12-15,20-27}, ...) fall on
+//     16 different 16-byte bank groups;
+//   * every wave issues the same number of pieces per step (4 activation + ceil(NF / 4) weight pieces), so ONE counted
+//     s_waitcnt vmcnt per step retires exactly the slot the step consumes; one barrier per step publishes it and frees the slot the
+//     next issue overwrites; the tail issues re-read the last slab into dead slots and are drained before the workgroup ends;
+//   * invalid channel chunks (cin % 32 != 0) fetch chunk 0 of the same position instead -- finite values against zero weights.
+// Epilogue: finish_store, as everywhere.
+__device__ static inline unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+__device__ static inline void glds16(unsigned voff, const char* sbase, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
+
+template <int NF, int R>
+__global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
+  typedef Prec<bf16_t> PR;
+  typedef typename PR::frag frag;
+  constexpr int EPL = 8;
+  constexpr int NFA = (NF + 3) / 4;              // weight pieces per wave per step
+  constexpr int NPW = 4 + NFA;                   // DMA instructions per wave per step
+  constexpr int SLOT = 16384 + NF * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, m = lane & 15;
+  int ptile, ntile;
+  {
+    const int per = 8 * p.ntile_n, id = blockIdx.x;
+    const int grp = id / per, r = id - grp * per;
+    ntile = r >> 3;
+    ptile = grp * 8 + (r & 7);
+  }
+  const unsigned npos = p.npos;
+  if ((unsigned)ptile * 256u >= npos) return;
+  const unsigned pos0 = (unsigned)ptile * 256u;
+  const unsigned lds0 = lds_addr32(smem);
+
+  // ---- DMA plan of this lane ----
+  const int gsw[4] = {0, 3, 2, 1};
+  const int cs = (lane & 3) ^ gsw[(lane >> 4) & 3];        // the chunk this lane fetches into slot lane & 3 of position lane >> 2
+  unsigned voff1[4], voff2[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned pos = pos0 + (unsigned)(16 * (wave + 4 * k) + (lane >> 2));
+    pos = pos < npos ? pos : npos - 1;                      // rows past the end: a valid address, never stored
+    voff1[k] = (pos * (unsigned)p.in_ld + (unsigned)(p.in_coff + cs * EPL)) * 2u;
+    voff2[k] = (pos * (unsigned)p.in2_ld + (unsigned)(p.in2_coff + cs * EPL)) * 2u;
+  }
+  unsigned wvoff[NFA];
+  int wpiece[NFA];
+#pragma unroll
+  for (int k = 0; k < NFA; ++k) {
+    const int f = wave + 4 * k < NF ? wave + 4 * k : wave;   // (NF = 6: waves 2, 3 move their first piece twice -- equal counts per wave)
+    wpiece[k] = f;
+    wvoff[k] = (unsigned)((ntile * NF + f) * 1024 + lane * 16);
+  }
+  const size_t wstep = (size_t)p.cout_frags * 1024;
+  const int nslab = p.nslab;
+  auto issue = [&](int step, int slot) {
+    const int s = step < nslab ? step : nslab - 1;
+    const bool seg2 = s >= p.nslab1;
+    const int sl = seg2 ? s - p.nslab1 : s;
+    const char* const base = (seg2 ? p.in2 : p.in) + (size_t)sl * 64;
+    const int cinseg = seg2 ? p.cin - p.cin1 : p.cin1;
+    const unsigned adj = sl * 32 + cs * EPL < cinseg ? 0u : (unsigned)(-(cs * 16));
+    const unsigned sb = lds0 + (unsigned)(slot * SLOT);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) glds16((seg2 ? voff2[k] : voff1[k]) + adj, base, sb + (unsigned)((wave + 4 * k) * 1024));
+    const char* const wb = p.w + (size_t)s * wstep;
+#pragma unroll
+    for (int k = 0; k < NFA; ++k) glds16(wvoff[k], wb, sb + 16384u + (unsigned)(wpiece[k] * 1024));
+  };
+
+  // ---- compute plan: wave w owns tile rows [64 w, 64 w + 64) ----
+  int boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) boff[i] = (64 * wave + 16 * i + m) * 64 + ((q ^ gsw[(m >> 2) & 3]) * 16);
+  f32x4 acc[NF][4];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int islot = 0;                                  // slot of the next issue
+#pragma unroll
+  for (int k = 0; k < R - 1; ++k) { issue(k, islot); islot = islot + 1 == R ? 0 : islot + 1; }
+  int cslot = 0;                                  // slot of the step being consumed
+  for (int k = 0; k < nslab; ++k) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW * (R - 2)) : "memory");      // this wave's pieces of step k have landed
+    __syncthreads();                              // everybody's have; and everybody is done reading the slot issued into next
+    issue(k + R - 1, islot);
+    islot = islot + 1 == R ? 0 : islot + 1;
+    const char* const sb = smem + cslot * SLOT;
+    cslot = cslot + 1 == R ? 0 : cslot + 1;
+    frag bf[4], af[NF];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(sb + boff[i]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) af[f] = *(const frag*)(sb + 16384 + (f * 64 + lane) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail issues must have landed before this workgroup's LDS can be handed on
+
+  // ---- epilogue ----
+  constexpr int NG = 4 * NF / EPL;
+  const int cbase = ntile * 16 * NF + q * EPL;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned pos = pos0 + (unsigned)(64 * wave + 16 * i + m);
+    if (pos >= npos) continue;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int c0 = cbase + g * 4 * EPL;
+      if (c0 >= p.cout) continue;
+      float v[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
+      finish_store<bf16_t>(p, (size_t)pos, nullptr, c0, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows, int max_halo) {
   if (max_halo <= 0 || max_halo > FLK_MAX_HALO) max_halo = FLK_MAX_HALO;
   if (max_rows <= 0 || max_rows > FLK_ROWS) max_rows = FLK_ROWS;
@@ -736,6 +876,7 @@ static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
 
 constexpr int FLK_MAX_KSPLIT = 8;
 static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, int dtype, int nf, int wn, int mode);
+static bool dbg_on() { static const bool d = getenv("FLK_CONV_DBG") != nullptr; return d; }
 
 static bool splitk_eligible(const flk_conv_args* a, const flk_conv_weights* w) {
   return !w->stem4 && w->nslab >= 2 && !a->pos_bias && a->ost == 1 && a->osh == 1 && a->osw == 1 && a->oot == 0 && a->ooh == 0 && a->oow == 0 &&
@@ -902,6 +1043,33 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     if (w->stem4) mode = 4;
     else if (da) mode = k1 ? 2 : 1;
     else if (k1 && kp.nslab >= 4 && !getenv("FLK_CONV_NO_K1")) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
+  }
+  // 1x1x1 GEMMs over a flat position grid: both operands through the LDS-DMA ring (conv1x1_dma_kernel).  FLK_CONV_DMA=0: modes 2 / 3.
+  {
+    static const int dma_on = getenv("FLK_CONV_DMA") ? atoi(getenv("FLK_CONV_DMA")) : 1;
+    const bool flat = a->st == 1 && a->sh == 1 && a->sw == 1 && a->pt == 0 && a->ph == 0 && a->pw == 0 && a->ost == 1 && a->osh == 1 && a->osw == 1 &&
+                      a->oot == 0 && a->ooh == 0 && a->oow == 0 && a->To == a->Ti && a->Ho == a->Hi && a->Wo == a->Wi && a->OT == a->To &&
+                      a->OH == a->Ho && a->OW == a->Wo;
+    const long npos = (long)a->B * a->To * a->Ho * a->Wo;
+    if (dma_on && dtype == FLK_BF16 && kp.ntaps == 1 && flat && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
+        (nf == 8 || nf == 6 || nf == 4) && kp.nslab >= 3 && npos >= (dma_on >= 2 ? 1 : 20000) && npos < (1l << 23)) {
+      kp.npos = (unsigned)npos;
+      const long pt = (npos + 255) / 256;
+      dim3 g((unsigned)((pt + 7) / 8 * 8 * ntile_n));
+      static bool attr_set[3][FLK_MAX_DEVICES] = {};
+      if (dbg_on()) fprintf(stderr, "conv 1x1x1 cin %d cout %d positions %ld | nf %d LDS-DMA ring, wgs %ld\n", a->cin, a->cout, npos, nf, pt * ntile_n);
+#define FLK_LAUNCH_DMA(NFv, idx)                                                                                                   \
+      if (nf == NFv) {                                                                                                              \
+        constexpr int Rv = 3;                                                                                                       \
+        const size_t l5 = (size_t)Rv * (16384 + NFv * 1024);                                                                        \
+        if (int rc = flk_raise_lds_limit((const void*)conv1x1_dma_kernel<NFv, Rv>, 96 * 1024, attr_set[idx])) return rc;           \
+        hipLaunchKernelGGL((conv1x1_dma_kernel<NFv, Rv>), g, dim3(256), l5, s, kp);                                                 \
+        FLK_CHECK_HIP(hipGetLastError());                                                                                           \
+        return FLK_OK;                                                                                                              \
+      }
+      FLK_LAUNCH_DMA(8, 0) FLK_LAUNCH_DMA(6, 1) FLK_LAUNCH_DMA(4, 2)
+#undef FLK_LAUNCH_DMA
+    }
   }
   // two halo images for small halos; the LDS weight ring only in mode 0
   const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4) ? 2 * (size_t)nf * 1024 : 0);
