@@ -149,6 +149,68 @@ __device__ static inline void finish_store(const ConvKP& p, size_t opos, const f
   else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c0 - p.cout1)) * sizeof(T)) = PR::from_f32(v);
 }
 
+// finish_store for the NG store groups (channels c0 + g * 4 * EPL) of ONE output position at once: every add / mask operand of the
+// position is requested before the first store.  Called group by group (finish_store), the loads of group g + 1 sit behind the
+// store of group g -- the compiler must assume they alias -- and each pays a full memory round trip.
+template <typename T, int NG>
+__device__ static inline void finish_store_row(const ConvKP& p, size_t opos, const float* pb, int c0, float (&v)[NG][Prec<T>::EPL]) {
+  typedef Prec<T> PR;
+  constexpr int EPL = PR::EPL;
+  uint4 av[NG], mv[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = c0 + g * 4 * EPL;
+    const bool in = c < p.cout;
+    if (p.add) av[g] = *(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + (in ? c : 0)) * sizeof(T));
+    if (p.mask) mv[g] = *(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + (in ? c : 0)) * sizeof(T));
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = c0 + g * 4 * EPL;
+    if (c >= p.cout) continue;
+    float* w = v[g];
+    if (p.scale) {
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) {
+        const float4 sc = *(const float4*)(p.scale + c + e);
+        w[e] *= sc.x; w[e + 1] *= sc.y; w[e + 2] *= sc.z; w[e + 3] *= sc.w;
+      }
+    }
+    if (p.bias) {
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) {
+        const float4 bi = *(const float4*)(p.bias + c + e);
+        w[e] += bi.x; w[e + 1] += bi.y; w[e + 2] += bi.z; w[e + 3] += bi.w;
+      }
+    }
+    if (pb) {
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) {
+        const float4 t4 = *(const float4*)(pb + c + e);
+        w[e] += t4.x; w[e + 1] += t4.y; w[e + 2] += t4.z; w[e + 3] += t4.w;
+      }
+    }
+    if (p.add) {
+      float a[EPL];
+      PR::to_f32(av[g], a);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] += a[e];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] = fmaxf(w[e], 0.f);
+    }
+    if (p.mask) {
+      float a[EPL];
+      PR::to_f32(mv[g], a);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] = a[e] > 0.f ? w[e] : 0.f;
+    }
+    if (c < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c) * sizeof(T)) = PR::from_f32(w);
+    else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c - p.cout1)) * sizeof(T)) = PR::from_f32(w);
+  }
+}
+
 constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pairs staged per thread (16)
 
 // WN = waves along N: the 4 waves form a (4/WN) x WN grid; the workgroup tile is 64*(4/WN) rows x 16*NF channels and
@@ -825,15 +887,12 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
   for (int i = 0; i < 4; ++i) {
     const unsigned pos = pos0 + (unsigned)(64 * wave + 16 * i + m);
     if (pos >= npos) continue;
+    float v[NG][EPL];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int c0 = cbase + g * 4 * EPL;
-      if (c0 >= p.cout) continue;
-      float v[EPL];
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) v[e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
-      finish_store<bf16_t>(p, (size_t)pos, nullptr, c0, v);
-    }
+      for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
+    finish_store_row<bf16_t, NG>(p, (size_t)pos, nullptr, cbase, v);
   }
 }
 
