@@ -393,6 +393,7 @@ def main():
         # conv_igemm launches split by the roofline that bounds each of them (time at the MFMA peak for its flops against time at
         # the HBM peak for its compulsory bytes): the 3x3x3 / 7x7x7 layers are MFMA-bound, the 1x1x1 GEMMs HBM-bound
         by_bound = {"mfma": {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0}, "hbm": {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0}}
+        by_kernel = {}       # convolution-class launches by the kernel they went to (flk_net_profile_read's "kernel")
         reps = 3
         for _ in range(reps):
             eng.step(x, labels, **hp)
@@ -404,9 +405,14 @@ def main():
                 elif r["kind"] == "conv":
                     bb = by_bound["mfma" if r["flops"] / (PEAK_TFLOPS[a.dtype] * 1e12) >= r["bytes"] / 8e12 else "hbm"]
                     bb["ms"] += r["ms"]; bb["flops"] += r["flops"]; bb["bytes"] += r["bytes"]; bb["launches"] += 1
+                    kk = by_kernel.setdefault(r.get("kernel") or "conv_igemm_kernel", {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+                    kk["ms"] += r["ms"]; kk["flops"] += r["flops"]; kk["bytes"] += r["bytes"]; kk["launches"] += 1
         eng.net.profile(False)
         cv = per_kind["conv"]
-        ig = {k: cv[k] - fused[k] for k in ("ms", "flops", "launches")}        # conv_igemm_kernel launches only
+        # the dominant kernel alone: conv_igemm_kernel (every 3x3x3 / strided / small convolution, forward and data-gradient).  The stem's
+        # forward (stem_fwd_u8_kernel), the 1x1x1 GEMMs (conv1x1_dma_kernel) and the stem's data-gradient (stem_delta_grad_kernel) are
+        # kernels of their own and get their own entries below.
+        ig = by_kernel.get("conv_igemm_kernel") or {k: cv[k] - fused[k] for k in ("ms", "flops", "launches")}
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
         # HBM traffic per launch comes from the committed rocprofv3 --pmc passes of this same command (bench.py cannot
         # profile itself): profiles/*_pmc_hbm_traffic.json, produced by tools/pmc_summary.py -- the file and the library
@@ -418,12 +424,22 @@ def main():
                 tj = json.load(open(f))
                 traffic = tj["kernels"]["conv_igemm_kernel"]["bytes_per_launch"]
                 traffic_src = {"file": os.path.relpath(f, ROOT), "state": tj.get("state", "unknown")}
-        out["roofline"] = {"kernel": "conv_igemm_kernel (implicit-GEMM conv3d fwd + dgrad, every layer but the stem's data-gradient)", "bound": "mfma",
+        out["roofline"] = {"kernel": "conv_igemm_kernel (implicit-GEMM conv3d fwd + dgrad with LDS halo tiles: every 3x3x3 / strided layer)", "bound": "mfma",
                            "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.dtype],
                            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, gfx950-corrected)", "traffic_source": traffic_src,
                            "launches_per_step": ig["launches"] // reps, "avg_launch_ms": ig["ms"] / ig["launches"],
                            "conv_ms_per_step": cv["ms"] / reps, "algorithmic_gflop_per_step": cv["flops"] / reps / 1e9,
                            "all_conv_achieved": cv["flops"] / (cv["ms"] * 1e-3) / 1e12}
+        oth = {}
+        for kn, kv in by_kernel.items():
+            if kn == "conv_igemm_kernel" or not kv["ms"]:
+                continue
+            tf, gb = kv["flops"] / (kv["ms"] * 1e-3) / 1e12, kv["bytes"] / (kv["ms"] * 1e-3) / 1e9
+            mf = kv["flops"] / (PEAK_TFLOPS[a.dtype] * 1e12) >= kv["bytes"] / 8e12
+            oth[kn] = {"bound": "mfma" if mf else "hbm", "launches_per_step": kv["launches"] // reps, "ms_per_step": kv["ms"] / reps,
+                       "avg_launch_ms": kv["ms"] / kv["launches"], "achieved_TFLOPs": tf, "achieved_GBps_compulsory": gb,
+                       "frac": tf / PEAK_TFLOPS[a.dtype] if mf else gb / 8000.0}
+        out["roofline"]["other_conv_kernels"] = oth
         m, h = by_bound["mfma"], by_bound["hbm"]
         out["roofline"]["conv_igemm_by_bound"] = {
             "mfma_bound": {"launches_per_step": m["launches"] // reps, "ms_per_step": m["ms"] / reps,
@@ -432,7 +448,8 @@ def main():
             "hbm_bound": {"launches_per_step": h["launches"] // reps, "ms_per_step": h["ms"] / reps,
                           "achieved_GBps": h["bytes"] / (h["ms"] * 1e-3) / 1e9 if h["ms"] else None, "peak_GBps": 8000.0,
                           "frac": h["bytes"] / (h["ms"] * 1e-3) / 8e12 if h["ms"] else None,
-                          "note": "compulsory bytes (input + output + epilogue operands once) of the 1x1x1 GEMMs"}}
+                          "note": "compulsory bytes (input + output + epilogue operands once) of the 1x1x1 GEMMs"},
+            "note": "every convolution-class launch of the step (all three kernels, without the stem's data-gradient slot) by the roofline that bounds it"}
         if fused["launches"]:
             out["roofline"]["stem_delta_grad_kernel"] = {"ms": fused["ms"] / reps, "achieved": fused["flops"] / (fused["ms"] * 1e-3) / 1e12,
                                                          "unit": "TFLOP/s (algorithmic flops of the stem data-gradient it replaces)",

@@ -5,6 +5,7 @@
 #include "flk_internal.h"
 
 static thread_local char g_err[1024] = "";
+thread_local const char* flk_last_kernel_tag = "";
 
 void flk_set_error(const char* fmt, ...) {
   va_list ap;

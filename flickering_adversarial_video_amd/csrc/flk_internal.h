@@ -30,6 +30,9 @@ void flk_set_error(const char* fmt, ...);
     }                                   \
   } while (0)
 
+// name of the kernel the last convolution-class launch of this thread went to (per-launch profile: flk_net_profile_read's "kernel")
+extern thread_local const char* flk_last_kernel_tag;
+
 static inline int flk_esize(int dtype) { return dtype == FLK_BF16 ? 2 : 4; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel and one process may drive several GPUs:

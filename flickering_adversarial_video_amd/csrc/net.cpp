@@ -154,6 +154,7 @@ struct flk_net {
   bool tuning = false;
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fwd, ev_bwd;
+  std::vector<const char*> tag_fwd, tag_bwd;      // kernel each profiled launch went to (flk_last_kernel_tag)
   bool ev_fwd_valid = false, ev_bwd_valid = false;
 
   int esz() const { return flk_esize(dtype); }
@@ -1102,6 +1103,8 @@ extern "C" int flk_net_num_classes(const flk_net* n) { return n ? n->num_classes
 
 static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool& ev_valid, hipStream_t s,
                    int replace_op = -1, const std::function<int(hipStream_t)>* replacement = nullptr) {
+  std::vector<const char*>& tags = &ops == &n->fwd ? n->tag_fwd : n->tag_bwd;
+  if (n->profile) tags.assign(ops.size(), "");
   if (n->profile && ev.size() != ops.size()) {
     for (size_t i = ev.size(); i < ops.size(); ++i) {
       // timing-only events (hipEventDisableSystemFence, the flag's documented use): a default event's system-scope fence writes the
@@ -1145,10 +1148,10 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
     // tuning pass: only the launches that run alone on the device (outside the fork/join regions) are timed in the
     // conditions they will run in; branch kernels co-run with their siblings, where the isolated optimum is not the best
     if (n->tuning) flk_conv_set_autotune(!in_fork);
-    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].first, st));
+    if (n->profile) { FLK_CHECK_HIP(hipEventRecord(ev[i].first, st)); flk_last_kernel_tag = ""; }
     int rc = ((int)i == replace_op && replacement) ? (*replacement)(st) : op.run(st);
     if (rc) return rc;
-    if (n->profile) FLK_CHECK_HIP(hipEventRecord(ev[i].second, st));
+    if (n->profile) { FLK_CHECK_HIP(hipEventRecord(ev[i].second, st)); tags[i] = flk_last_kernel_tag; }
   }
   ev_valid = n->profile;
   return FLK_OK;
@@ -1300,14 +1303,15 @@ extern "C" int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap) {
   std::string js = "[";
   auto dump = [&](std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool valid, const char* pass) -> int {
     if (!valid) return FLK_OK;
+    const std::vector<const char*>& tags = &ops == &n->fwd ? n->tag_fwd : n->tag_bwd;
     for (size_t i = 0; i < ops.size(); ++i) {
       if (ops[i].kind == K_FORK || ops[i].kind == K_JOIN) continue;
       FLK_CHECK_HIP(hipEventSynchronize(ev[i].second));
       float ms = 0.f;
       FLK_CHECK_HIP(hipEventElapsedTime(&ms, ev[i].first, ev[i].second));
       char buf[512];
-      snprintf(buf, sizeof(buf), "%s{\"name\":\"%s\",\"pass\":\"%s\",\"kind\":\"%s\",\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
-               js.size() > 1 ? "," : "", ops[i].name.c_str(), pass, kKindName[ops[i].kind], ms, ops[i].flops, ops[i].bytes);
+      snprintf(buf, sizeof(buf), "%s{\"name\":\"%s\",\"pass\":\"%s\",\"kind\":\"%s\",\"kernel\":\"%s\",\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
+               js.size() > 1 ? "," : "", ops[i].name.c_str(), pass, kKindName[ops[i].kind], i < tags.size() ? tags[i] : "", ms, ops[i].flops, ops[i].bytes);
       js += buf;
     }
     return FLK_OK;

@@ -380,5 +380,6 @@ extern "C" int flk_stem_fwd_u8(const flk_apply_args* a, const flk_conv_weights* 
     hipLaunchKernelGGL(stem_fwd_u8_kernel<8>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<8>::LDS, st, kp);
   }
   FLK_CHECK_HIP(hipGetLastError());
+  flk_last_kernel_tag = "stem_fwd_u8_kernel";
   return FLK_OK;
 }

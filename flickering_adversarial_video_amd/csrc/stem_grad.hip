@@ -451,6 +451,7 @@ extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g
   if (!mask_done && (rc = flk_stem_delta_grad_mask(a, scratch, stream))) return rc;
   hipLaunchKernelGGL(stem_delta_grad_kernel, dim3((unsigned)(a->B * kp.To * kp.nchunk)), dim3(SG_THREADS), SG_LDS, s, kp);
   FLK_CHECK_HIP(hipGetLastError());
+  flk_last_kernel_tag = "stem_delta_grad_kernel";
   flk_apply_args a2 = *a;
   a2.fold_t = 2;                                       // stage 2 reads the partials as (frame pair, parity)
   return flk_grad_reduce_stage2_launch(&a2, kp.nchunk, scratch, gdelta, s);

@@ -61,6 +61,28 @@ static void packing() {
   flk_stem_delta_grad_weights_destroy(dev); dev = nullptr;
   EXPECT(flk_stem_delta_bias_weights_create(w7.data(), s7.data(), &dev) == FLK_OK && dev, "stem delta-bias weights");
   flk_stem_delta_grad_weights_destroy(dev);
+  // the stem straight from the uint8 clip: 74 packed "taps" (37 K steps x 2 column parities); argument checks of the launch
+  EXPECT(flk_stem_fwd_u8_weights_create(w7.data(), &cw) == FLK_OK && cw, "stem-from-uint8 weights");
+  EXPECT(flk_stem_fwd_u8_weights_create(nullptr, &cw) == FLK_EINVAL, "stem-from-uint8 weights: null");
+  {
+    const int B = 1, T = 4;
+    std::vector<uint8_t> clip((size_t)B * T * 224 * 224 * 3, 7);
+    std::vector<float> delta((size_t)T * 3, 0.01f), sc(64, 1.f), bi(64, 0.f);
+    std::vector<uint16_t> out((size_t)B * (T / 2) * 112 * 112 * 64);
+    flk_apply_args a{};
+    a.x = clip.data(); a.x_is_u8 = 1; a.x_scale = 1.f / 128; a.x_bias = -1.f; a.delta = delta.data(); a.dclip = 0.4f;
+    a.inv_std[0] = a.inv_std[1] = a.inv_std[2] = 1.f; a.lo = -1.f; a.hi = 1.f; a.adv_flag = 1.f; a.B = B; a.T = T; a.H = 224; a.W = 224; a.fold_t = 3; a.center = 1;
+    EXPECT(flk_stem_fwd_u8(&a, cw, sc.data(), bi.data(), nullptr, 0, out.data(), 64, nullptr) == FLK_OK, "stem-from-uint8 launch");
+    flk_apply_args b = a; b.center = 0;
+    EXPECT(flk_stem_fwd_u8(&b, cw, sc.data(), bi.data(), nullptr, 0, out.data(), 64, nullptr) == FLK_EINVAL, "stem-from-uint8 needs center = 1");
+    b = a; b.H = 112;
+    EXPECT(flk_stem_fwd_u8(&b, cw, sc.data(), bi.data(), nullptr, 0, out.data(), 64, nullptr) == FLK_EINVAL, "stem-from-uint8 needs 224 x 224");
+    flk_conv_weights* other = nullptr;
+    EXPECT(flk_conv_weights_create(w7.data(), 1, 1, 1, 32, 64, nullptr, 0, FLK_BF16, 4, &other) == FLK_OK, "a 1x1x1 weight object");
+    EXPECT(flk_stem_fwd_u8(&a, other, sc.data(), bi.data(), nullptr, 0, out.data(), 64, nullptr) == FLK_EINVAL, "stem-from-uint8 refuses foreign weights");
+    flk_conv_weights_destroy(other);
+  }
+  flk_conv_weights_destroy(cw);
 }
 
 static void validation() {
@@ -153,7 +175,10 @@ static void plan(int arch, int dtype, int B, int T, int HW, const std::map<std::
     EXPECT(flk_perturb_apply_s2d(&a, x.data(), FLK_BF16, nullptr) == FLK_OK, "%s apply", tag);
     EXPECT(flk_net_forward_flicker(n, x.data(), &a, lg.data(), nullptr) == FLK_OK, "%s forward_flicker", tag);
     EXPECT(flk_net_backward_delta(n, dl.data(), &a, gd.data(), scratch.data(), nullptr) == FLK_OK, "%s backward_delta", tag);
+    EXPECT(flk_net_prepare_backward_delta(n, &a, scratch.data(), nullptr) == FLK_OK, "%s prepare_backward_delta (clip mask beside the forward pass)", tag);
     EXPECT(flk_net_forward_apply(n, &a, x.data(), lg.data(), nullptr) == FLK_OK, "%s forward_apply (apply inside the plan, per batch slice)", tag);
+    EXPECT(flk_net_backward_delta(n, dl.data(), &a, gd.data(), scratch.data(), nullptr) == FLK_OK, "%s backward_delta behind a prepared mask", tag);
+    EXPECT(flk_net_prepare_backward_delta(n, nullptr, scratch.data(), nullptr) == FLK_EINVAL, "%s prepare_backward_delta: null arguments", tag);
     {   // per-clip perturbations: one delta, one position-bias table and one clamp bound per clip
       std::vector<float> dpc((size_t)B * T * 3, 0.02f), gpc((size_t)B * T * 3), bounds(B, 0.3f);
       flk_apply_args pc = a; pc.delta = dpc.data(); pc.delta_per_clip = 1; pc.dclip_dev = bounds.data();
