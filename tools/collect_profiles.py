@@ -43,6 +43,9 @@ def short(name):
     m = re.search(r"conv_igemm_kernel<([^>]*)>", name)
     if m:
         return "conv_igemm_kernel<" + m.group(1).replace("__hip_bfloat16", "bf16").replace(" ", "") + ">"
+    m = re.search(r"(conv1x1_dma_kernel|stem_fwd_u8_kernel)(?:<([^>]*)>|I([A-Za-z0-9_]*?)E)?", name)
+    if m:
+        return m.group(1) + ("<%s>" % m.group(2).replace(" ", "") if m.group(2) else "")
     m = re.search(r"(stem_delta_grad_kernel|stem_mask_kernel|stem_delta_bias_kernel|conv_splitk_finish_kernel|maxpool_\w+|head_\w+|apply_s2d_\w+|"
                   r"grad_reduce_\w+|softmax_adv_loss_kernel|reg_adam_kernel|dense_\w+)", name)
     if m:

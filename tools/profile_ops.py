@@ -20,21 +20,21 @@ acc = {}
 for _ in range(a.reps):
     eng.step(x, labels)
     for i, r in enumerate(eng.net.profile_read()):
-        k = (i, r["name"], r["pass"], r["kind"])
+        k = (i, r["name"], r["pass"], r["kind"], r.get("kernel", ""))
         e = acc.setdefault(k, dict(ms=0.0, flops=r["flops"], bytes=r["bytes"]))
         e["ms"] += r["ms"] / a.reps
-rows = [dict(name=k[1], **{"pass": k[2]}, kind=k[3], **v) for k, v in acc.items()]
+rows = [dict(name=k[1], **{"pass": k[2]}, kind=k[3], kernel=k[4], **v) for k, v in acc.items()]
 tot = sum(r["ms"] for r in rows)
 # roofline per launch: time the MFMA peak (bf16 2500 / fp32 ~157 TFLOP/s) or a streaming kernel's HBM rate (~4.5 TB/s of the 8 TB/s
 # peak) would need for the launch's algorithmic flops / compulsory bytes, whichever is larger; frac = that bound / measured time
 PEAK_TF = 2500.0 if a.dtype == "bf16" else 157.0
-print(f"{'op':58s} {'pass':4s} {'ms':>8s} {'%':>6s} {'TFLOP/s':>9s} {'GB/s':>8s} {'bound':>5s} {'frac':>5s}")
+print(f"{'op':58s} {'pass':4s} {'ms':>8s} {'%':>6s} {'TFLOP/s':>9s} {'GB/s':>8s} {'bound':>5s} {'frac':>5s}  kernel")
 for r in sorted(rows, key=lambda r: -r["ms"]):
     tf = r["flops"] / r["ms"] / 1e9 if r["flops"] else 0
     gb = r["bytes"] / r["ms"] / 1e6 if r["bytes"] else 0
     t_mfma, t_hbm = r["flops"] / (PEAK_TF * 1e9), r["bytes"] / 8e9          # ms at the peaks
     bound, frac = ("mfma", t_mfma / r["ms"]) if t_mfma >= t_hbm else ("hbm", t_hbm / r["ms"])
-    print(f"{r['name'][:58]:58s} {r['pass']:4s} {r['ms']:8.3f} {100*r['ms']/tot:6.1f} {tf:9.1f} {gb:8.0f} {bound:>5s} {frac:5.2f}")
+    print(f"{r['name'][:58]:58s} {r['pass']:4s} {r['ms']:8.3f} {100*r['ms']/tot:6.1f} {tf:9.1f} {gb:8.0f} {bound:>5s} {frac:5.2f}  {r['kernel'].replace('_kernel', '')}")
 print("total ms", tot)
 by = {}
 for r in rows:

@@ -13,7 +13,7 @@ starts = [i + 1 for i in ends if i + 1 < len(ev)]
 def short(n):
     if "conv_igemm" in n:
         return "conv"
-    for k in ("stem_delta_grad", "stem_mask", "wrun", "s1_tiled", "scatter", "strided_bwd", "maxpool_fwd", "head", "softmax", "reg_adam",
+    for k in ("conv1x1_dma", "stem_fwd_u8", "stem_delta_grad", "stem_mask", "wrun", "s1_tiled", "scatter", "strided_bwd", "maxpool_fwd", "head", "softmax", "reg_adam",
               "grad_reduce", "apply", "bias", "pack"):
         if k in n:
             return k
