@@ -406,6 +406,46 @@ def test_conv_two_segment_output_and_input(ops, dtype):
     torch.testing.assert_close(gx.float().cpu(), gx_ref, rtol=r * 2, atol=a * 2)
 
 
+@pytest.mark.parametrize("nf", [4, 6, 8])
+def test_conv1x1_dma_ring_all_features(ops, nf):
+    """conv1x1_dma_kernel (bf16 1x1x1 GEMMs of >= 2048 positions: both operands through the LDS-DMA ring) with everything the fused
+    Inception GEMMs use at once -- a position count that is not a multiple of the 256-position tile, cin % 32 != 0 (invalid channel
+    chunks fetch chunk 0 against zero weights), two output segments with offsets, then the data-gradient form: K gathered from two
+    gradient buffers + accumulate operand + ReLU mask -- against torch-CPU"""
+    dtype = torch.bfloat16
+    B, T, H, W, cin = 1, 3, 27, 29, 72                       # 2349 positions = 9 tiles + 45 rows
+    c0, c1 = 112, 40
+    x = q(rnd((B, T, H, W, cin + 8), 41), dtype)              # read at coff 8
+    w = q(rnd((1, 1, 1, cin, c0 + c1), 42, 0.1), dtype)
+    sc, bi = rnd((c0 + c1,), 43).abs() + 0.5, rnd((c0 + c1,), 44) * 0.1
+    ref = torch.relu(ref_conv(x[..., 8:].contiguous(), w, (1, 1, 1), (0, 0, 0), (T, H, W)) * sc + bi)
+    outA = torch.full((B, T, H, W, c0 + 16), 3.0, dtype=dtype).cuda()
+    outB = torch.full((B, T, H, W, c1 + 8), 3.0, dtype=dtype).cuda()
+    pw = ops.ConvWeights(w.numpy(), dtype, nf)
+    ops.conv3d(x.to(dtype).cuda(), pw, in_coff=8, cin=cin, out=outA, out_coff=8, out2=outB, out2_coff=8, cout1=c0, scale=sc.cuda(), bias=bi.cuda(), relu=True)
+    r, a = tol(dtype, ref)
+    torch.testing.assert_close(outA.float().cpu()[..., 8:8 + c0], ref[..., :c0], rtol=r, atol=a)
+    torch.testing.assert_close(outB.float().cpu()[..., 8:], ref[..., c0:], rtol=r, atol=a)
+    assert (outA.float().cpu()[..., :8] == 3).all() and (outA.float().cpu()[..., 8 + c0:] == 3).all() and (outB.float().cpu()[..., :8] == 3).all()
+    # data-gradient form: gx = ([gA | gB] . (a W)^T + add) masked
+    gA, gB = q(rnd((B, T, H, W, c0 + 8), 45), dtype), q(rnd((B, T, H, W, c1), 46), dtype)
+    g = torch.cat([gA[..., 8:], gB], -1)
+    add = q(rnd((B, T, H, W, cin + 8), 47), dtype)
+    mask = q(rnd((B, T, H, W, cin), 48), dtype)
+    gx_ref = torch.einsum("bthwk,ck->bthwc", g * sc, w[0, 0, 0]) + add[..., 8:]
+    gx_ref = torch.where(mask > 0, gx_ref, torch.zeros_like(gx_ref))
+    wT = w[0, 0, 0].t().contiguous().reshape(1, 1, 1, c0 + c1, cin)
+    pb = ops.ConvWeights(wT.numpy(), dtype, nf, row_scale=sc.numpy(), cin_split=c0)
+    gx = ops.conv3d(gA.to(dtype).cuda(), pb, in_coff=8, cin=c0 + c1, in2=gB.to(dtype).cuda(), in2_coff=0,
+                    add=add.to(dtype).cuda(), add_coff=8, mask=mask.to(dtype).cuda())
+    r, a = tol(dtype, gx_ref)
+    torch.testing.assert_close(gx.float().cpu(), gx_ref, rtol=r * 2, atol=a * 2)
+    # the register-queue path (3x fewer positions: below the ring's threshold) gives the same values up to summation order
+    xs = x[:, :1, :20, :20].contiguous()
+    small = ops.conv3d(xs.to(dtype).cuda(), pw, in_coff=8, cin=cin, scale=sc.cuda(), bias=bi.cuda(), relu=True)
+    torch.testing.assert_close(small.float().cpu(), ref[:, :1, :20, :20], rtol=r, atol=a)
+
+
 @pytest.mark.parametrize("case", ["u8", "f32_torch_dialect", "cyclic_u8"])
 def test_stem_delta_grad_fused(case):
     """flk_stem_delta_grad (csrc/stem_grad.hip): d(loss)/d(delta[t,c]) in ONE kernel from the stem's output gradient G -- against
