@@ -1112,7 +1112,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
                       a->OH == a->Ho && a->OW == a->Wo;
     const long npos = (long)a->B * a->To * a->Ho * a->Wo;
     if (dma_on && dtype == FLK_BF16 && kp.ntaps == 1 && flat && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
-        (nf == 8 || nf == 6 || nf == 4) && kp.nslab >= 3 && npos >= (dma_on >= 2 ? 1 : 2048) && npos < (1l << 23)) {
+        (nf == 8 || nf == 6 || nf == 4) && kp.nslab >= 2 && npos >= (dma_on >= 2 ? 1 : 2048) && npos < (1l << 23)) {
       kp.npos = (unsigned)npos;
       const long pt = (npos + 255) / 256;
       dim3 g((unsigned)((pt + 7) / 8 * 8 * ntile_n));
