@@ -134,3 +134,37 @@ def test_plan_uses_the_uint8_stem(ops, batch, monkeypatch):
         el = float((l_new - l_old).abs().max() / l_old.abs().max())
         print(f"[bs {batch}, delta {shape}] uint8 stem vs two-kernel path: stem output {e1:.2e}, logits {el:.2e}")
         assert e1 < 8e-3 and el < 2e-2
+
+
+def test_prepared_clip_mask_gives_the_same_delta_gradient(ops):
+    """flk_net_prepare_backward_delta (the stem's clip-mask pre-pass started before the forward pass, on the plan's own side stream) changes
+    WHEN the mask is computed, not what it is: the delta-gradient is bitwise the one of the unprepared call; a preparation for other
+    arguments is ignored (the backward call computes its own mask)"""
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd._lib import FLK_NET_I3D, load
+    B, T = 2, 16
+    W = i3d_spec.synthetic_i3d_weights(42)
+    net = ops.Net(FLK_NET_I3D, "bf16", B, T, 224, 224, W)
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(B, T, seed=3)).cuda()
+    rng = np.random.default_rng(2)
+    d1 = torch.from_numpy(rng.uniform(-0.3, 0.3, (T, 3)).astype(np.float32)).cuda()
+    d2 = torch.from_numpy(rng.uniform(-0.3, 0.3, (T, 3)).astype(np.float32)).cuda()
+    dl = torch.from_numpy(rng.standard_normal((B, 400)).astype(np.float32) * 1e-3).cuda()
+    scratch = torch.empty(max(1, load().flk_stem_delta_grad_scratch_bytes(B, T, 224) // 4), dtype=torch.float32, device="cuda")
+    xs = torch.empty((B, T // 2, 112, 112, 32), dtype=torch.bfloat16, device="cuda")
+
+    def grad(delta, prepare_with=None):
+        a = ops.make_apply_args(xu, delta, fold_t=ops.I3D_FOLD, center=True)
+        if prepare_with is not None:
+            net.prepare_backward_delta(ops.make_apply_args(xu, prepare_with, fold_t=ops.I3D_FOLD, center=True), scratch)
+        net.forward_apply(a, xs)
+        g = torch.empty((T, 3), dtype=torch.float32, device="cuda")
+        net.backward_delta(dl, a, g, scratch)
+        torch.cuda.synchronize()
+        return g.clone()
+
+    plain = grad(d1)
+    assert torch.isfinite(plain).all() and float(plain.abs().max()) > 0
+    assert torch.equal(grad(d1, prepare_with=d1), plain)            # prepared: same bits
+    assert torch.equal(grad(d1, prepare_with=d2), plain)            # prepared for another perturbation: ignored
+    assert not torch.equal(grad(d2), plain)
