@@ -25,8 +25,9 @@
 //     The 4 wi (24 bytes apart) x 4 rt (two planes = 16 banks apart: plane pitch = 32 mod 128) of one q cover 32 banks and a second
 //     chunk 32 bytes further (or one plane further) covers exactly the other 32 -- so the 148 chunk slots are PAIRED: (kt, kh, j = 0)
 //     with (kt, kh, 2); (kt, kh, 1) with (kt + 1, kh, 1); three left-over pairs conflict two-way (scratch/stem_banks.py);
-//   * weights: A fragments of both parities through a double-buffered 2 x 8 KiB LDS ring, register prefetch one step ahead, one
-//     barrier per K step (as conv_igemm.hip mode 0); the 37 steps are fully unrolled (every LDS offset a compile-time constant);
+//   * weights: A fragments of both parities through a double-buffered 2 x 8 KiB LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no
+//     register staging, no ds_write in the loop), issued one step ahead right behind the step's barrier, one barrier per K step; the 37
+//     steps are fully unrolled (every LDS offset a compile-time constant);
 //   * epilogue as conv_igemm.hip: lane = position, 8 consecutive channels per lane group: acc * bn_scale + bias + position-class bias
 //     (the perturbation's contribution, exact in fp32), ReLU, 16-byte bf16 stores.
 // LDS 52 160 bytes: three workgroups per CU.
@@ -76,7 +77,7 @@ struct StemFwdKP {
   char* out; int out_ld;
   int To, nTt, ntiles, chunk;
   int stagger;     // timing experiments only: workgroups 256..767 start (id / 256) * stagger * 8128 cycles late
-  int ablate;      // timing experiments only (-DSF_ABLATE builds): bit 0 no ring refill, 1 no staging, 2 no B reads, 3 no A reads, 4 no MFMA
+  int ablate;      // timing experiments only (-DSF_ABLATE builds): bit 1 no staging, 2 no B reads, 3 no A reads, 4 no MFMA
 };
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -85,6 +86,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ inline unsigned lds_addr(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
 __device__ inline int wrapT(int t, int T) { t %= T; return t < 0 ? t + T : t; }
 __device__ inline float clipf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// one LDS-DMA wave instruction: lane l moves 16 bytes from sbase + voff (per lane) to LDS byte lds_base + 16 l (lds_base wave-uniform)
+__device__ inline void glds16(unsigned voff, const char* sbase, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
+}
 
 template <int OFF>
 __device__ inline u32x2 lds_read64(unsigned addr) {
@@ -136,9 +144,13 @@ __global__ __launch_bounds__(256, NI == 4 ? 3 : 2) void stem_fwd_u8_kernel(const
     for (int k = 0; k < (int)(blockIdx.x >> 8) * p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
 #endif
   // weights of step 0 (in flight while the halo is staged)
-  const char* wsrc = p.w + tid * 16;
-  uint4 wreg0 = *(const uint4*)wsrc, wreg1 = *(const uint4*)(wsrc + 4096);
-  wsrc += 8192;
+  // the 8 KiB of a step go global -> LDS by DMA: wave w moves pieces w and w + 4 (1 KiB each) of the step -- no register staging, no
+  // ds_write in the K loop (stamps: the ring-write segment of a step 214 -> 73 ticks, the kernel -5.5 %)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned ring_lds = lds_addr(ring);
+  const unsigned wvoff0 = (unsigned)(wv * 1024 + lane * 16), wvoff1 = wvoff0 + 4096u;
+  glds16(wvoff0, p.w, ring_lds + (unsigned)(wv * 1024));
+  glds16(wvoff1, p.w, ring_lds + (unsigned)(wv * 1024) + 4096u);
 
   // ---- per-frame table: clamp bounds lo - p[c], hi - p[c], source frame, validity ----
   if (tid < SF_TH) {
@@ -239,16 +251,14 @@ __global__ __launch_bounds__(256, NI == 4 ? 3 : 2) void stem_fwd_u8_kernel(const
 #pragma unroll
   for (int s = 0; s < SF_STEPS; ++s) {
     char* const wcur = ring + (s & 1) * 8192;
-    if (s == 0 || SF_ON(0)) {
-      *(uint4*)(wcur + tid * 16) = wreg0;
-      *(uint4*)(wcur + tid * 16 + 4096) = wreg1;
-      if (s + 1 < SF_STEPS) {
-        wreg0 = *(const uint4*)wsrc;
-        wreg1 = *(const uint4*)(wsrc + 4096);
-        wsrc += 8192;
-      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of step s have landed (issued one step ago)
+    __syncthreads();      // everybody's have (step 0: also the halo image); slot (s + 1) & 1 was last read in step s - 1
+    if (s + 1 < SF_STEPS) {
+      const char* const wb = p.w + (size_t)(s + 1) * 8192;
+      const unsigned dst = ring_lds + (unsigned)(((s + 1) & 1) * 8192 + wv * 1024);
+      glds16(wvoff0, wb, dst);
+      glds16(wvoff1, wb, dst + 4096u);
     }
-    __syncthreads();      // step 0: also publishes the halo image
     const int so = q == 0 ? sf_stepoff<NI>(s, 0) : q == 1 ? sf_stepoff<NI>(s, 1) : q == 2 ? sf_stepoff<NI>(s, 2) : sf_stepoff<NI>(s, 3);
     const unsigned cur = pos0 + (unsigned)so;
     if (s == 0 || SF_ON(3)) {
