@@ -198,14 +198,14 @@ extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dty
   const bool bf = dtype == FLK_BF16;
   if (ft == 2 && a->x_is_u8 && !a->delta_dense && a->W % 8 == 0 && a->T / 2 < 65536 && a->B < 65536 && !getenv("FLK_APPLY_GENERIC")) {
     const dim3 g3((unsigned)(((a->H / 2) * (a->W / 8) + 255) / 256), (unsigned)(a->T / 2), (unsigned)a->B);
-    if (bf && ftl == 2) hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<bf16_t, 2>), g3, dim3(256), 0, st, *a, (char*)out);
-    else if (bf) hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<bf16_t, 3>), g3, dim3(256), 0, st, *a, (char*)out);
-    else if (ftl == 2) hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<float, 2>), g3, dim3(256), 0, st, *a, (char*)out);
-    else hipLaunchKernelGGL((apply_s2d_u8_flicker_kernel<float, 3>), g3, dim3(256), 0, st, *a, (char*)out);
+    if (bf && ftl == 2) FLK_LAUNCH_KERNEL((apply_s2d_u8_flicker_kernel<bf16_t, 2>), g3, dim3(256), 0, st, *a, (char*)out);
+    else if (bf) FLK_LAUNCH_KERNEL((apply_s2d_u8_flicker_kernel<bf16_t, 3>), g3, dim3(256), 0, st, *a, (char*)out);
+    else if (ftl == 2) FLK_LAUNCH_KERNEL((apply_s2d_u8_flicker_kernel<float, 2>), g3, dim3(256), 0, st, *a, (char*)out);
+    else FLK_LAUNCH_KERNEL((apply_s2d_u8_flicker_kernel<float, 3>), g3, dim3(256), 0, st, *a, (char*)out);
     FLK_CHECK_HIP(hipGetLastError());
     return FLK_OK;
   }
-#define FLK_APPLY(TT, L) hipLaunchKernelGGL((apply_s2d_kernel<TT, L>), dim3(grid), dim3(256), 0, st, *a, (char*)out)
+#define FLK_APPLY(TT, L) FLK_LAUNCH_KERNEL((apply_s2d_kernel<TT, L>), dim3(grid), dim3(256), 0, st, *a, (char*)out)
   if (bf) { if (ftl == 1) FLK_APPLY(bf16_t, 1); else if (ftl == 2) FLK_APPLY(bf16_t, 2); else FLK_APPLY(bf16_t, 3); }
   else { if (ftl == 1) FLK_APPLY(float, 1); else if (ftl == 2) FLK_APPLY(float, 2); else FLK_APPLY(float, 3); }
 #undef FLK_APPLY
@@ -292,7 +292,7 @@ __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const flo
 
 // stage 2 alone, for producers of stage-1 partials outside this file (stem_grad.hip)
 int flk_grad_reduce_stage2_launch(const flk_apply_args* a, int nchunk, const float* partials, float* gdelta, hipStream_t s) {
-  hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128, a->delta_per_clip ? a->B : 1), dim3(128), 0, s, *a, nchunk, partials, gdelta);
+  FLK_LAUNCH_KERNEL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128, a->delta_per_clip ? a->B : 1), dim3(128), 0, s, *a, nchunk, partials, gdelta);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -362,7 +362,7 @@ extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s
   if (a->delta_dense) {
     const long total = (long)(a->T / ft) * (a->H / 2) * (a->W / 2);
     const unsigned grid = (unsigned)((total + 255) / 256);
-#define FLK_GD(TT, L) hipLaunchKernelGGL((grad_dense_kernel<TT, L>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta)
+#define FLK_GD(TT, L) FLK_LAUNCH_KERNEL((grad_dense_kernel<TT, L>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, gdelta)
     if (bf) { if (ftl == 1) FLK_GD(bf16_t, 1); else if (ftl == 2) FLK_GD(bf16_t, 2); else FLK_GD(bf16_t, 3); }
     else { if (ftl == 1) FLK_GD(float, 1); else if (ftl == 2) FLK_GD(float, 2); else FLK_GD(float, 3); }
 #undef FLK_GD
@@ -372,11 +372,11 @@ extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s
     // trajectory, bit for bit in fp32, as the same clip attacked alone
     const int nchunk = grad_nchunk(a->delta_per_clip ? 1 : a->B, a->T, a->H);
     const unsigned grid = (unsigned)(a->B * (a->T / ft) * nchunk);
-#define FLK_GR(TT, L) hipLaunchKernelGGL((grad_reduce_stage1<TT, L>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials)
+#define FLK_GR(TT, L) FLK_LAUNCH_KERNEL((grad_reduce_stage1<TT, L>), dim3(grid), dim3(256), 0, s, *a, (const char*)gx_s2d, nchunk, partials)
     if (bf) { if (ftl == 1) FLK_GR(bf16_t, 1); else if (ftl == 2) FLK_GR(bf16_t, 2); else FLK_GR(bf16_t, 3); }
     else { if (ftl == 1) FLK_GR(float, 1); else if (ftl == 2) FLK_GR(float, 2); else FLK_GR(float, 3); }
 #undef FLK_GR
-    hipLaunchKernelGGL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128, a->delta_per_clip ? a->B : 1), dim3(128), 0, s, *a, nchunk, partials, gdelta);
+    FLK_LAUNCH_KERNEL(grad_reduce_stage2, dim3((a->T * 3 + 127) / 128, a->delta_per_clip ? a->B : 1), dim3(128), 0, s, *a, nchunk, partials, gdelta);
   }
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
@@ -392,7 +392,7 @@ __global__ void pack_batch_sums_kernel(const float* per_clip, int B, float prob_
 
 extern "C" int flk_pack_batch_sums(const float* per_clip, int B, float prob_scale, float* out3, void* stream) {
   FLK_REQUIRE(per_clip && out3 && B > 0, "flk_pack_batch_sums: bad arguments");
-  hipLaunchKernelGGL(pack_batch_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, per_clip, B, prob_scale, out3);
+  FLK_LAUNCH_KERNEL(pack_batch_sums_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, per_clip, B, prob_scale, out3);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -489,7 +489,7 @@ extern "C" int flk_perturb_reg_adam(const flk_adam_args* a, const float* g_adv, 
   FLK_REQUIRE(a && g_adv && delta && m && v, "flk_perturb_reg_adam: null argument");
   FLK_REQUIRE(a->T > 0 && 3 * a->T <= 256 * ADAM_PER, "flk_perturb_reg_adam: T out of range (%d)", a->T);
   FLK_REQUIRE(a->step >= 1, "flk_perturb_reg_adam: step is 1-based");
-  hipLaunchKernelGGL(reg_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, (int*)nullptr, (const int*)nullptr, (const float*)nullptr);
+  FLK_LAUNCH_KERNEL(reg_adam_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, (int*)nullptr, (const int*)nullptr, (const float*)nullptr);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -499,7 +499,7 @@ extern "C" int flk_perturb_reg_adam_batched(const flk_adam_args* a, int nclip, c
   FLK_REQUIRE(a && g_adv && delta && m && v && steps_dev, "flk_perturb_reg_adam_batched: null argument");
   FLK_REQUIRE(nclip > 0 && nclip < 65536, "flk_perturb_reg_adam_batched: bad clip count %d", nclip);
   FLK_REQUIRE(a->T > 0 && 3 * a->T <= 256 * ADAM_PER, "flk_perturb_reg_adam_batched: T out of range (%d)", a->T);
-  hipLaunchKernelGGL(reg_adam_kernel, dim3((unsigned)nclip), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, steps_dev, active_dev, dyn_max_norm_dev);
+  FLK_LAUNCH_KERNEL(reg_adam_kernel, dim3((unsigned)nclip), dim3(256), 0, (hipStream_t)stream, *a, g_adv, delta, m, v, scalars, steps_dev, active_dev, dyn_max_norm_dev);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -602,10 +602,10 @@ extern "C" int flk_perturb_dense_l12_adam(const flk_dense_adam_args* a, const fl
   float* part = scratch;
   float* frame_rms = scratch + (size_t)a->T * DENSE_CHUNKS * 4;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(dense_frame_stats, dim3(DENSE_CHUNKS, a->T), dim3(256), 0, s, delta, fe, part,
+  FLK_LAUNCH_KERNEL(dense_frame_stats, dim3(DENSE_CHUNKS, a->T), dim3(256), 0, s, delta, fe, part,
                      a->dyn_max_norm > 0.f ? a->dyn_max_norm : INFINITY);
-  hipLaunchKernelGGL(dense_frame_finish, dim3(1), dim3(1024), 0, s, part, a->T, fe, frame_rms, scalars);
-  hipLaunchKernelGGL(dense_adam_kernel, dim3(64, a->T), dim3(256), 0, s, *a, fe, frame_rms, g_adv, delta, m, v);
+  FLK_LAUNCH_KERNEL(dense_frame_finish, dim3(1), dim3(1024), 0, s, part, a->T, fe, frame_rms, scalars);
+  FLK_LAUNCH_KERNEL(dense_adam_kernel, dim3(64, a->T), dim3(256), 0, s, *a, fe, frame_rms, g_adv, delta, m, v);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

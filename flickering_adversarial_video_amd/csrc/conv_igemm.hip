@@ -928,7 +928,7 @@ template <typename T, int NF, int WN, int MODE>
 static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
   static bool attr_set[FLK_MAX_DEVICES] = {};      // per device: one process may drive several GPUs
   if (int rc = flk_raise_lds_limit((const void*)conv_igemm_kernel<T, NF, WN, MODE>, 96 * 1024, attr_set)) return rc;
-  hipLaunchKernelGGL((conv_igemm_kernel<T, NF, WN, MODE>), grid, dim3(256), lds, s, kp);
+  FLK_LAUNCH_KERNEL((conv_igemm_kernel<T, NF, WN, MODE>), grid, dim3(256), lds, s, kp);
   flk_last_kernel_tag = "conv_igemm_kernel";
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
@@ -1124,7 +1124,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
         constexpr int Rv = 3;                                                                                                       \
         const size_t l5 = (size_t)Rv * (16384 + NFv * 1024);                                                                        \
         if (int rc = flk_raise_lds_limit((const void*)conv1x1_dma_kernel<NFv, Rv>, 96 * 1024, attr_set[idx])) return rc;           \
-        hipLaunchKernelGGL((conv1x1_dma_kernel<NFv, Rv>), g, dim3(256), l5, s, kp);                                                 \
+        FLK_LAUNCH_KERNEL((conv1x1_dma_kernel<NFv, Rv>), g, dim3(256), l5, s, kp);                                                 \
         flk_last_kernel_tag = "conv1x1_dma_kernel";                                                                                 \
         FLK_CHECK_HIP(hipGetLastError());                                                                                           \
         return FLK_OK;                                                                                                              \
@@ -1148,8 +1148,8 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     if (rc) return rc;
     const int epl = dtype == FLK_BF16 ? 8 : 4;
     const size_t n = (size_t)kp.npos * ((a->cout + epl - 1) / epl);
-    if (dtype == FLK_BF16) hipLaunchKernelGGL(conv_splitk_finish_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kp);
-    else hipLaunchKernelGGL(conv_splitk_finish_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kp);
+    if (dtype == FLK_BF16) FLK_LAUNCH_KERNEL(conv_splitk_finish_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kp);
+    else FLK_LAUNCH_KERNEL(conv_splitk_finish_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kp);
     FLK_CHECK_HIP(hipGetLastError());
     return FLK_OK;
   }

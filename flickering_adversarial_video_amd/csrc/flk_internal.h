@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libflicker_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -28,6 +29,24 @@ void flk_set_error(const char* fmt, ...);
       flk_set_error(__VA_ARGS__);       \
       return FLK_EINVAL;                \
     }                                   \
+  } while (0)
+
+// Every kernel launch of the library goes through FLK_LAUNCH_KERNEL.  When the plan (net.cpp) has armed flk_stop_event -- the launch is
+// the last one a stream does before another stream waits for it -- the kernel is launched with that event as its STOP event
+// (hipExtLaunchKernelGGL: the event is bound to the kernel's own completion signal), so the fork / join needs no separate
+// hipEventRecord marker packet behind the kernel.  Armed by the plan for single-launch operators only; the launch disarms it.
+extern thread_local hipEvent_t flk_stop_event;
+extern thread_local int flk_launch_count;      // kernel launches of this thread (the plan counts the launches of each operator)
+#define FLK_LAUNCH_KERNEL(kernel, grid, block, lds, stream, ...)                                         \
+  do {                                                                                                   \
+    ++flk_launch_count;                                                                                  \
+    hipEvent_t _flk_ev = flk_stop_event;                                                                 \
+    if (_flk_ev) {                                                                                       \
+      flk_stop_event = nullptr;                                                                          \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, _flk_ev, 0, __VA_ARGS__);         \
+    } else {                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                 \
+    }                                                                                                    \
   } while (0)
 
 // name of the kernel the last convolution-class launch of this thread went to (per-launch profile: flk_net_profile_read's "kernel")

@@ -141,9 +141,9 @@ int flk_head_forward(const void* y, int ld, int coff, int C, int B, int Tn, int 
                      const float* bias, int N, float* feat, float* logits, int dtype, hipStream_t s) {
   FLK_REQUIRE(C <= 2048 && N <= 1024, "head: C<=2048, N<=1024 supported");
   dim3 g1((C + 63) / 64, B);
-  if (dtype == FLK_BF16) hipLaunchKernelGGL(head_pool_kernel<bf16_t>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
-  else hipLaunchKernelGGL(head_pool_kernel<float>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
-  hipLaunchKernelGGL(head_fc_kernel, dim3((N + 63) / 64, B), dim3(1024), 0, s, feat, W, bias, C, N, logits);
+  if (dtype == FLK_BF16) FLK_LAUNCH_KERNEL(head_pool_kernel<bf16_t>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
+  else FLK_LAUNCH_KERNEL(head_pool_kernel<float>, g1, dim3(256), 0, s, (const char*)y, ld, coff, C, Tn, HW, wt, feat);
+  FLK_LAUNCH_KERNEL(head_fc_kernel, dim3((N + 63) / 64, B), dim3(1024), 0, s, feat, W, bias, C, N, logits);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -154,13 +154,13 @@ int flk_head_backward(const void* y, int ld, int coff, void* gy, int gld, int gc
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   FLK_REQUIRE(C % epl == 0 && ld % epl == 0 && coff % epl == 0 && gld % epl == 0 && gcoff % epl == 0 && N <= 1024 &&
               (long)B * Tn * HW * (C / epl) < (1l << 31), "head backward: channel counts / strides must be multiples of %d", epl);
-  hipLaunchKernelGGL(head_fc_bwd_kernel, dim3((C + 15) / 16, B), dim3(256), 0, s, dlogits, W, C, N, dfeat);
+  FLK_LAUNCH_KERNEL(head_fc_bwd_kernel, dim3((C + 15) / 16, B), dim3(256), 0, s, dlogits, W, C, N, dfeat);
   const long total = (long)B * Tn * HW * (C / epl);
   const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   if (dtype == FLK_BF16)
-    hipLaunchKernelGGL(head_pool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const char*)y, ld, coff, (char*)gy, gld, gcoff, C, Tn, HW, B, wt, dfeat, use_mask);
+    FLK_LAUNCH_KERNEL(head_pool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const char*)y, ld, coff, (char*)gy, gld, gcoff, C, Tn, HW, B, wt, dfeat, use_mask);
   else
-    hipLaunchKernelGGL(head_pool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const char*)y, ld, coff, (char*)gy, gld, gcoff, C, Tn, HW, B, wt, dfeat, use_mask);
+    FLK_LAUNCH_KERNEL(head_pool_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const char*)y, ld, coff, (char*)gy, gld, gcoff, C, Tn, HW, B, wt, dfeat, use_mask);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -305,7 +305,7 @@ extern "C" int flk_softmax_adv_loss(const flk_loss_args* a, const float* logits,
               "flk_softmax_adv_loss: the reference's targeted improve-loss is non-functional in the torch dialect "
               "(model.py:223-225 references undefined names); refusing to guess");
   FLK_REQUIRE(a->margin > 0.f || !a->improve_loss, "flk_softmax_adv_loss: margin must be > 0");
-  hipLaunchKernelGGL(softmax_adv_loss_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a, logits, labels, softmax, dlogits, per_clip);
+  FLK_LAUNCH_KERNEL(softmax_adv_loss_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, *a, logits, labels, softmax, dlogits, per_clip);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

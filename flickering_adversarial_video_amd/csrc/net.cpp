@@ -33,6 +33,7 @@ struct Op {
   double flops;   // algorithmic flops (2*MAC) for conv ops, 0 otherwise
   double bytes;   // algorithmic HBM bytes (compulsory traffic) for memory-bound ops
   std::function<int(hipStream_t)> run;
+  int nlaunch = 0;   // kernel launches of the operator's last run (run_ops counts them: single-launch operators can carry a stop event)
   int lane = 0;   // 0 = the caller's stream, 1..kSideStreams = side streams (between a fork and its join)
   int mask = ~0;  // fork: which side streams start here (bit l = side stream l); the others keep what they were doing
 };
@@ -1126,6 +1127,35 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
   }
   // per-layer profiling runs the plan serially on the caller's stream: durations of co-running kernels would overlap
   const bool ms = n->multi_stream && n->side[0] && !n->profile;
+  // Fork / join events riding on kernels (FLK_EXT_EVENTS=0: every fork / join records its event with a marker packet of its own).
+  // The last operator a stream runs before another stream waits for it is launched with the fork's / join's event as its STOP event
+  // (FLK_LAUNCH_KERNEL): arm[i] = event for operator i, or null; armed operators are single-launch ones (nlaunch of their last run).
+  static const bool ext_ev = !(getenv("FLK_EXT_EVENTS") && atoi(getenv("FLK_EXT_EVENTS")) == 0);
+  std::vector<hipEvent_t> arm(ops.size(), nullptr);
+  std::vector<char> rode(ops.size() * (kSideStreams + 1), 0);      // [sync op][0 = fork | 1 + side stream]: its event rode on a kernel
+  if (ms && ext_ev) {
+    int last[kSideStreams + 1];
+    for (int& l : last) l = -1;
+    unsigned nf = 0;
+    for (size_t i = 0; i < ops.size(); ++i) {
+      const Op& op = ops[i];
+      if (op.kind == K_FORK) {
+        hipEvent_t e = n->ev_fork[nf++ & 1];
+        if (last[0] >= 0 && ops[last[0]].nlaunch == 1 && !arm[last[0]]) { arm[last[0]] = e; rode[i * (kSideStreams + 1)] = 1; }
+        last[0] = -1;                                   // (an event rides on a kernel once)
+      } else if (op.kind == K_JOIN) {
+        for (int l = 0; l < kSideStreams; ++l) {
+          if (!(op.mask >> l & 1)) continue;
+          const int j = last[l + 1];
+          if (j >= 0 && ops[j].nlaunch == 1 && !arm[j]) { arm[j] = n->ev_join[l]; rode[i * (kSideStreams + 1) + 1 + l] = 1; }
+          last[l + 1] = -1;
+        }
+        last[0] = -1;      // the caller's stream waits here: a later fork's event must fire behind these waits, not with an earlier kernel
+      } else {
+        last[op.lane] = (int)i == replace_op ? -1 : (int)i;     // (the replaced operator -- the fused stem kernel -- launches several kernels)
+      }
+    }
+  }
   bool in_fork = false;
   unsigned n_fork = 0;
   for (size_t i = 0; i < ops.size(); ++i) {
@@ -1134,7 +1164,7 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       in_fork = true;
       if (ms) {
         hipEvent_t e = n->ev_fork[n_fork++ & 1];          // two forks per block: alternate the event objects
-        FLK_CHECK_HIP(hipEventRecord(e, s));
+        if (!rode[i * (kSideStreams + 1)]) FLK_CHECK_HIP(hipEventRecord(e, s));
         for (int l = 0; l < kSideStreams; ++l)
           if (op.mask >> l & 1) FLK_CHECK_HIP(hipStreamWaitEvent(n->side[l], e, 0));
       }
@@ -1145,7 +1175,7 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       if (ms)
         for (int l = 0; l < kSideStreams; ++l) {
           if (!(op.mask >> l & 1)) continue;              // side streams that took no part in this fork
-          FLK_CHECK_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
+          if (!rode[i * (kSideStreams + 1) + 1 + l]) FLK_CHECK_HIP(hipEventRecord(n->ev_join[l], n->side[l]));
           FLK_CHECK_HIP(hipStreamWaitEvent(s, n->ev_join[l], 0));
         }
       continue;
@@ -1155,8 +1185,14 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
     // conditions they will run in; branch kernels co-run with their siblings, where the isolated optimum is not the best
     if (n->tuning) flk_conv_set_autotune(!in_fork);
     if (n->profile) { FLK_CHECK_HIP(hipEventRecord(ev[i].first, st)); flk_last_kernel_tag = ""; }
+    const int lc0 = flk_launch_count;
+    flk_stop_event = arm[i];
     int rc = ((int)i == replace_op && replacement) ? (*replacement)(st) : op.run(st);
+    const bool taken = arm[i] && !flk_stop_event;
+    flk_stop_event = nullptr;
     if (rc) return rc;
+    if (arm[i] && !taken) FLK_CHECK_HIP(hipEventRecord(arm[i], st));      // (armed but the operator launched nothing: record the plain way)
+    op.nlaunch = flk_launch_count - lc0;
     if (n->profile) { FLK_CHECK_HIP(hipEventRecord(ev[i].second, st)); tags[i] = flk_last_kernel_tag; }
   }
   ev_valid = n->profile;

@@ -221,7 +221,7 @@ static int launch_strided_bwd(const PoolKP& kp, const flk_pool_args* a, hipStrea
   constexpr int EPL = PV<T>::EPL;
   FLK_REQUIRE(a->Ho < 65536 && (long)a->B * a->To < 65536, "flk_maxpool3d_bwd: grid too large");
   const dim3 grid((unsigned)((a->Wo * (a->C / EPL) + 255) / 256), (unsigned)a->Ho, (unsigned)(a->B * a->To));
-  hipLaunchKernelGGL((maxpool_strided_bwd<T, KT, KH, KW, ST, SH, SW>), grid, dim3(256), 0, s, kp);
+  FLK_LAUNCH_KERNEL((maxpool_strided_bwd<T, KT, KH, KW, ST, SH, SW>), grid, dim3(256), 0, s, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -530,7 +530,7 @@ static int launch_wrun_fwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   static bool attr_set[FLK_MAX_DEVICES] = {};
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_wrun_fwd_bf16<WT>, 96 * 1024, attr_set)) return rc;
-  hipLaunchKernelGGL((maxpool_s1_wrun_fwd_bf16<WT>), grid, dim3(256), lds, s, tp);
+  FLK_LAUNCH_KERNEL((maxpool_s1_wrun_fwd_bf16<WT>), grid, dim3(256), lds, s, tp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -903,7 +903,7 @@ static int launch_scatter_bwd(const PoolKP& kp, const flk_pool_args* a, hipStrea
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
   tp.plane_b = (tp.rows + 47) / 64 * 64 + 16;                         // accumulator plane stride in floats, = 16 (mod 64)
   const size_t lds = (size_t)(4 * tp.plane_b * EPL + 256) * sizeof(float);    // <= 35 KiB (+ one dummy word per thread)
-  hipLaunchKernelGGL(maxpool_scatter_bwd<T>, grid, dim3(256), lds, s, tp, magic(a->kh * a->kw), magic(a->kw));
+  FLK_LAUNCH_KERNEL(maxpool_scatter_bwd<T>, grid, dim3(256), lds, s, tp, magic(a->kh * a->kw), magic(a->kw));
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -933,14 +933,14 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
   static bool attr_fwd[FLK_MAX_DEVICES] = {}, attr_bwd[FLK_MAX_DEVICES] = {};
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_fwd<T>, 96 * 1024, attr_fwd)) return rc;
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_bwd<T>, 96 * 1024, attr_bwd)) return rc;
-  if (bwd) hipLaunchKernelGGL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
+  if (bwd) FLK_LAUNCH_KERNEL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
   else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3 && a->pt == 1 && a->ph == 1 && a->pw == 1 && !getenv("FLK_POOL_NO_WRUN")) {
     return a->Wo % 7 == 0 ? launch_wrun_fwd<7>(kp, a, s) : launch_wrun_fwd<8>(kp, a, s);
   } else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
     static bool attr2[FLK_MAX_DEVICES] = {};
     if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_fwd_bf16<3, 3, 3>, 96 * 1024, attr2)) return rc;
-    hipLaunchKernelGGL((maxpool_s1_tiled_fwd_bf16<3, 3, 3>), grid, dim3(256), lds, s, tp);
-  } else hipLaunchKernelGGL(maxpool_s1_tiled_fwd<T>, grid, dim3(256), lds, s, tp);
+    FLK_LAUNCH_KERNEL((maxpool_s1_tiled_fwd_bf16<3, 3, 3>), grid, dim3(256), lds, s, tp);
+  } else FLK_LAUNCH_KERNEL(maxpool_s1_tiled_fwd<T>, grid, dim3(256), lds, s, tp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -983,8 +983,8 @@ extern "C" int flk_maxpool3d_fwd(const flk_pool_args* a, int dtype, void* stream
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   FLK_REQUIRE(a->Ho < 65536 && (long)a->B * a->To < 65536, "flk_maxpool3d_fwd: grid too large");
   const dim3 grid((unsigned)((a->Wo * (a->C / epl) + 255) / 256), (unsigned)a->Ho, (unsigned)(a->B * a->To));
-  if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
-  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  if (dtype == FLK_BF16) FLK_LAUNCH_KERNEL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  else FLK_LAUNCH_KERNEL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -1025,8 +1025,8 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   FLK_REQUIRE(a->Hi < 65536 && (long)a->B * a->Ti < 65536, "flk_maxpool3d_bwd: grid too large");
   const dim3 grid((unsigned)((a->Wi * (a->C / epl) + 255) / 256), (unsigned)a->Hi, (unsigned)(a->B * a->Ti));
-  if (dtype == FLK_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
-  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  if (dtype == FLK_BF16) FLK_LAUNCH_KERNEL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  else FLK_LAUNCH_KERNEL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -1095,10 +1095,10 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   hipStream_t s = (hipStream_t)stream;
   const unsigned m1 = magic(a->kh * a->kw), m2 = magic(a->kw);
   switch (pg.KS) {
-    case 1: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<1>, grid, dim3(256), lds, s, pg, m1, m2); break;
-    case 2: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<2>, grid, dim3(256), lds, s, pg, m1, m2); break;
-    case 3: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<3>, grid, dim3(256), lds, s, pg, m1, m2); break;
-    default: hipLaunchKernelGGL(maxpool_scatter_gemm_bwd<4>, grid, dim3(256), lds, s, pg, m1, m2); break;
+    case 1: FLK_LAUNCH_KERNEL(maxpool_scatter_gemm_bwd<1>, grid, dim3(256), lds, s, pg, m1, m2); break;
+    case 2: FLK_LAUNCH_KERNEL(maxpool_scatter_gemm_bwd<2>, grid, dim3(256), lds, s, pg, m1, m2); break;
+    case 3: FLK_LAUNCH_KERNEL(maxpool_scatter_gemm_bwd<3>, grid, dim3(256), lds, s, pg, m1, m2); break;
+    default: FLK_LAUNCH_KERNEL(maxpool_scatter_gemm_bwd<4>, grid, dim3(256), lds, s, pg, m1, m2); break;
   }
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;

@@ -381,13 +381,13 @@ extern "C" int flk_stem_fwd_u8(const flk_apply_args* a, const flk_conv_weights* 
     kp.chunk = (kp.ntiles + 7) / 8;
     static bool attr_set[FLK_MAX_DEVICES] = {};
     if (int rc = flk_raise_lds_limit((const void*)stem_fwd_u8_kernel<4>, SfGeo<4>::LDS, attr_set)) return rc;
-    hipLaunchKernelGGL(stem_fwd_u8_kernel<4>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<4>::LDS, st, kp);
+    FLK_LAUNCH_KERNEL(stem_fwd_u8_kernel<4>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<4>::LDS, st, kp);
   } else {
     kp.ntiles = a->B * kp.nTt * SfGeo<8>::NTH * 14;
     kp.chunk = (kp.ntiles + 7) / 8;
     static bool attr_set[FLK_MAX_DEVICES] = {};
     if (int rc = flk_raise_lds_limit((const void*)stem_fwd_u8_kernel<8>, SfGeo<8>::LDS, attr_set)) return rc;
-    hipLaunchKernelGGL(stem_fwd_u8_kernel<8>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<8>::LDS, st, kp);
+    FLK_LAUNCH_KERNEL(stem_fwd_u8_kernel<8>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<8>::LDS, st, kp);
   }
   FLK_CHECK_HIP(hipGetLastError());
   flk_last_kernel_tag = "stem_fwd_u8_kernel";

@@ -421,7 +421,7 @@ extern "C" int flk_stem_delta_grad_mask(const flk_apply_args* a, float* scratch,
   FLK_REQUIRE(scratch, "flk_stem_delta_grad_mask: null scratch");
   char* const mask = (char*)scratch + sg_partial_bytes(a->B, a->T, a->H);
   const long nrows = (long)a->B * a->T * a->H;
-  hipLaunchKernelGGL(stem_mask_kernel, dim3((unsigned)(nrows < 8192 ? nrows : 8192)), dim3(256), 0, (hipStream_t)stream, *a, mask);
+  FLK_LAUNCH_KERNEL(stem_mask_kernel, dim3((unsigned)(nrows < 8192 ? nrows : 8192)), dim3(256), 0, (hipStream_t)stream, *a, mask);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -449,7 +449,7 @@ extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g
   if ((rc = flk_raise_lds_limit((const void*)stem_delta_grad_kernel, SG_LDS, attr_set))) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (!mask_done && (rc = flk_stem_delta_grad_mask(a, scratch, stream))) return rc;
-  hipLaunchKernelGGL(stem_delta_grad_kernel, dim3((unsigned)(a->B * kp.To * kp.nchunk)), dim3(SG_THREADS), SG_LDS, s, kp);
+  FLK_LAUNCH_KERNEL(stem_delta_grad_kernel, dim3((unsigned)(a->B * kp.To * kp.nchunk)), dim3(SG_THREADS), SG_LDS, s, kp);
   FLK_CHECK_HIP(hipGetLastError());
   flk_last_kernel_tag = "stem_delta_grad_kernel";
   flk_apply_args a2 = *a;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(64) void stem_delta_bias_kernel(const flk_apply_arg
 extern "C" int flk_stem_delta_bias(const flk_apply_args* a, const float* sums_dev, float* table_out, void* stream) {
   FLK_REQUIRE(a && a->delta && sums_dev && table_out, "flk_stem_delta_bias: null argument");
   FLK_REQUIRE(!a->delta_dense && a->T >= 2 && a->T % 2 == 0, "flk_stem_delta_bias: flicker perturbation [T,3], even T");
-  hipLaunchKernelGGL(stem_delta_bias_kernel, dim3((unsigned)(a->T / 2 * 16), (unsigned)(a->delta_per_clip ? a->B : 1)), dim3(64), 0, (hipStream_t)stream,
+  FLK_LAUNCH_KERNEL(stem_delta_bias_kernel, dim3((unsigned)(a->T / 2 * 16), (unsigned)(a->delta_per_clip ? a->B : 1)), dim3(64), 0, (hipStream_t)stream,
                      *a, sums_dev, table_out);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;

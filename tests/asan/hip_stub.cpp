@@ -44,6 +44,10 @@ hipError_t hipLaunchKernel(const void*, dim3 grid, dim3 block, void**, size_t ld
   ++g_launches;
   return hipSuccess;
 }
+// hipExtLaunchKernelGGL (fork / join events riding on kernels): same checks, the events are ignored
+hipError_t hipExtLaunchKernel(const void* f, dim3 grid, dim3 block, void** args, size_t lds, hipStream_t s, hipEvent_t, hipEvent_t, int) {
+  return hipLaunchKernel(f, grid, block, args, lds, s);
+}
 // kernel-launch plumbing emitted by clang for <<< >>> / hipLaunchKernelGGL and the module constructor
 struct CallCfg { dim3 g, b; size_t lds; hipStream_t s; };
 static thread_local CallCfg g_cfg;
