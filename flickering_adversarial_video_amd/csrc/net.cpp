@@ -145,6 +145,7 @@ struct flk_net {
   hipStream_t side[kSideStreams] = {nullptr, nullptr};
   hipStream_t mask_stream = nullptr;   // the stem clip-mask pre-pass has a stream of its own: on a branch lane it delayed that lane's first kernels
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[kSideStreams] = {nullptr, nullptr};
+  hipEvent_t ev_main[2] = {nullptr, nullptr};     // "the caller's stream up to its last kernel before a join" (forks that follow a join directly)
   hipEvent_t ev_mask_fork = nullptr, ev_mask_done = nullptr;     // the stem clip-mask pre-pass runs beside the backward pass
   // flk_net_prepare_backward_delta: the clip mask of the coming flk_net_backward_delta is already being computed (into `premask_scratch`,
   // for these arguments) on mask_stream
@@ -1046,6 +1047,7 @@ extern "C" int flk_net_destroy(flk_net* n) {
   }
   if (n->mask_stream) (void)hipStreamDestroy(n->mask_stream);
   for (auto e : n->ev_fork) if (e) (void)hipEventDestroy(e);
+  for (auto e : n->ev_main) if (e) (void)hipEventDestroy(e);
   if (n->ev_mask_fork) (void)hipEventDestroy(n->ev_mask_fork);
   if (n->ev_mask_done) (void)hipEventDestroy(n->ev_mask_done);
   flk_stem_delta_grad_weights_destroy(n->d_stem_wf);
@@ -1092,6 +1094,7 @@ extern "C" int flk_net_finalize(flk_net* n) {
   }
   FLK_CHECK_HIP(hipStreamCreateWithFlags(&n->mask_stream, hipStreamNonBlocking));
   for (auto& e : n->ev_fork) FLK_CHECK_HIP(hipEventCreateWithFlags(&e, evf));
+  for (auto& e : n->ev_main) FLK_CHECK_HIP(hipEventCreateWithFlags(&e, evf));
   FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_fork, evf));
   FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_done, evf));
   n->multi_stream = !getenv("FLK_SINGLE_STREAM");
@@ -1133,17 +1136,29 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
   static const bool ext_ev = !(getenv("FLK_EXT_EVENTS") && atoi(getenv("FLK_EXT_EVENTS")) == 0);
   std::vector<hipEvent_t> arm(ops.size(), nullptr);
   std::vector<char> rode(ops.size() * (kSideStreams + 1), 0);      // [sync op][0 = fork | 1 + side stream]: its event rode on a kernel
+  // A fork that follows a join directly (forward pass: block k's join, block k + 1's pool fork) needs no event of its own: the forked
+  // streams wait for what the caller's stream waited for at the join (the other side streams' join events) and for the caller's stream's
+  // last kernel before the join (ev_main, riding on it).  derived[i] = index of that join, or -1; dmain[i] = its ev_main.
+  std::vector<int> derived(ops.size(), -1);
+  std::vector<hipEvent_t> dmain(ops.size(), nullptr);
   if (ms && ext_ev) {
     int last[kSideStreams + 1];
     for (int& l : last) l = -1;
-    unsigned nf = 0;
+    unsigned nf = 0, nm = 0;
+    int last_join = -1, main_before_join = -1;
     for (size_t i = 0; i < ops.size(); ++i) {
       const Op& op = ops[i];
       if (op.kind == K_FORK) {
         hipEvent_t e = n->ev_fork[nf++ & 1];
         if (last[0] >= 0 && ops[last[0]].nlaunch == 1 && !arm[last[0]]) { arm[last[0]] = e; rode[i * (kSideStreams + 1)] = 1; }
+        else if (last[0] < 0 && last_join >= 0 && main_before_join >= 0 && ops[main_before_join].nlaunch == 1 && !arm[main_before_join]) {
+          hipEvent_t em = n->ev_main[nm++ & 1];
+          arm[main_before_join] = em; derived[i] = last_join; dmain[i] = em;
+        }
         last[0] = -1;                                   // (an event rides on a kernel once)
+        last_join = -1;
       } else if (op.kind == K_JOIN) {
+        last_join = (int)i; main_before_join = last[0];
         for (int l = 0; l < kSideStreams; ++l) {
           if (!(op.mask >> l & 1)) continue;
           const int j = last[l + 1];
@@ -1153,6 +1168,7 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
         last[0] = -1;      // the caller's stream waits here: a later fork's event must fire behind these waits, not with an earlier kernel
       } else {
         last[op.lane] = (int)i == replace_op ? -1 : (int)i;     // (the replaced operator -- the fused stem kernel -- launches several kernels)
+        if (op.lane == 0) last_join = -1;                       // work on the caller's stream between the join and a fork: not "directly"
       }
     }
   }
@@ -1164,6 +1180,16 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       in_fork = true;
       if (ms) {
         hipEvent_t e = n->ev_fork[n_fork++ & 1];          // two forks per block: alternate the event objects
+        if (derived[i] >= 0) {
+          const Op& jn = ops[derived[i]];
+          for (int l = 0; l < kSideStreams; ++l) {
+            if (!(op.mask >> l & 1)) continue;
+            FLK_CHECK_HIP(hipStreamWaitEvent(n->side[l], dmain[i], 0));
+            for (int l2 = 0; l2 < kSideStreams; ++l2)
+              if (l2 != l && (jn.mask >> l2 & 1)) FLK_CHECK_HIP(hipStreamWaitEvent(n->side[l], n->ev_join[l2], 0));
+          }
+          continue;
+        }
         if (!rode[i * (kSideStreams + 1)]) FLK_CHECK_HIP(hipEventRecord(e, s));
         for (int l = 0; l < kSideStreams; ++l)
           if (op.mask >> l & 1) FLK_CHECK_HIP(hipStreamWaitEvent(n->side[l], e, 0));
