@@ -153,6 +153,7 @@ struct flk_net {
   float* premask_scratch = nullptr;
   flk_apply_args premask_args{};
   bool multi_stream = true;
+  bool ext_events = true;      // fork / join events ride on kernels as stop events (FLK_EXT_EVENTS=0 at finalize: marker packets)
   bool tuning = false;
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fwd, ev_bwd;
@@ -1098,6 +1099,7 @@ extern "C" int flk_net_finalize(flk_net* n) {
   FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_fork, evf));
   FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_mask_done, evf));
   n->multi_stream = !getenv("FLK_SINGLE_STREAM");
+  n->ext_events = !(getenv("FLK_EXT_EVENTS") && atoi(getenv("FLK_EXT_EVENTS")) == 0);
   FLK_CHECK_HIP(hipDeviceSynchronize());
   n->finalized = true;
   return FLK_OK;
@@ -1133,7 +1135,7 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
   // Fork / join events riding on kernels (FLK_EXT_EVENTS=0: every fork / join records its event with a marker packet of its own).
   // The last operator a stream runs before another stream waits for it is launched with the fork's / join's event as its STOP event
   // (FLK_LAUNCH_KERNEL): arm[i] = event for operator i, or null; armed operators are single-launch ones (nlaunch of their last run).
-  static const bool ext_ev = !(getenv("FLK_EXT_EVENTS") && atoi(getenv("FLK_EXT_EVENTS")) == 0);
+  const bool ext_ev = n->ext_events;
   std::vector<hipEvent_t> arm(ops.size(), nullptr);
   std::vector<char> rode(ops.size() * (kSideStreams + 1), 0);      // [sync op][0 = fork | 1 + side stream]: its event rode on a kernel
   // A fork that follows a join directly (forward pass: block k's join, block k + 1's pool fork) needs no event of its own: the forked

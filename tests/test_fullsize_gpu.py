@@ -133,23 +133,27 @@ def test_fork_join_events_without_system_fence_give_the_same_bits(env):
     from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
     W, x = env
     outs = []
-    for flags in ("2", None):                                   # 0x2 = hipEventDisableTiming
-        if flags is None:
-            os.environ.pop("FLK_EVENT_FLAGS", None)
-        else:
-            os.environ["FLK_EVENT_FLAGS"] = flags
+    # third variant: the product flags with the events recorded by marker packets of their own (FLK_EXT_EVENTS=0) instead of riding on
+    # the kernels as stop events (hipExtLaunchKernelGGL) -- where an event fires must not change a bit either
+    for flags, ext in (("2", None), (None, "0"), (None, None)):   # 0x2 = hipEventDisableTiming
+        for k, v in (("FLK_EVENT_FLAGS", flags), ("FLK_EXT_EVENTS", ext)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         try:
             e = FlickerI3D(W, batch_size=B, frames=T, dtype="bf16")
         finally:
             os.environ.pop("FLK_EVENT_FLAGS", None)
+            os.environ.pop("FLK_EXT_EVENTS", None)
         labels = e.logits(x, adv_flag=0.0).argmax(-1).clone()
         for _ in range(3):
             r = e.step(x, labels, **HP)
         outs.append((e._logits.clone(), e.delta_gradient().clone(), e.perturbation.clone(), r["adv_loss"].clone()))
         del e
         torch.cuda.empty_cache()
-    for a_, b_ in zip(*outs):
-        assert torch.equal(a_, b_)
+    for a_, b_, c_ in zip(*outs):
+        assert torch.equal(a_, b_) and torch.equal(a_, c_)
 
 
 def test_bf16_attack_level_equivalence(env):
