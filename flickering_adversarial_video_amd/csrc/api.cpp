@@ -7,7 +7,7 @@
 static thread_local char g_err[1024] = "";
 thread_local const char* flk_last_kernel_tag = "";
 thread_local hipEvent_t flk_stop_event = nullptr;
-thread_local int flk_launch_count = 0;
+thread_local unsigned flk_launch_count = 0;
 
 void flk_set_error(const char* fmt, ...) {
   va_list ap;

@@ -36,7 +36,7 @@ void flk_set_error(const char* fmt, ...);
 // (hipExtLaunchKernelGGL: the event is bound to the kernel's own completion signal), so the fork / join needs no separate
 // hipEventRecord marker packet behind the kernel.  Armed by the plan for single-launch operators only; the launch disarms it.
 extern thread_local hipEvent_t flk_stop_event;
-extern thread_local int flk_launch_count;      // kernel launches of this thread (the plan counts the launches of each operator)
+extern thread_local unsigned flk_launch_count;      // kernel launches of this thread (the plan counts the launches of each operator)
 #define FLK_LAUNCH_KERNEL(kernel, grid, block, lds, stream, ...)                                         \
   do {                                                                                                   \
     ++flk_launch_count;                                                                                  \

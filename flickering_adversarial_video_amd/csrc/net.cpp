@@ -1213,14 +1213,14 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
     // conditions they will run in; branch kernels co-run with their siblings, where the isolated optimum is not the best
     if (n->tuning) flk_conv_set_autotune(!in_fork);
     if (n->profile) { FLK_CHECK_HIP(hipEventRecord(ev[i].first, st)); flk_last_kernel_tag = ""; }
-    const int lc0 = flk_launch_count;
+    const unsigned lc0 = flk_launch_count;
     flk_stop_event = arm[i];
     int rc = ((int)i == replace_op && replacement) ? (*replacement)(st) : op.run(st);
     const bool taken = arm[i] && !flk_stop_event;
     flk_stop_event = nullptr;
     if (rc) return rc;
     if (arm[i] && !taken) FLK_CHECK_HIP(hipEventRecord(arm[i], st));      // (armed but the operator launched nothing: record the plain way)
-    op.nlaunch = flk_launch_count - lc0;
+    op.nlaunch = (int)(flk_launch_count - lc0);
     if (n->profile) { FLK_CHECK_HIP(hipEventRecord(ev[i].second, st)); tags[i] = flk_last_kernel_tag; }
   }
   ev_valid = n->profile;
