@@ -20,9 +20,12 @@
 // and neither gx (205 MB at bs 8) nor the space-to-depth clip is read or written.
 //
 // Two launches:
-//  1. stem_mask_kernel (HBM-bound, 0.27 GB written at bs 8): the clip mask in the GEMM's B-operand order -- per (clip, frame, input row h)
-//     21 = 3 x 7 byte rows E[c*7+kw][ow] = m[h, 2*ow+kw-2, c] (0x40 = pass, 0x00 = clipped / outside the frame): the stride-2 tap shift
-//     is resolved here, so every B fragment of the GEMM is 8 CONSECUTIVE bytes.
+//  1. stem_mask_kernel (88 MB written at bs 8 x 64 frames): the clip mask de-interleaved -- per (clip, frame, input row h) 6 byte sequences
+//     (channel c, pixel parity), byte 9 + i = m[h, 2 i + parity, c] (0x40 = pass, 0x00 = clipped), zero padded = outside the frame.  Column
+//     (c, kw) of the B operand at output position ow is byte 9 + ow + (kw>>1) - 1 of sequence (c, kw & 1): the stride-2 tap becomes a byte
+//     shift of 0..3 inside 12 ALIGNED bytes.  (Round 2 stored all 7 shifts, 21 rows of 112 bytes per input row: every B fragment was 8
+//     consecutive bytes, but the mask was 270 MB and its pre-pass cost the step 0.09 ms; this layout is 3x smaller, the GEMM pays one more
+//     ds_read_b32 per fragment, +3 %.)
 //  2. stem_delta_grad_kernel: workgroup = (clip b, frame pair t2, chunk of output rows), 8 waves.  Waves 0..6 only run MFMAs: wave (p, q) owns
 //     C for output frame ot = t2+1-p and clip frame t = 2*t2+q (tap kt = 2p+q), 64 x 160 accumulators; the odd frame has three taps, so
 //     wave 7 has no MFMA work: it is the PRODUCER.  It feeds the G tiles (two K steps ahead, three LDS buffers) and the mask rows (ring of
@@ -31,8 +34,9 @@
 //     K step = 32 output positions = 4 runs of 8 consecutive ow:
 //       A (G^T): the [32 positions][4 planes][64 ch] tile sits row-major in LDS (128-byte rows; the XOR swizzle of the 16-byte slots is
 //                applied on the DMA's SOURCE address) and is read with ds_read_b64_tr_b16 (hardware transpose: lane = channel, 8 positions);
-//       B (mask): 8 bytes per lane; a byte is 0x00 / 0x40, so two v_perm_b32 turn 4 bytes into 4 bf16 values 0.0 / 2.0 (bf16 2.0 =
-//                0x4000: its low byte is zero); the factor 2 is undone in the epilogue.
+//       B (mask): 12 aligned bytes per lane (ds_read_b64 + ds_read_b32) of which it uses 8, from byte kw>>1 on; a byte is 0x00 / 0x40, so
+//                four v_perm_b32 -- their selectors carry the byte shift -- turn them into 8 bf16 values 0.0 / 2.0 (bf16 2.0 = 0x4000: its low
+//                byte is zero); the factor 2 is undone in the epilogue.
 // Partials are written in the layout of attack.hip's grad_reduce_stage1, so its deterministic stage 2 (batch / chunk sum in a
 // fixed order, roll, 1/std, delta-clip mask) is reused unchanged.
 #include <stdlib.h>
@@ -46,13 +50,15 @@ constexpr int SG_NCOL = 147;           // 3 * 7 * 7 columns (c, kh, kw)
 constexpr int SG_NPAD = 160;           // padded to 10 fragments of 16
 constexpr int SG_NF = SG_NPAD / 16;
 constexpr int SG_WO = 112;             // output width (the I3D stem on 224 x 224 frames)
-constexpr int SG_MROW = SG_WO;         // bytes per (c, kw) mask row: 112 B = 28 banks -> the 16 rows of a fragment read hit distinct banks
-constexpr int SG_ROWSET = 21 * SG_MROW;   // one input row of one frame: 3 channels x 7 kw = 2352 bytes = 147 x 16
+constexpr int SG_MPAD = 9;             // zero bytes in front of a mask sequence: the 8 positions of a run + tap shift s = kw>>1 start at byte 8 + 8 m + s
+constexpr int SG_MSEQ = 128;           // one mask sequence (channel c, w parity): 9 zeros | 112 mask bytes | 7 zeros
+constexpr int SG_ROWSET = 6 * SG_MSEQ;    // one input row of one frame in HBM: 3 channels x 2 parities = 768 bytes = 48 x 16
+constexpr int SG_RPITCH = SG_ROWSET + 48; // pitch of a ring slot in LDS: 204 dwords = 12 banks mod 64 (consecutive rows kh land on different banks)
 constexpr int SG_RING = 16;            // input rows kept per frame (9 live + 4 in flight)
 constexpr int SG_GTILE = 4 * 32 * 128;    // bytes of one K step's G tile: 4 planes x 32 positions x 64 bf16
 constexpr int SG_GBUFS = 3;            // G tiles: two K steps of DMA look-ahead
 constexpr int SG_OFF_MRING = SG_GBUFS * SG_GTILE;
-constexpr int SG_OFF_RED = SG_OFF_MRING + 2 * SG_RING * SG_ROWSET;
+constexpr int SG_OFF_RED = SG_OFF_MRING + 2 * SG_RING * SG_RPITCH;
 constexpr int SG_LDS = SG_OFF_RED + 8 * 3 * 4;
 
 struct StemGradKP {
@@ -75,76 +81,74 @@ __device__ inline float sg_pert(const flk_apply_args& a, int b, int t, int c) {
   return d * a.inv_std[c];
 }
 
-// ---- 1. the clip mask in B-operand order ----
-// One workgroup walks over (clip, frame, row) triples.  Per row: the 672 interleaved RGB values are read once (coalesced) and their pass
-// bits written into 6 byte sequences S[c][w parity][w/2] in LDS; the 21 (c, kw) rows of E are byte-shifted windows of those sequences
-// (row kw = sequence kw&1 shifted by (kw>>1)-1, zero beyond the frame): two aligned LDS dwords + v_alignbyte_b32 per 4 mask bytes,
-// stored as 147 coalesced 16-byte pieces.  HBM-bound: 1 read of the clip, 3.5x that written.
-constexpr int SM_SEQ = 120;            // bytes per sequence: 4 zeros | 112 mask bytes | 4 zeros
+// ---- 1. the clip mask, de-interleaved ----
+// Per (clip, frame, row) the mask is kept as 6 byte sequences (channel c, pixel parity): byte SG_MPAD + i of sequence (c, par) is the pass
+// byte (0x40 = pass, 0x00 = clipped) of pixel w = 2 i + par, zero padded on both sides = beyond the frame.  Column (c, kw) of the GEMM's B
+// operand at output position ow is byte SG_MPAD + ow + (kw>>1) - 1 of sequence (c, kw & 1): the stride-2 tap shift is a byte shift the
+// GEMM applies itself (12 aligned bytes; the shift goes into the v_perm selectors that widen the bytes).
+// One workgroup = SM_ROWS rows of one frame, one pass, one barrier; all index arithmetic is wave-uniform or by constants.  A thread owns 8
+// pixels x 3 channels of a row (24 contiguous values), builds the four bytes each of the 6 sequences gets from them in registers and writes
+// them as ONE aligned dword per sequence into an LDS image (sequences 3 bytes further right than in HBM: dword aligned); the image then
+// leaves as 48 coalesced 16-byte pieces per row, shifted back by v_alignbyte_b32.  HBM: 1 read of the clip, 1.14x that written.
+constexpr int SM_ROWS = 8;             // rows per workgroup
+constexpr int SM_SEQ = 132;            // LDS image of a sequence: 12 zeros | 112 mask bytes | 8 zeros (33 dwords)
+constexpr int SM_GROUPS = SG_WO / 4;   // 28 groups of 8 pixels per row
 __global__ __launch_bounds__(256) void stem_mask_kernel(const flk_apply_args a, char* out) {
-  __shared__ __attribute__((aligned(16))) unsigned char S[2][6 * SM_SEQ];
+  __shared__ __attribute__((aligned(16))) unsigned S[SM_ROWS][6 * SM_SEQ / 4];
   const int tid = threadIdx.x;
-  if (tid < 2 * 6 * 2) {                                           // the zero sentinels of both buffers
-    const int bsel = tid / 12, r = tid % 12;
-    *(unsigned*)&S[bsel][(r >> 1) * SM_SEQ + (r & 1) * (SM_SEQ - 4)] = 0u;
+  const int hblocks = (a.H + SM_ROWS - 1) / SM_ROWS;               // workgroup = (clip b, frame t, rows h0 .. h0 + SM_ROWS): uniform b, t
+  const int hb = blockIdx.x % hblocks, bt = blockIdx.x / hblocks, t = bt % a.T, b = bt / a.T;
+  const int h0 = hb * SM_ROWS, nr = min(SM_ROWS, a.H - h0);
+  if (tid < SM_ROWS * 6 * 5) {                                     // the zero pads: dwords 0..2 and 31..32 of each sequence
+    const int r = tid / 30, k = tid % 30, sq = k / 5, e = k % 5;
+    S[r][sq * (SM_SEQ / 4) + (e < 3 ? e : 28 + e)] = 0u;
   }
-  // this thread's 4 output dwords d = 4 tid + e of a row (d < 588): sequence window and shift -- functions of d only
-  int o_src[4], o_sh[4];
+  const int r = tid / SM_GROUPS, j = tid - r * SM_GROUPS;          // this thread's row and pixel group
+  if (r < nr) {
+    const size_t src = ((((size_t)b * a.T + sg_wrap(t - a.shift_x, a.T)) * a.H + h0 + r) * a.W) * 3 + 24 * j;   // x'[t] = x[(t - shift_x) mod T]
+    float xv[24];
+    if (a.x_is_u8) {
+      unsigned xu[6];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int d = 4 * tid + e, cw = d / 28, ow4 = d - cw * 28, c = cw / 7, kw = cw - c * 7;
-    const int qb = 4 * ow4 + (kw >> 1) - 1 + 4;                    // byte offset into the sequence incl. its leading zeros
-    o_src[e] = (c * 2 + (kw & 1)) * SM_SEQ + (qb & ~3);
-    o_sh[e] = qb & 3;
-  }
-  const int nrows = a.B * a.T * a.H;
-  const bool loader = 4 * tid < a.W * 3;                           // W*3 = 672 interleaved values per row: 168 threads x 4
-  auto row_src = [&](int row) -> size_t {
-    const int h = row % a.H, bt = row / a.H, t = bt % a.T, b = bt / a.T;
-    return ((((size_t)b * a.T + sg_wrap(t - a.shift_x, a.T)) * a.H + h) * a.W) * 3 + 4 * tid;   // x'[t] = x[(t - shift_x) mod T]
-  };
-  unsigned nu = 0; float4 nf = make_float4(0.f, 0.f, 0.f, 0.f);   // the NEXT row's values: loaded one row ahead (latency hidden)
-  if (loader && (int)blockIdx.x < nrows) {
-    if (a.x_is_u8) nu = *(const unsigned*)((const unsigned char*)a.x + row_src(blockIdx.x));
-    else nf = *(const float4*)((const float*)a.x + row_src(blockIdx.x));
-  }
-  int buf = 0;
-  for (int row = blockIdx.x; row < nrows; row += gridDim.x, buf ^= 1) {
-    const int t = (row / a.H) % a.T, b = row / (a.H * a.T);
-    const unsigned cu = nu; const float4 cf = nf;
-    if (loader && row + (int)gridDim.x < nrows) {
-      if (a.x_is_u8) nu = *(const unsigned*)((const unsigned char*)a.x + row_src(row + gridDim.x));
-      else nf = *(const float4*)((const float*)a.x + row_src(row + gridDim.x));
-    }
-    if (loader) {
-      float pv[3];
+      for (int k = 0; k < 6; ++k) xu[k] = *(const unsigned*)((const unsigned char*)a.x + src + 4 * k);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pv[c] = a.adv_flag * sg_pert(a, b, t, c);
-      float xv[4];
-      if (a.x_is_u8) {
+      for (int e = 0; e < 24; ++e) xv[e] = (float)((xu[e >> 2] >> (8 * (e & 3))) & 255u) * a.x_scale + a.x_bias;
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] = (float)((cu >> (8 * e)) & 255u) * a.x_scale + a.x_bias;
-      } else {
-        xv[0] = cf.x; xv[1] = cf.y; xv[2] = cf.z; xv[3] = cf.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * tid + e, w = i / 3, c = i - 3 * w;
-        const float u = xv[e] + (c == 0 ? pv[0] : c == 1 ? pv[1] : pv[2]);   // both clip gradients are inclusive at the bounds
-        S[buf][(c * 2 + (w & 1)) * SM_SEQ + 4 + (w >> 1)] = (u >= a.lo && u <= a.hi) ? 0x40 : 0x00;
+      for (int k = 0; k < 6; ++k) {
+        const float4 f = *(const float4*)((const float*)a.x + src + 4 * k);
+        xv[4 * k] = f.x; xv[4 * k + 1] = f.y; xv[4 * k + 2] = f.z; xv[4 * k + 3] = f.w;
       }
     }
-    __syncthreads();     // (also orders this row's writes to S[buf] behind the reads of two rows ago: every thread passed the barrier in between)
-    if (tid < SG_ROWSET / 16) {
-      uint4 o;
-      unsigned* ow = (unsigned*)&o;
+    float pv[3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned* sp = (const unsigned*)&S[buf][o_src[e]];
-        ow[e] = __builtin_amdgcn_alignbyte(sp[1], sp[0], (unsigned)o_sh[e]);
+    for (int c = 0; c < 3; ++c) pv[c] = a.adv_flag * sg_pert(a, b, t, c);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        unsigned d = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = xv[(2 * k + par) * 3 + c] + pv[c];       // both clip gradients are inclusive at the bounds
+          d |= (u >= a.lo && u <= a.hi) ? (0x40u << (8 * k)) : 0u;
+        }
+        S[r][(c * 2 + par) * (SM_SEQ / 4) + 3 + j] = d;
       }
-      *(uint4*)(out + (size_t)row * SG_ROWSET + tid * 16) = o;
-    }
+  }
+  __syncthreads();
+  constexpr int NPIECE = SG_ROWSET / 16;                           // 48 pieces per row, 8 per sequence
+  char* const dst = out + ((size_t)bt * a.H + h0) * SG_ROWSET;
+  for (int it = tid; it < nr * NPIECE; it += 256) {
+    const int rr = it / NPIECE, pc = it - rr * NPIECE;
+    const unsigned* sp = &S[rr][(pc >> 3) * (SM_SEQ / 4) + 4 * (pc & 7)];
+    const unsigned d0 = sp[0], d1 = sp[1], d2 = sp[2], d3 = sp[3], d4 = sp[4];
+    uint4 o;                                                       // HBM byte g of a sequence = image byte g + 3
+    o.x = __builtin_amdgcn_alignbyte(d1, d0, 3u);
+    o.y = __builtin_amdgcn_alignbyte(d2, d1, 3u);
+    o.z = __builtin_amdgcn_alignbyte(d3, d2, 3u);
+    o.w = __builtin_amdgcn_alignbyte(d4, d3, 3u);
+    *(uint4*)(dst + (size_t)it * 16) = o;
   }
 }
 
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
       }
     }
   };
-  // mask rows h_from..h_to of both frames into their ring slots: 3 DMA instructions (147 x 16 B) per row and frame; rows outside the
+  // mask rows h_from..h_to of both frames into their ring slots: 1 DMA instruction (48 x 16 B) per row and frame; rows outside the
   // frame come from the zero page
   auto mask_issue = [&](int h_from, int h_to) {
     for (int h = h_from; h <= h_to; ++h) {
@@ -219,13 +223,9 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const char* row = p.mask + (((size_t)b * p.T + 2 * t2 + qq) * p.H + (inside ? h : 0)) * SG_ROWSET;
-        const unsigned dst = lds0 + (unsigned)(SG_OFF_MRING + (qq * SG_RING + ((h + 2) & (SG_RING - 1))) * SG_ROWSET);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int L = 64 * k + lane;
-          const char* src = inside ? row + (L << 4) : zeros;
-          if (L < SG_ROWSET / 16) glds16(src, dst + 1024u * k);
-        }
+        const unsigned dst = lds0 + (unsigned)(SG_OFF_MRING + (qq * SG_RING + ((h + 2) & (SG_RING - 1))) * SG_RPITCH);
+        const char* src = inside ? row + (lane << 4) : zeros;
+        if (lane < SG_ROWSET / 16) glds16(src, dst);
       }
     }
   };
@@ -250,15 +250,17 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
       int mine = 0;
       if (s + 2 < nsteps) {
         const int hm = hmax_of(s + 2);
-        if (hm > h_req && !(p.dbg & 1)) { mask_issue(h_req + 1, hm); mine += 6 * (hm - h_req); }
+        if (hm > h_req && !(p.dbg & 1)) { mask_issue(h_req + 1, hm); mine += 2 * (hm - h_req); }
         if (hm > h_req) h_req = hm;
         if (!(p.dbg & 4)) { g_issue(s + 2, (s + 2) % SG_GBUFS); mine += 16; }      // that buffer was last read in step s-1
       }
-      if (mine >= 28) asm volatile("s_waitcnt vmcnt(28)\n\ts_barrier" ::: "memory");
+      if (mine >= 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
       else if (mine >= 22) asm volatile("s_waitcnt vmcnt(22)\n\ts_barrier" ::: "memory");
+      else if (mine >= 20) asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
+      else if (mine >= 18) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
       else if (mine >= 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-      else if (mine >= 12) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-      else if (mine >= 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+      else if (mine >= 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+      else if (mine >= 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
   } else {
@@ -274,13 +276,15 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
         a_off[i][h] = ((pl * 32 + row) * 8 + ((2 * (i ^ gsw)) + (pp >> 1))) * 16 + 8 * (pp & 1);
       }
     // B fragments: column n = 16 f + i16 -> (c, kh, kw); columns >= 147 read column 146 (their weights are zero)
-    int b_row[SG_NF], b_kh[SG_NF];
+    int b_row[SG_NF], b_kh[SG_NF]; unsigned b_sel[SG_NF];
 #pragma unroll
     for (int f = 0; f < SG_NF; ++f) {
       int n = 16 * f + i16;
       if (n > SG_NCOL - 1) n = SG_NCOL - 1;
       const int c = n / 49, rem = n - c * 49, kh = rem / 7, kw = rem - kh * 7;
-      b_row[f] = q * SG_RING * SG_ROWSET + (c * 7 + kw) * SG_MROW;
+      b_row[f] = q * SG_RING * SG_RPITCH + (c * 2 + (kw & 1)) * SG_MSEQ + SG_MPAD - 1;   // tap kw of position ow reads pixel 2*ow + kw - 2:
+      b_sel[f] = 0x010c000cu + (unsigned)(kw >> 1) * 0x01000100u;                        // byte SG_MPAD + ow + (kw>>1) - 1 of sequence (c, kw&1):
+                                                                                         // the shift kw>>1 sits in the v_perm selectors
       b_kh[f] = kh;
     }
     int m_row = 0, m_col = g;                          // this lane group's 8-run: relative output row, 8-group column (gpr >= 4)
@@ -307,12 +311,17 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
         const char* const mb = mring + m_col * 8;
 #pragma unroll
         for (int f = 0; f < SG_NF; ++f) {
-          const uint2 raw = *(const uint2*)(mb + ((slot0 + b_kh[f]) & (SG_RING - 1)) * SG_ROWSET + b_row[f]);
+          const char* const mp = mb + ((slot0 + b_kh[f]) & (SG_RING - 1)) * SG_RPITCH + b_row[f];
+          const uint2 m01 = *(const uint2*)mp;
+          const unsigned m2 = *(const unsigned*)(mp + 8);
+          // mask bytes s + 0..7 of the 12 (s = kw>>1 <= 3) -> bf16 (m << 8): 0x4000 = 2.0.  v_perm_b32 picks from 8 bytes; selector
+          // 0x0c = constant zero (the bf16 low bytes), s+1 | s (bytes 0..4 of {m01.y, m01.x}), s+3 | s+2 (bytes 2..6)
+          const unsigned selA = b_sel[f], selB = selA + 0x02000200u;
           uint4 bw;
-          bw.x = __builtin_amdgcn_perm(0u, raw.x, 0x010c000cu);   // bytes m0, m1 -> bf16 (m0 << 8), (m1 << 8): 0x4000 = 2.0
-          bw.y = __builtin_amdgcn_perm(0u, raw.x, 0x030c020cu);
-          bw.z = __builtin_amdgcn_perm(0u, raw.y, 0x010c000cu);
-          bw.w = __builtin_amdgcn_perm(0u, raw.y, 0x030c020cu);
+          bw.x = __builtin_amdgcn_perm(m01.y, m01.x, selA);
+          bw.y = __builtin_amdgcn_perm(m01.y, m01.x, selB);
+          bw.z = __builtin_amdgcn_perm(m2, m01.y, selA);
+          bw.w = __builtin_amdgcn_perm(m2, m01.y, selB);
           const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][f], 0, 0, 0);
@@ -376,7 +385,7 @@ static int64_t sg_partial_bytes(int B, int T, int H) {
   return ((int64_t)B * (T / 2) * 16 * 6 * (int64_t)sizeof(float) + 255) / 256 * 256;      // (16 = the largest chunk count)
 }
 
-// scratch = [stage-1 partials | clip mask in B-operand order: B*T*H*2352 bytes]
+// scratch = [stage-1 partials | clip mask in B-operand order: B*T*H*768 bytes]
 extern "C" int64_t flk_stem_delta_grad_scratch_bytes(int B, int T, int H) {
   if (B <= 0 || T <= 0 || H <= 0) return 0;
   return sg_partial_bytes(B, T, H) + (int64_t)B * T * H * SG_ROWSET;
@@ -420,8 +429,7 @@ extern "C" int flk_stem_delta_grad_mask(const flk_apply_args* a, float* scratch,
   if (rc) return rc;
   FLK_REQUIRE(scratch, "flk_stem_delta_grad_mask: null scratch");
   char* const mask = (char*)scratch + sg_partial_bytes(a->B, a->T, a->H);
-  const long nrows = (long)a->B * a->T * a->H;
-  FLK_LAUNCH_KERNEL(stem_mask_kernel, dim3((unsigned)(nrows < 8192 ? nrows : 8192)), dim3(256), 0, (hipStream_t)stream, *a, mask);
+  FLK_LAUNCH_KERNEL(stem_mask_kernel, dim3((unsigned)((long)a->B * a->T * ((a->H + SM_ROWS - 1) / SM_ROWS))), dim3(256), 0, (hipStream_t)stream, *a, mask);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }

@@ -197,7 +197,7 @@ int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s2d, int dty
  * form (csrc/stem_grad.hip): the per-pixel gradient is never materialised.  `a` are the arguments the clip was applied with (its
  * clip / roll / 1/std semantics define the mask); wf_dev comes from flk_stem_delta_grad_weights_create (the canonical
  * [7,7,7,3,64] stem weights x the folded batch-norm scale, fp32); scratch: flk_stem_delta_grad_scratch_bytes() of caller scratch
- * (stage-1 partials + the clip mask in the GEMM's operand order, 2352 bytes per clip row).  Two launches: the mask pre-pass (HBM-bound;
+ * (stage-1 partials + the de-interleaved clip mask, 768 bytes per clip row).  Two launches: the mask pre-pass (HBM-bound;
  * mask_done != 0 skips it when flk_stem_delta_grad_mask already ran for the same arguments) and the GEMM.
  * Deterministic (fixed summation order); bf16 gradients only -- the fp32 parity mode keeps the two-kernel path. */
 int64_t flk_stem_delta_grad_scratch_bytes(int B, int T, int H);
