@@ -250,13 +250,14 @@ __device__ static inline int pplane_off(int c, int plane_b) { return c * plane_b
 // are still in that XCD's L2 (a slab is only 64 B of a position's row).
 // PoolTP.interleave = 0 deals the tiles themselves to the XCDs in contiguous chunks (XCD x works through tiles [x * chunk, (x + 1) * chunk)
 // in order; FLK_POOL_XCD_CHUNK=1), 1 (default) puts tile i on XCD i % 8.
-__device__ static inline bool tile_slab_of_block(const PoolTP& p, int& tile, int& slab) {
+__device__ static inline bool tile_slab_of_block(const PoolTP& p, int nslab, int& tile, int& slab) {
   const int bid = blockIdx.x, xcd = bid & 7, r = bid >> 3;
-  slab = r % p.nslab;
-  const int chunk = (int)gridDim.x / (8 * p.nslab);          // = ceil(ntiles / 8): the host sizes the grid as 8 * chunk * nslab
-  tile = p.interleave ? (r / p.nslab) * 8 + xcd : xcd * chunk + r / p.nslab;
+  slab = r % nslab;
+  const int chunk = (int)gridDim.x / (8 * nslab);            // = ceil(ntiles / 8): the host sizes the grid as 8 * chunk * nslab
+  tile = p.interleave ? (r / nslab) * 8 + xcd : xcd * chunk + r / nslab;
   return tile < p.ntiles;
 }
+__device__ static inline bool tile_slab_of_block(const PoolTP& p, int& tile, int& slab) { return tile_slab_of_block(p, p.nslab, tile, slab); }
 
 // (measured: chunked pool tiles 6.81 vs interleaved 6.77-6.79 ms per step with the convolutions chunked -- the pools keep the
 // interleaved order; FLK_POOL_XCD_CHUNK=1 selects the chunked one)
@@ -749,6 +750,7 @@ struct PoolGemmP {
   PoolTP t;
   const char* g; int g_ld, g_coff, KS;       // KS = K / 32 k-steps
   const char* wpack;                          // [slab][ks][f = 0,1][64 lanes][16 B]
+  int dbg;                                    // timing experiments only (FLK_PG_DBG): 1 = no atomics, 2 = no tile write, 4 = no g loads, 8 = no index loads, 16 = no zeroing
 };
 
 template <int KS>
@@ -857,6 +859,148 @@ __global__ __launch_bounds__(256, 4) void maxpool_scatter_gemm_bwd(const PoolGem
   // ---- write the tile: thread = (cell, 16-byte channel chunk) ----
   const int ch = tid & 3, c0 = cslab * 32 + ch * 8;
   if (c0 >= k.C) return;
+  const int hw = p.Ht * p.Wt;
+  for (int r = tid >> 2; r < p.rows; r += 64) {
+    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
+    if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = (float)(int)acc[(ch * 8 + e) * RS + r] * inv_scale;
+    const size_t ipos = (((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw);
+    PV<bf16_t>::st(k.gin + (ipos * k.gin_ld + k.gin_coff + c0) * 2, g);
+  }
+}
+
+// The same kernel for tiles reached by at most 64 * NIT windows (the (4,7,7) tiles of the I3D blocks: 486): a wave's NIT passes are
+// unrolled, the g rows and index bytes of NB passes are requested together (the loop form above waits for one load round trip per pass and
+// per product pass -- 2 x 8 dependent round trips per workgroup: latency-bound, 1 TB/s), and the products and index bytes stay in registers
+// between the max pass and the scatter pass: each is loaded and computed ONCE.  That alone changed little: the kernel is VALU-bound on the
+// scatter's per-element decode (tap -> (dt,dh,dw), three bound checks, address: ~27 instructions x 8 elements x 8 passes per lane, one wave
+// per SIMD and workgroup).  3x3x3 windows only: which taps of a window land inside the tile is a 27-bit mask computed once per window
+// (8 elements share it), and a tap's cell offset comes from a 256-entry table in LDS: ~12 instructions per element.
+// Measured (Mixed_3c, 8 x 32 x 28 x 28 x 256 channels, K = 64; tools/pool_gemm_time.py, FLK_PG_DBG ablations): loop form 192 us, this form
+// 161 us; without atomics 137, without the tile write 138, without g loads 145, without index loads 138, without all of them and the
+// zeroing 80 us -- what is left is the decode of 486 windows x 32 channels per 196-cell tile (2.48x the cells: the windows that reach a
+// tile overlap its neighbours'), ~45 us of VALU time at ~12 instructions per element, plus the per-workgroup chain.  Tried and dropped:
+// accumulator plane stride 4 / 20 (mod 64) instead of 16 (no change: the atomics are not bank-bound); the lanes of one atomic on windows 3
+// apart, which cannot share an argmax cell (5 % slower: the loads lose locality, same-address serialisation is not the limit either); a
+// persistent workgroup per tile that walks over its channel slabs with the decode, masks and g fragments kept and the next slab's
+// weights / index bytes prefetched (169 us: 246 VGPRs, two workgroups per CU).
+template <int KS, int NIT, int NB>
+__global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd_reg(const PoolGemmP pg, unsigned m_khkw, unsigned m_kw) {
+  typedef __bf16 frag8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* const acc = (unsigned*)smem;     // [32 channels][RS cells] fixed-point accumulators
+  const PoolTP& p = pg.t;
+  const PoolKP& k = p.k;
+  const int RS = p.plane_b;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, m = lane & 15;
+  int bid, cslab;
+  if (!tile_slab_of_block(p, bid, cslab)) return;
+  const int tw = bid % p.nTw; bid /= p.nTw;
+  const int th = bid % p.nTh; bid /= p.nTh;
+  const int tt = bid % p.nTt;
+  const int b = bid / p.nTt;
+  const int i_t0 = tt * p.Tt, i_h0 = th * p.Ht, i_w0 = tw * p.Wt;
+  const int o_t0 = max(0, (i_t0 + k.pt - k.kt + k.st) / k.st), o_t1 = min(k.To - 1, (i_t0 + p.Tt - 1 + k.pt) / k.st);
+  const int o_h0 = max(0, (i_h0 + k.ph - k.kh + k.sh) / k.sh), o_h1 = min(k.Ho - 1, (i_h0 + p.Ht - 1 + k.ph) / k.sh);
+  const int o_w0 = max(0, (i_w0 + k.pw - k.kw + k.sw) / k.sw), o_w1 = min(k.Wo - 1, (i_w0 + p.Wt - 1 + k.pw) / k.sw);
+  const int nt = max(0, o_t1 - o_t0 + 1), nh = max(0, o_h1 - o_h0 + 1), nw = max(0, o_w1 - o_w0 + 1);
+  const int nhw = nh * nw, P = nt * nhw;                       // <= 64 * NIT (the host checks the tile)
+  const float inv_hw = 1.0f / (float)max(nhw, 1), inv_w = 1.0f / (float)max(nw, 1);
+  if (!(pg.dbg & 16)) for (int i = tid; i < 32 * RS; i += 256) acc[i] = 0u;
+  unsigned* const smax = acc + 32 * RS;
+  if (tid == 0) *smax = 0u;
+  unsigned* const lut = smax + 64;                             // byte offset of tap's cell relative to the window origin's cell
+  {
+    const int dt = tid / 9, r2 = tid - dt * 9, dh = r2 / 3, dw = r2 - dh * 3;
+    lut[tid] = tid < 27 ? (unsigned)(((dt * p.Ht + dh) * p.Wt + dw) * 4) : 0u;
+  }
+  f32x4 v[NIT][2];
+  unsigned ib[NIT][2];
+  int org[NIT];                                                // byte offset of the window origin's cell in an accumulator plane (may be negative)
+  unsigned okm[NIT];                                           // bit tap = the tap's cell lies inside the tile
+  unsigned mx = 0u;
+  if (P > 0) {
+    frag8 af[KS][2];
+    {
+      const char* wp = pg.wpack + ((size_t)cslab * KS * 2 * 64 + lane) * 16;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) af[ks][f] = *(const frag8*)(wp + (size_t)(ks * 2 + f) * 1024);
+    }
+#pragma unroll
+    for (int i0 = 0; i0 < NIT; i0 += NB) {
+      frag8 bf[NB][KS];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = i0 + u;
+        const int hp = wave * 16 + 64 * i + m;
+        const bool live = hp < P;
+        const int hc = min(hp, P - 1);
+        const int a = (int)(((float)hc + 0.5f) * inv_hw), rem = hc - a * nhw;
+        const int bq = (int)(((float)rem + 0.5f) * inv_w), c = rem - bq * nw;
+        const int ot = o_t0 + a, oh = o_h0 + bq, ow = o_w0 + c;
+        const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+        const int lt0 = ot * k.st - k.pt - i_t0, lh0 = oh * k.sh - k.ph - i_h0, lw0 = ow * k.sw - k.pw - i_w0;
+        org[i] = ((lt0 * p.Ht + lh0) * p.Wt + lw0) * 4;
+        // taps d = 0..2 of a dimension with 0 <= l0 + d < n, as 3 bits; the 27-bit mask is their outer product (bit (dt*3 + dh)*3 + dw)
+        auto bits3 = [](int l0, int n) { return (7u << min(max(-l0, 0), 3)) & 7u & ((1u << min(max(n - l0, 0), 3)) - 1u); };
+        const unsigned bt3 = bits3(lt0, p.Tt), bh3 = bits3(lh0, p.Ht), bw3 = bits3(lw0, p.Wt);
+        const unsigned eh = (bh3 & 1u) | ((bh3 & 2u) << 2) | ((bh3 & 4u) << 4);          // spread by 3
+        const unsigned et = (bt3 & 1u) | ((bt3 & 2u) << 8) | ((bt3 & 4u) << 16);         // spread by 9
+        okm[i] = live ? bw3 * eh * et : 0u;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) ib[i][f] = (pg.dbg & 8) ? (unsigned)(m * 0x01010101u) & 0x0f0f0f0fu : *(const unsigned*)(k.idx + opos * k.C + cslab * 32 + f * 16 + q * 4);
+        const char* gp = pg.g + (opos * pg.g_ld + pg.g_coff + q * 8) * 2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bf[u][ks] = (pg.dbg & 4) ? af[ks][0] : *(const frag8*)(gp + ks * 64);
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int i = i0 + u;
+        v[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; v[i][1] = v[i][0];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          v[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][0], bf[u][ks], v[i][0], 0, 0, 0);
+          v[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][1], bf[u][ks], v[i][1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mx = max(mx, __float_as_uint(v[i][f][j]) & 0x7fffffffu);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+  __syncthreads();                                             // the accumulators and *smax are zero
+  if (lane == 0) atomicMax(smax, mx);
+  __syncthreads();
+  int ex = (int)(*smax >> 23);
+  ex = min(max(ex, 26), 254);
+  const float scale = __uint_as_float((unsigned)(127 + 24 + 127 - ex) << 23);
+  const float inv_scale = __uint_as_float((unsigned)(127 - 24 - 127 + ex) << 23);
+  if (P > 0) {
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      char* const plane0 = (char*)acc + (size_t)(q * 4 * RS) * 4 + org[i];
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned tap = (ib[i][f] >> (8 * j)) & 255u;               // 255 ("no cell"): bit 31 of the mask, never set
+          if (((okm[i] >> (tap & 31u)) & 1u) && !(pg.dbg & 1))
+            atomicAdd((unsigned*)(plane0 + (size_t)((f * 16 + j) * RS) * 4 + lut[tap]), (unsigned)__float2int_rn(v[i][f][j] * scale));
+        }
+    }
+  }
+  __syncthreads();
+  // ---- write the tile: thread = (cell, 16-byte channel chunk) ----
+  const int ch = tid & 3, c0 = cslab * 32 + ch * 8;
+  if (c0 >= k.C || (pg.dbg & 2)) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
     const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
@@ -1082,6 +1226,7 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   fill(pg.t.k, a);
   pg.t.k.gin = (char*)gin; pg.t.k.gin_ld = gin_ld; pg.t.k.gin_coff = gin_coff;
   pg.g = (const char*)g; pg.g_ld = g_ld; pg.g_coff = g_coff; pg.KS = K / 32; pg.wpack = (const char*)wpack;
+  { const char* e = getenv("FLK_PG_DBG"); pg.dbg = e ? atoi(e) : 0; }
   const flk_tile t = choose_scatter_tile(a);
   PoolTP& tp = pg.t;
   tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
@@ -1090,10 +1235,30 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   tp.interleave = pool_interleave();
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
-  tp.plane_b = (tp.rows + 47) / 64 * 64 + 16;
+  { // accumulator plane stride in words: 4 (mod 64) -- the four lane groups q of an atomic (planes 4 q + j) start 16 banks apart
+    // (16 (mod 64), the stride of maxpool_scatter_bwd, puts all four on the same banks); FLK_POOL_PLANE_MOD overrides the residue
+    const char* e = getenv("FLK_POOL_PLANE_MOD");
+    const int res = e ? atoi(e) & 63 : 4;
+    tp.plane_b = (tp.rows - res + 63) / 64 * 64 + res;
+  }
   const size_t lds = (size_t)(32 * tp.plane_b + 64) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
   const unsigned m1 = magic(a->kh * a->kw), m2 = magic(a->kw);
+  // windows that can reach a tile: at most 64 * 8 -> the register-resident form
+  const long reach = (long)((t.Tt + a->kt - 2) / a->st + 1) * ((t.Ht + a->kh - 2) / a->sh + 1) * ((t.Wt + a->kw - 2) / a->sw + 1);
+  const char* const reg_env = getenv("FLK_POOL_GEMM_REG");     // (read per call: the tests compare the two forms)
+  const bool reg_form = !(reg_env && atoi(reg_env) == 0);
+  if (reg_form && reach <= 512 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
+    const size_t lds_reg = lds + (size_t)(64 + 256) * sizeof(unsigned);      // + the tap table
+    switch (pg.KS) {
+      case 1: FLK_LAUNCH_KERNEL((maxpool_scatter_gemm_bwd_reg<1, 8, 4>), grid, dim3(256), lds_reg, s, pg, m1, m2); break;
+      case 2: FLK_LAUNCH_KERNEL((maxpool_scatter_gemm_bwd_reg<2, 8, 4>), grid, dim3(256), lds_reg, s, pg, m1, m2); break;
+      case 3: FLK_LAUNCH_KERNEL((maxpool_scatter_gemm_bwd_reg<3, 8, 2>), grid, dim3(256), lds_reg, s, pg, m1, m2); break;
+      default: FLK_LAUNCH_KERNEL((maxpool_scatter_gemm_bwd_reg<4, 8, 2>), grid, dim3(256), lds_reg, s, pg, m1, m2); break;
+    }
+    FLK_CHECK_HIP(hipGetLastError());
+    return FLK_OK;
+  }
   switch (pg.KS) {
     case 1: FLK_LAUNCH_KERNEL(maxpool_scatter_gemm_bwd<1>, grid, dim3(256), lds, s, pg, m1, m2); break;
     case 2: FLK_LAUNCH_KERNEL(maxpool_scatter_gemm_bwd<2>, grid, dim3(256), lds, s, pg, m1, m2); break;

@@ -260,7 +260,7 @@ def test_maxpool_fwd_bwd(ops, dtype, k, s, dims):
 
 
 @pytest.mark.parametrize("dims,C_,K", [((4, 14, 14), 72, 64), ((3, 7, 9), 32, 32), ((4, 7, 7), 832, 128), ((5, 11, 6), 96, 96)])
-def test_maxpool_bwd_gemm_fused(ops, dims, C_, K):
+def test_maxpool_bwd_gemm_fused(ops, dims, C_, K, monkeypatch):
     """flk_maxpool3d_bwd_gemm (Branch_3 backward of an Inception block in one kernel, i3d.py:211-216 backward): gin =
     MaxPool3DGrad(idx, g @ Wt) against (a) torch-CPU autograd of max_pool3d fed the fp32 product -- the kernel keeps the product in
     fp32, so only the bf16 rounding of the stored gin separates them -- and (b) the two-launch chain it replaces (1x1x1 data-gradient ->
@@ -284,6 +284,9 @@ def test_maxpool_bwd_gemm_fused(ops, dims, C_, K):
     assert torch.equal(gin, ops.maxpool3d_bwd_gemm(ctx, g.to(dtype).cuda(), wp, g_coff=8))
     chain = ops.maxpool3d_bwd(ctx, gpl.to(dtype).cuda())              # the two-launch form: the product rounded to bf16 first
     torch.testing.assert_close(gin.float().cpu(), chain.float().cpu(), rtol=2e-2, atol=2e-2 * float(gref.abs().max()))
+    # the loop form of the kernel (FLK_POOL_GEMM_REG=0; tiles reached by more than 512 windows) adds the same integers: same bits
+    monkeypatch.setenv("FLK_POOL_GEMM_REG", "0")
+    assert torch.equal(gin, ops.maxpool3d_bwd_gemm(ctx, g.to(dtype).cuda(), wp, g_coff=8))
 
 
 BLOCKS = {"small": (1, 2, 7, 7, 64, (32, 24, 48, 16, 32, 16)),
