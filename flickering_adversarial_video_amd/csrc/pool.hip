@@ -241,6 +241,7 @@ struct PoolTP {
   PoolKP k;
   int Tt, Ht, Wt, nTt, nTh, nTw, Th, Hh, Wh, P, plane_b, rows, ntiles, nslab;
   int interleave;      // 1: tile i on XCD i % 8 (default); 0: contiguous chunks of tiles per XCD (FLK_POOL_XCD_CHUNK=1)
+  int dbg;             // timing experiments only (FLK_PF_DBG, W-run forward): 1 = no halo loads, 2 = no column maxima, 4 = no stores
 };
 
 __device__ static inline int pplane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
@@ -258,6 +259,14 @@ __device__ static inline bool tile_slab_of_block(const PoolTP& p, int nslab, int
   return tile < p.ntiles;
 }
 __device__ static inline bool tile_slab_of_block(const PoolTP& p, int& tile, int& slab) { return tile_slab_of_block(p, p.nslab, tile, slab); }
+
+// x / d for 0 <= x < 2^20 and a small run-time divisor d, inv = 1.0f / d: (x + 0.5) / d is never within 0.5 / d of an integer, so the float
+// quotient truncates exactly -- 3 VALU operations instead of the ~40 of a 32-bit integer division (which made the index arithmetic of the
+// staging / write-out loops below as expensive as the pooling itself)
+__device__ static inline int qdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
+__device__ static inline void split3(int x, int d1, float inv1, int d2, float inv2, int& a, int& b, int& c) {   // x = (a * d1) + b * d2 + c, d1 = (rows of b) * d2
+  a = qdiv(x, inv1); const int rem = x - a * d1; b = qdiv(rem, inv2); c = rem - b * d2;
+}
 
 // (measured: chunked pool tiles 6.81 vs interleaved 6.77-6.79 ms per step with the convolutions chunked -- the pools keep the
 // interleaved order; FLK_POOL_XCD_CHUNK=1 selects the chunked one)
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd(const PoolTP p) {
   const int HW = p.Hh * p.Wh;
   // stage the halo (-inf outside the tensor: padded cells never win)
   for (int hp = tid >> 2; hp < p.P; hp += 64) {
-    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+    int a, bq, c; split3(hp, HW, 1.0f / (float)HW, p.Wh, 1.0f / (float)p.Wh, a, bq, c);
     const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
     float v[EPL];
 #pragma unroll
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd(const PoolTP p) {
   if (!chvalid) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
-    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    int rt, rh, rw; split3(r, hw, 1.0f / (float)hw, p.Wt, 1.0f / (float)p.Wt, rt, rh, rw);
     const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
     if (ot >= k.To || oh >= k.Ho || ow >= k.Wo) continue;
     const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * p.Wh + rw) * 16;
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd_bf16(const PoolTP
   const int it0 = ot0 - k.pt, ih0 = oh0 - k.ph, iw0 = ow0 - k.pw;
   const int HW = p.Hh * p.Wh;
   for (int hp = tid >> 2; hp < p.P; hp += 64) {
-    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+    int a, bq, c; split3(hp, HW, 1.0f / (float)HW, p.Wh, 1.0f / (float)p.Wh, a, bq, c);
     const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
     uint4 v = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);     // -inf
     if (chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi)
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd_bf16(const PoolTP
   if (!chvalid) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
-    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    int rt, rh, rw; split3(r, hw, 1.0f / (float)hw, p.Wt, 1.0f / (float)p.Wt, rt, rh, rw);
     const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
     if (ot >= k.To || oh >= k.Ho || ow >= k.Wo) continue;
     const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * p.Wh + rw) * 16;
@@ -430,12 +439,14 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
   const bool chvalid = c0 < k.C;
   const int ot0 = tt * p.Tt, oh0 = th * p.Ht, ow0 = tw * WT;
   const int it0 = ot0 - 1, ih0 = oh0 - 1, iw0 = ow0 - 1;
-  const int HW = p.Hh * p.Wh;
-  for (int hp = tid >> 2; hp < p.P; hp += 64) {
-    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+  constexpr int WH = WT + 2;                                   // = p.Wh
+  const int HW = p.Hh * WH;
+  const float inv_HW = 1.0f / (float)HW;                       // (hp + 0.5) / HW is never within 0.5 / HW of an integer: the float quotient truncates exactly
+  for (int hp = tid >> 2; hp < p.P; hp += 64) {                // (integer divisions by run-time values here were as many VALU operations as the pooling itself)
+    const int a = (int)(((float)hp + 0.5f) * inv_HW), rem = hp - a * HW, bq = rem / WH, c = rem - bq * WH;
     const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
     uint4 v = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);     // -inf
-    if (chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi)
+    if (chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi && !(p.dbg & 1))
       v = *(const uint4*)(k.in + ((((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw) * k.in_ld + k.in_coff + c0) * 2);
     v.x = bf16x2_to_keys(v.x); v.y = bf16x2_to_keys(v.y); v.z = bf16x2_to_keys(v.z); v.w = bf16x2_to_keys(v.w);
     *(uint4*)(smem + pplane_off(ch, p.plane_b) + hp * 16) = v;
@@ -444,10 +455,10 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
   if (!chvalid) return;
   const int npairs = p.Tt * p.Ht;
   for (int pr = tid >> 2; pr < npairs; pr += 64) {
-    const int rt = pr / p.Ht, rh = pr - rt * p.Ht;
+    const int rt = qdiv(pr, 1.0f / (float)p.Ht), rh = pr - rt * p.Ht;
     const int ot = ot0 + rt, oh = oh0 + rh;
     if (ot >= k.To || oh >= k.Ho) continue;
-    const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * p.Wh) * 16;
+    const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * WH) * 16;
     uint32_t cm[3][8];
     auto colmax = [&](int c, uint32_t (&m)[8]) {
 #pragma unroll
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
           // tag = 27 - tap of (dt, dh, dw = 0): small enough for an inline constant, so the high-half key is ONE v_and_or_b32
           // (with 255 - tap the mask and the tag were two literals: v_and + v_or)
           const uint32_t tag = 27u - 3u * (uint32_t)(dt * 3 + dh);
-          const uint4 v = *(const uint4*)(base + ((dt * p.Hh + dh) * p.Wh + c) * 16);
+          const uint4 v = *(const uint4*)(base + ((dt * p.Hh + dh) * WH + c) * 16);
           const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -468,11 +479,14 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
           }
         }
     };
-    colmax(0, cm[0]);
-    colmax(1, cm[1]);
+    if (p.dbg & 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cm[0][e] = cm[1][e] = cm[2][e] = (unsigned)(tid + e) << 8;
+    }
+    if (!(p.dbg & 2)) { colmax(0, cm[0]); colmax(1, cm[1]); }
 #pragma unroll
     for (int rw = 0; rw < WT; ++rw) {
-      colmax(rw + 2, cm[(rw + 2) % 3]);
+      if (!(p.dbg & 2)) colmax(rw + 2, cm[(rw + 2) % 3]);
       const int ow = ow0 + rw;
       if (ow >= k.Wo) continue;
       const uint32_t (&l)[8] = cm[rw % 3];
@@ -498,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
       id.x = ix[0] | (ix[1] << 8) | (ix[2] << 16) | (ix[3] << 24);
       id.y = ix[4] | (ix[5] << 8) | (ix[6] << 16) | (ix[7] << 24);
       const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
+      if (p.dbg & 4) { if (o.x == 0x12345u && id.x == 0x777u) *(uint2*)(k.idx + opos * k.C + c0) = id; continue; }
       *(uint4*)(k.out + (opos * k.out_ld + k.out_coff + c0) * 2) = o;
       *(uint2*)(k.idx + opos * k.C + c0) = id;
     }
@@ -528,6 +543,7 @@ static int launch_wrun_fwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t
   const size_t lds = 4 * (size_t)tp.plane_b + 64;
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
   tp.interleave = pool_interleave();
+  { const char* e = getenv("FLK_PF_DBG"); tp.dbg = e ? atoi(e) : 0; }
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   static bool attr_set[FLK_MAX_DEVICES] = {};
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_wrun_fwd_bf16<WT>, 96 * 1024, attr_set)) return rc;
@@ -556,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_bwd(const PoolTP p) {
   const int o_t0 = i_t0 - (k.kt - 1 - k.pt), o_h0 = i_h0 - (k.kh - 1 - k.ph), o_w0 = i_w0 - (k.kw - 1 - k.pw);
   const int HW = p.Hh * p.Wh;
   for (int hp = tid >> 2; hp < p.P; hp += 64) {
-    const int a = hp / HW, rem = hp - a * HW, bq = rem / p.Wh, c = rem - bq * p.Wh;
+    int a, bq, c; split3(hp, HW, 1.0f / (float)HW, p.Wh, 1.0f / (float)p.Wh, a, bq, c);
     const int ot = o_t0 + a, oh = o_h0 + bq, ow = o_w0 + c;
     uint4 g = make_uint4(0, 0, 0, 0);
     int id[EPL];
@@ -574,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_bwd(const PoolTP p) {
   if (!chvalid) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
-    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    int rt, rh, rw; split3(r, hw, 1.0f / (float)hw, p.Wt, 1.0f / (float)p.Wt, rt, rh, rw);
     const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
     if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
     float g[EPL];
@@ -716,7 +732,7 @@ __global__ __launch_bounds__(256, 4) void maxpool_scatter_bwd(const PoolTP p, un
   if (!chvalid) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
-    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    int rt, rh, rw; split3(r, hw, 1.0f / (float)hw, p.Wt, 1.0f / (float)p.Wt, rt, rh, rw);
     const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
     if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
     float g[EPL];
@@ -861,7 +877,7 @@ __global__ __launch_bounds__(256, 4) void maxpool_scatter_gemm_bwd(const PoolGem
   if (c0 >= k.C) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
-    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    int rt, rh, rw; split3(r, hw, 1.0f / (float)hw, p.Wt, 1.0f / (float)p.Wt, rt, rh, rw);
     const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
     if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
     float g[8];
@@ -1003,7 +1019,7 @@ __global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd
   if (c0 >= k.C || (pg.dbg & 2)) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
-    const int rt = r / hw, rem = r - rt * hw, rh = rem / p.Wt, rw = rem - rh * p.Wt;
+    int rt, rh, rw; split3(r, hw, 1.0f / (float)hw, p.Wt, 1.0f / (float)p.Wt, rt, rh, rw);
     const int it = i_t0 + rt, ih = i_h0 + rh, iw = i_w0 + rw;
     if (it >= k.Ti || ih >= k.Hi || iw >= k.Wi) continue;
     float g[8];
