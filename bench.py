@@ -453,7 +453,7 @@ def main():
         if fused["launches"]:
             out["roofline"]["stem_delta_grad_kernel"] = {"ms": fused["ms"] / reps, "achieved": fused["flops"] / (fused["ms"] * 1e-3) / 1e12,
                                                          "unit": "TFLOP/s (algorithmic flops of the stem data-gradient it replaces)",
-                                                         "includes": "the clip-mask pre-pass (0.15 ms, HBM-bound), run inline in this serial profile; in the timed region it runs beside the backward pass",
+                                                         "includes": "the clip-mask pre-pass (0.04 ms), run inline in this serial profile; in the timed region it runs beside the stem forward",
                                                          "frac": fused["flops"] / (fused["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype]}
         out["kernel_ms_per_step"] = {k: v["ms"] / reps for k, v in per_kind.items()}
         if "pool" in per_kind and per_kind["pool"]["ms"] > 0:
