@@ -233,8 +233,14 @@ struct flk_net {
   // it is memory-bound, the padded MFMAs are free: 25 -> 22 us for 192 -> 32 at 200 704 positions)
   int nf_for(int cout, int taps, long rows) const {
     const int nf = choose_nf(cout, taps, nf6_ok(rows));
+    // 1x1x1 GEMMs on 8 .. 255 position tiles (Mixed_4* / Mixed_5* at bs 8): 64-channel tiles, twice the workgroups of the 128-wide
+    // choice -- these launches are paced by the step chain of ONE workgroup per CU (DMA issue -> LDS reads -> MFMAs, one wave per
+    // SIMD), not by bytes: same total time alone, the step -0.035 ms (they overlap their neighbours better).  FLK_SMALL_NF=0: off
+    if (dtype == FLK_BF16 && taps == 1 && small_nf() && rows >= 2048 && rows < 256L * 256 && cout > 64) return small_nf();
+    // (the same for the 3x3x3 layers of those blocks: 6.122-6.124 vs 6.132-6.135 ms, within the noise; 96-wide: 6.32 ms -- not done)
     return (dtype == FLK_BF16 && taps == 1 && nf == 2) ? 4 : nf;
   }
+  static int small_nf() { static const int v = getenv("FLK_SMALL_NF") ? atoi(getenv("FLK_SMALL_NF")) : 4; return v == 4 || v == 8 ? (v == 8 ? 0 : 4) : 0; }
   int pack(ConvLayer* L, long rows = 0) {
     const int taps = L->kt * L->kh * L->kw;
     int rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, nullptr, 0, dtype,
@@ -569,8 +575,8 @@ int flk_net::build_i3d() {
       std::vector<float> wT((size_t)cf * cur_c);
       for (int ci = 0; ci < cur_c; ++ci)
         for (int k = 0; k < cf; ++k) wT[(size_t)k * cur_c + ci] = L->w[(size_t)ci * cf + k];
-      if ((rc = flk_conv_weights_create_impl(L->w.data(), 1, 1, 1, cur_c, cf, nullptr, 0, dtype, choose_nf(cf, 1, nf6_ok(rows_blk)), 0, &L->wf))) return rc;
-      if ((rc = flk_conv_weights_create_impl(wT.data(), 1, 1, 1, cf, cur_c, L->scale.data(), 0, dtype, choose_nf(cur_c, 1, nf6_ok(rows_blk)), c0, &L->wb))) return rc;
+      if ((rc = flk_conv_weights_create_impl(L->w.data(), 1, 1, 1, cur_c, cf, nullptr, 0, dtype, nf_for(cf, 1, rows_blk), 0, &L->wf))) return rc;
+      if ((rc = flk_conv_weights_create_impl(wT.data(), 1, 1, 1, cf, cur_c, L->scale.data(), 0, dtype, nf_for(cur_c, 1, rows_blk), c0, &L->wb))) return rc;
       if ((rc = upload(&L->d_scale, L->scale)) || (rc = upload(&L->d_bias, L->bias))) return rc;
       Lf = L.get();
       convs.push_back(std::move(L));
