@@ -55,10 +55,12 @@ constexpr int SG_MSEQ = 128;           // one mask sequence (channel c, w parity
 constexpr int SG_ROWSET = 6 * SG_MSEQ;    // one input row of one frame in HBM: 3 channels x 2 parities = 768 bytes = 48 x 16
 constexpr int SG_RPITCH = SG_ROWSET + 48; // pitch of a ring slot in LDS: 204 dwords = 12 banks mod 64 (consecutive rows kh land on different banks)
 constexpr int SG_RING = 16;            // input rows kept per frame (9 live + 4 in flight)
+constexpr int SG_MIRROR = 6;           // ring slots 0..5 are kept a second time behind slot 15: the 7 rows kh of a window start at any slot and never wrap
+constexpr int SG_RINGP = SG_RING + SG_MIRROR;   // physical slots per frame
 constexpr int SG_GTILE = 4 * 32 * 128;    // bytes of one K step's G tile: 4 planes x 32 positions x 64 bf16
 constexpr int SG_GBUFS = 3;            // G tiles: two K steps of DMA look-ahead
 constexpr int SG_OFF_MRING = SG_GBUFS * SG_GTILE;
-constexpr int SG_OFF_RED = SG_OFF_MRING + 2 * SG_RING * SG_RPITCH;
+constexpr int SG_OFF_RED = SG_OFF_MRING + 2 * SG_RINGP * SG_RPITCH;
 constexpr int SG_LDS = SG_OFF_RED + 8 * 3 * 4;
 
 struct StemGradKP {
@@ -215,19 +217,24 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
       }
     }
   };
-  // mask rows h_from..h_to of both frames into their ring slots: 1 DMA instruction (48 x 16 B) per row and frame; rows outside the
-  // frame come from the zero page
+  // mask rows h_from..h_to of both frames into their ring slots: 1 DMA instruction (48 x 16 B) per row and frame, a second one into the
+  // mirror slot for the slots 0..5; rows outside the frame come from the zero page.  Returns the number of DMA instructions.
   auto mask_issue = [&](int h_from, int h_to) {
+    int n = 0;
     for (int h = h_from; h <= h_to; ++h) {
       const bool inside = h >= 0 && h < p.H;
+      const int slot = (h + 2) & (SG_RING - 1);
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
         const char* row = p.mask + (((size_t)b * p.T + 2 * t2 + qq) * p.H + (inside ? h : 0)) * SG_ROWSET;
-        const unsigned dst = lds0 + (unsigned)(SG_OFF_MRING + (qq * SG_RING + ((h + 2) & (SG_RING - 1))) * SG_RPITCH);
+        const unsigned dst = lds0 + (unsigned)(SG_OFF_MRING + (qq * SG_RINGP + slot) * SG_RPITCH);
         const char* src = inside ? row + (lane << 4) : zeros;
         if (lane < SG_ROWSET / 16) glds16(src, dst);
+        if (slot < SG_MIRROR && lane < SG_ROWSET / 16) glds16(src, dst + (unsigned)(SG_RING * SG_RPITCH));
       }
+      n += slot < SG_MIRROR ? 4 : 2;
     }
+    return n;
   };
 
   // ---- prologue: the mask rows of steps 0 and 1, G tiles 0 and 1 ----
@@ -250,18 +257,25 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
       int mine = 0;
       if (s + 2 < nsteps) {
         const int hm = hmax_of(s + 2);
-        if (hm > h_req && !(p.dbg & 1)) { mask_issue(h_req + 1, hm); mine += 2 * (hm - h_req); }
+        if (hm > h_req && !(p.dbg & 1)) mine += mask_issue(h_req + 1, hm);
         if (hm > h_req) h_req = hm;
         if (!(p.dbg & 4)) { g_issue(s + 2, (s + 2) % SG_GBUFS); mine += 16; }      // that buffer was last read in step s-1
       }
-      if (mine >= 24) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-      else if (mine >= 22) asm volatile("s_waitcnt vmcnt(22)\n\ts_barrier" ::: "memory");
-      else if (mine >= 20) asm volatile("s_waitcnt vmcnt(20)\n\ts_barrier" ::: "memory");
-      else if (mine >= 18) asm volatile("s_waitcnt vmcnt(18)\n\ts_barrier" ::: "memory");
-      else if (mine >= 16) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-      else if (mine >= 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-      else if (mine >= 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#define SG_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
+      if (mine >= 28) SG_WAIT(28);
+      else if (mine >= 26) SG_WAIT(26);
+      else if (mine >= 24) SG_WAIT(24);
+      else if (mine >= 22) SG_WAIT(22);
+      else if (mine >= 20) SG_WAIT(20);
+      else if (mine >= 18) SG_WAIT(18);
+      else if (mine >= 16) SG_WAIT(16);
+      else if (mine >= 12) SG_WAIT(12);
+      else if (mine >= 8) SG_WAIT(8);
+      else if (mine >= 6) SG_WAIT(6);
+      else if (mine >= 4) SG_WAIT(4);
+      else if (mine >= 2) SG_WAIT(2);
+      else SG_WAIT(0);
+#undef SG_WAIT
     }
   } else {
     // ================= consumer waves: MFMA plan of this lane =================
@@ -276,16 +290,17 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
         a_off[i][h] = ((pl * 32 + row) * 8 + ((2 * (i ^ gsw)) + (pp >> 1))) * 16 + 8 * (pp & 1);
       }
     // B fragments: column n = 16 f + i16 -> (c, kh, kw); columns >= 147 read column 146 (their weights are zero)
-    int b_row[SG_NF], b_kh[SG_NF]; unsigned b_sel[SG_NF];
+    int b_off[SG_NF]; unsigned b_selA[SG_NF], b_selB[SG_NF];
 #pragma unroll
     for (int f = 0; f < SG_NF; ++f) {
       int n = 16 * f + i16;
       if (n > SG_NCOL - 1) n = SG_NCOL - 1;
       const int c = n / 49, rem = n - c * 49, kh = rem / 7, kw = rem - kh * 7;
-      b_row[f] = q * SG_RING * SG_RPITCH + (c * 2 + (kw & 1)) * SG_MSEQ + SG_MPAD - 1;   // tap kw of position ow reads pixel 2*ow + kw - 2:
-      b_sel[f] = 0x010c000cu + (unsigned)(kw >> 1) * 0x01000100u;                        // byte SG_MPAD + ow + (kw>>1) - 1 of sequence (c, kw&1):
-                                                                                         // the shift kw>>1 sits in the v_perm selectors
-      b_kh[f] = kh;
+      // tap kw of position ow reads pixel 2*ow + kw - 2 = byte SG_MPAD + ow + (kw>>1) - 1 of sequence (c, kw&1); the row kh sits kh slots behind
+      // the window's first slot (no wrap: mirror slots); the shift kw>>1 goes into the v_perm selectors
+      b_off[f] = (q * SG_RINGP + kh) * SG_RPITCH + (c * 2 + (kw & 1)) * SG_MSEQ + SG_MPAD - 1;
+      b_selA[f] = 0x010c000cu + (unsigned)(kw >> 1) * 0x01000100u;
+      b_selB[f] = b_selA[f] + 0x02000200u;
     }
     int m_row = 0, m_col = g;                          // this lane group's 8-run: relative output row, 8-group column (gpr >= 4)
     f32x4 acc[4][SG_NF];
@@ -308,15 +323,21 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
         int oh = oh_lo + m_row;
         if (oh > oh_hi - 1) oh = oh_hi - 1;                     // padded groups: G is zero there, the address must stay on staged rows
         const int slot0 = (2 * oh) & (SG_RING - 1);             // ring slot of input row 2*oh - 2 (tap kh = 0)
-        const char* const mb = mring + m_col * 8;
+        const char* const mb = mring + m_col * 8 + slot0 * SG_RPITCH;
+        // B operands two fragments ahead of their MFMAs (three rotating register sets; left to itself hipcc requests the bytes of two
+        // fragments, waits, multiplies, and only then requests the next two: one exposed LDS round trip per pair)
+        uint2 q01[3]; unsigned q2[3];
+        auto loadb = [&](int f) { const char* const mp = mb + b_off[f]; q01[f % 3] = *(const uint2*)mp; q2[f % 3] = *(const unsigned*)(mp + 8); };
+        loadb(0); loadb(1);
 #pragma unroll
         for (int f = 0; f < SG_NF; ++f) {
-          const char* const mp = mb + ((slot0 + b_kh[f]) & (SG_RING - 1)) * SG_RPITCH + b_row[f];
-          const uint2 m01 = *(const uint2*)mp;
-          const unsigned m2 = *(const unsigned*)(mp + 8);
+          if (f + 2 < SG_NF) loadb(f + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          const uint2 m01 = q01[f % 3];
+          const unsigned m2 = q2[f % 3];
           // mask bytes s + 0..7 of the 12 (s = kw>>1 <= 3) -> bf16 (m << 8): 0x4000 = 2.0.  v_perm_b32 picks from 8 bytes; selector
           // 0x0c = constant zero (the bf16 low bytes), s+1 | s (bytes 0..4 of {m01.y, m01.x}), s+3 | s+2 (bytes 2..6)
-          const unsigned selA = b_sel[f], selB = selA + 0x02000200u;
+          const unsigned selA = b_selA[f], selB = b_selB[f];
           uint4 bw;
           bw.x = __builtin_amdgcn_perm(m01.y, m01.x, selA);
           bw.y = __builtin_amdgcn_perm(m01.y, m01.x, selB);
@@ -325,6 +346,7 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
           const bf16x8 bfr = __builtin_bit_cast(bf16x8, bw);
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][f], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       m_col += 4;
