@@ -55,6 +55,9 @@ constexpr int SG_MSEQ = 128;           // one mask sequence (channel c, w parity
 constexpr int SG_ROWSET = 6 * SG_MSEQ;    // one input row of one frame in HBM: 3 channels x 2 parities = 768 bytes = 48 x 16
 constexpr int SG_RPITCH = SG_ROWSET + 48; // pitch of a ring slot in LDS: 204 dwords = 12 banks mod 64 (consecutive rows kh land on different banks)
 constexpr int SG_RING = 16;            // input rows kept per frame (9 live + 4 in flight)
+#ifndef SG_PD
+#define SG_PD 2                        // B-operand prefetch distance in fragments (3, 4: the same time)
+#endif
 constexpr int SG_MIRROR = 6;           // ring slots 0..5 are kept a second time behind slot 15: the 7 rows kh of a window start at any slot and never wrap
 constexpr int SG_RINGP = SG_RING + SG_MIRROR;   // physical slots per frame
 constexpr int SG_GTILE = 4 * 32 * 128;    // bytes of one K step's G tile: 4 planes x 32 positions x 64 bf16
@@ -326,15 +329,17 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
         const char* const mb = mring + m_col * 8 + slot0 * SG_RPITCH;
         // B operands two fragments ahead of their MFMAs (three rotating register sets; left to itself hipcc requests the bytes of two
         // fragments, waits, multiplies, and only then requests the next two: one exposed LDS round trip per pair)
-        uint2 q01[3]; unsigned q2[3];
-        auto loadb = [&](int f) { const char* const mp = mb + b_off[f]; q01[f % 3] = *(const uint2*)mp; q2[f % 3] = *(const unsigned*)(mp + 8); };
-        loadb(0); loadb(1);
+        constexpr int PD = SG_PD;                        // prefetch distance in fragments
+        uint2 q01[PD + 1]; unsigned q2[PD + 1];
+        auto loadb = [&](int f) { const char* const mp = mb + b_off[f]; q01[f % (PD + 1)] = *(const uint2*)mp; q2[f % (PD + 1)] = *(const unsigned*)(mp + 8); };
+#pragma unroll
+        for (int f = 0; f < PD; ++f) loadb(f);
 #pragma unroll
         for (int f = 0; f < SG_NF; ++f) {
-          if (f + 2 < SG_NF) loadb(f + 2);
+          if (f + PD < SG_NF) loadb(f + PD);
           __builtin_amdgcn_sched_barrier(0);
-          const uint2 m01 = q01[f % 3];
-          const unsigned m2 = q2[f % 3];
+          const uint2 m01 = q01[f % (PD + 1)];
+          const unsigned m2 = q2[f % (PD + 1)];
           // mask bytes s + 0..7 of the 12 (s = kw>>1 <= 3) -> bf16 (m << 8): 0x4000 = 2.0.  v_perm_b32 picks from 8 bytes; selector
           // 0x0c = constant zero (the bf16 low bytes), s+1 | s (bytes 0..4 of {m01.y, m01.x}), s+3 | s+2 (bytes 2..6)
           const unsigned selA = b_selA[f], selB = b_selB[f];
