@@ -202,20 +202,33 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
   // therefore fetches chunk (l%8) ^ 2*gsw(row) -- the swizzle the transposing reads below expect.  (Measured: issuing a piece costs
   // its wave 60-100 cycles; spreading the pieces over the consumer waves -- all of them, or only wave 3 whose SIMD carries half the MFMA
   // load -- slowed the MFMA phases by more than the producer gained: 0.70-0.76 ms against 0.64 ms for the whole delta-gradient.)
+  // (the plane bases and the lane's share of the offset are computed ONCE: written inside the loop, hipcc redid the 64-bit plane
+  // product with ~20 scalar multiplies / adds and a branch per DMA piece.  It did not change the time: without the MFMA phase the loop
+  // still takes 0.69 us per step for its ~18 pieces -- ~90 cycles per global_load_lds from ONE wave is the instruction's own rate)
+  const char* gplane[4];
+#pragma unroll
+  for (int pp = 0; pp < 4; ++pp) {
+    const int ot = t2 + 1 - pp;
+    gplane[pp] = ot >= 0 && ot < p.To ? p.G + (size_t)(b * p.To + ot) * p.Ho * p.Wo * p.g_ld * 2 : nullptr;
+  }
+  unsigned glane[4];                                   // byte offset of this lane inside the 8 positions of group gg (swizzled chunk)
+#pragma unroll
+  for (int gg = 0; gg < 4; ++gg) {
+    const int j = gg * 8 + (lane >> 3);
+    const int gsw = ((j >> 1) & 1) | (((j >> 3) & 1) << 1);
+    const int ch = (lane & 7) ^ (2 * gsw);
+    glane[gg] = (unsigned)(((lane >> 3) * p.g_ld + ch * 8) * 2);
+  }
   auto g_issue = [&](int s, int buf) {
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
       const int gi = 4 * s + gg;
       const int r = gi / gpr, col = gi - r * gpr;
-      const int oh = oh_lo + r, j = gg * 8 + (lane >> 3);
-      const int gsw = ((j >> 1) & 1) | (((j >> 3) & 1) << 1);
-      const int ch = (lane & 7) ^ (2 * gsw);
-      const size_t pos_off = (((size_t)oh * p.Wo + col * 8 + (lane >> 3)) * p.g_ld + ch * 8) * 2;
+      const int oh = oh_lo + r;
+      const unsigned pos_off = (unsigned)((oh * p.Wo + col * 8) * p.g_ld * 2) + glane[gg];   // < 2^31: the host checks the tensor size
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) {
-        const int ot = t2 + 1 - pp;
-        const bool ok = ot >= 0 && ot < p.To && oh < oh_hi;
-        const char* src = ok ? p.G + (size_t)(b * p.To + ot) * p.Ho * p.Wo * p.g_ld * 2 + pos_off : zeros;
+        const char* src = gplane[pp] && oh < oh_hi ? gplane[pp] + pos_off : zeros;
         glds16(src, lds0 + (unsigned)(buf * SG_GTILE + (pp * 32 + gg * 8) * 128));
       }
     }
