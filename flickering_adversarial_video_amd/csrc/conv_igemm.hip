@@ -776,7 +776,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvKP p)
 //     16 different 16-byte bank groups;
 //   * every wave issues the same number of pieces per step (4 activation + ceil(NF / 4) weight pieces), so ONE counted
 //     s_waitcnt vmcnt per step retires exactly the slot the step consumes; one barrier per step publishes it and frees the slot the
-//     next issue overwrites; the tail issues re-read the last slab into dead slots and are drained before the workgroup ends;
+//     next issue overwrites; the last step waits for everything (nothing newer is in flight);
 //   * invalid channel chunks (cin % 32 != 0) fetch chunk 0 of the same position instead -- finite values against zero weights.
 // Epilogue: finish_store, as everywhere.
 __device__ static inline unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
@@ -856,14 +856,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  static_assert(R == 3, "the tail logic below is written for one step of look-ahead beyond the one being waited for");
   int islot = 0;                                  // slot of the next issue
 #pragma unroll
-  for (int k = 0; k < R - 1; ++k) { issue(k, islot); islot = islot + 1 == R ? 0 : islot + 1; }
+  for (int k = 0; k < R - 1; ++k) { issue(k, islot); islot = islot + 1 == R ? 0 : islot + 1; }      // (nslab >= 2: the host checks)
   int cslot = 0;                                  // slot of the step being consumed
   for (int k = 0; k < nslab; ++k) {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW * (R - 2)) : "memory");      // this wave's pieces of step k have landed
+    // this wave's pieces of step k have landed: all but the NPW of step k + 1 -- in the last step there is nothing newer.  (Until the
+    // third session of round 3 the tail re-read the last slab into dead slots to keep the counts equal, 2 of nslab + 2 fetches wasted:
+    // 256 -> 128 channels at 200 704 positions 35.9 -> 35.0 us, 256 -> 384 74.4 -> 71.3 us, 64 -> 128 24.0 -> 22.3 us.)
+    if (k + 1 < nslab) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                              // everybody's have; and everybody is done reading the slot issued into next
-    issue(k + R - 1, islot);
+    if (k + R - 1 < nslab) issue(k + R - 1, islot);
     islot = islot + 1 == R ? 0 : islot + 1;
     const char* const sb = smem + cslot * SLOT;
     cslot = cslot + 1 == R ? 0 : cslot + 1;
@@ -878,7 +883,6 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail issues must have landed before this workgroup's LDS can be handed on
 
   // ---- epilogue ----
   constexpr int NG = 4 * NF / EPL;
