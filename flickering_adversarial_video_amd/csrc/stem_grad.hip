@@ -28,7 +28,7 @@
 //     ds_read_b32 per fragment, +3 %.)
 //  2. stem_delta_grad_kernel: workgroup = (clip b, frame pair t2, chunk of output rows), 8 waves.  Waves 0..6 only run MFMAs: wave (p, q) owns
 //     C for output frame ot = t2+1-p and clip frame t = 2*t2+q (tap kt = 2p+q), 64 x 160 accumulators; the odd frame has three taps, so
-//     wave 7 has no MFMA work: it is the PRODUCER.  It feeds the G tiles (two K steps ahead, three LDS buffers) and the mask rows (ring of
+//     wave 7 has no MFMA work: it is the PRODUCER.  It feeds the G tiles (three K steps ahead, four LDS buffers) and the mask rows (ring of
 //     16 input rows per frame) by LDS-DMA (global_load_lds: no VGPR round trip), issued from inline asm so that hipcc inserts no wait
 //     of its own, and retires them with ONE counted s_waitcnt vmcnt(N) per step (N = what this step issued: everything older has landed).
 //     K step = 32 output positions = 4 runs of 8 consecutive ow:
@@ -61,7 +61,11 @@ constexpr int SG_RING = 16;            // input rows kept per frame (9 live + 4 
 constexpr int SG_MIRROR = 6;           // ring slots 0..5 are kept a second time behind slot 15: the 7 rows kh of a window start at any slot and never wrap
 constexpr int SG_RINGP = SG_RING + SG_MIRROR;   // physical slots per frame
 constexpr int SG_GTILE = 4 * 32 * 128;    // bytes of one K step's G tile: 4 planes x 32 positions x 64 bf16
-constexpr int SG_GBUFS = 3;            // G tiles: two K steps of DMA look-ahead
+#ifndef SG_LA
+#define SG_LA 3
+#endif
+constexpr int SG_LA_ = SG_LA;          // K steps of DMA look-ahead (2 or 3; alone the same time, inside the step 3 is 0.01 ms ahead)
+constexpr int SG_GBUFS = SG_LA_ + 1;   // G tiles
 constexpr int SG_OFF_MRING = SG_GBUFS * SG_GTILE;
 constexpr int SG_OFF_RED = SG_OFF_MRING + 2 * SG_RINGP * SG_RPITCH;
 constexpr int SG_LDS = SG_OFF_RED + 8 * 3 * 4;
@@ -253,13 +257,14 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
     return n;
   };
 
-  // ---- prologue: the mask rows of steps 0 and 1, G tiles 0 and 1 ----
+  // ---- prologue: the mask rows and G tiles of the first SG_LA steps ----
   const int h_first = 2 * oh_lo - 2;
-  int h_req = hmax_of(nsteps > 1 ? 1 : 0);           // highest mask row requested
+  int h_req = hmax_of(min(SG_LA_ - 1, nsteps - 1));  // highest mask row requested
   if (producer) {
     mask_issue(h_first, h_req);
-    g_issue(0, 0);
-    if (nsteps > 1) g_issue(1, 1);
+#pragma unroll
+    for (int j = 0; j < SG_LA_; ++j)
+      if (j < nsteps) g_issue(j, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
@@ -267,31 +272,25 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
   float sum[3] = {0.f, 0.f, 0.f};
   if (producer) {
     // ================= producer wave: one barrier per K step, like the consumers =================
-    // Step s issues the mask rows and the G tile of step s+2, then waits until only ITS OWN DMA is still in flight: everything issued in
-    // earlier steps -- what step s+1 reads -- has landed (vmcnt retires in issue order).
+    // Step s issues the mask rows and the G tile of step s + SG_LA, then waits until only the DMA of the last SG_LA - 1 steps is still in
+    // flight: everything issued earlier -- what step s+1 reads -- has landed (vmcnt retires in issue order).
+    int prev = 0;                                      // pieces issued in step s - 1
     for (int s = 0; s < nsteps; ++s) {
       int mine = 0;
-      if (s + 2 < nsteps) {
-        const int hm = hmax_of(s + 2);
+      if (s + SG_LA_ < nsteps) {
+        const int hm = hmax_of(s + SG_LA_);
         if (hm > h_req && !(p.dbg & 1)) mine += mask_issue(h_req + 1, hm);
         if (hm > h_req) h_req = hm;
-        if (!(p.dbg & 4)) { g_issue(s + 2, (s + 2) % SG_GBUFS); mine += 16; }      // that buffer was last read in step s-1
+        if (!(p.dbg & 4)) { g_issue(s + SG_LA_, (s + SG_LA_) % SG_GBUFS); mine += 16; }      // that buffer was last read in step s-1
       }
-#define SG_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory")
-      if (mine >= 28) SG_WAIT(28);
-      else if (mine >= 26) SG_WAIT(26);
-      else if (mine >= 24) SG_WAIT(24);
-      else if (mine >= 22) SG_WAIT(22);
-      else if (mine >= 20) SG_WAIT(20);
-      else if (mine >= 18) SG_WAIT(18);
-      else if (mine >= 16) SG_WAIT(16);
-      else if (mine >= 12) SG_WAIT(12);
-      else if (mine >= 8) SG_WAIT(8);
-      else if (mine >= 6) SG_WAIT(6);
-      else if (mine >= 4) SG_WAIT(4);
-      else if (mine >= 2) SG_WAIT(2);
-      else SG_WAIT(0);
+      const int allow = SG_LA_ >= 3 ? mine + prev : mine;
+      prev = mine;
+#define SG_WAIT(n) if (allow >= n) { asm volatile("s_waitcnt vmcnt(" #n ")\n\ts_barrier" ::: "memory"); continue; }
+      SG_WAIT(56) SG_WAIT(52) SG_WAIT(48) SG_WAIT(44) SG_WAIT(40) SG_WAIT(38) SG_WAIT(36) SG_WAIT(34) SG_WAIT(32) SG_WAIT(30)
+      SG_WAIT(28) SG_WAIT(26) SG_WAIT(24) SG_WAIT(22) SG_WAIT(20) SG_WAIT(18) SG_WAIT(16) SG_WAIT(12) SG_WAIT(8) SG_WAIT(6)
+      SG_WAIT(4) SG_WAIT(2)
 #undef SG_WAIT
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     }
   } else {
     // ================= consumer waves: MFMA plan of this lane =================
