@@ -64,8 +64,12 @@ constexpr int SG_GTILE = 4 * 32 * 128;    // bytes of one K step's G tile: 4 pla
 #ifndef SG_LA
 #define SG_LA 3
 #endif
-constexpr int SG_LA_ = SG_LA;          // K steps of DMA look-ahead (2 or 3; alone the same time, inside the step 3 is 0.01 ms ahead)
-constexpr int SG_GBUFS = SG_LA_ + 1;   // G tiles
+#ifndef SG_SPB
+#define SG_SPB 1
+#endif
+constexpr int SG_LA_ = SG_LA;          // barrier intervals of DMA look-ahead (2 or 3; alone the same time, inside the step 3 is 0.01 ms ahead)
+constexpr int SG_SPB_ = SG_SPB;        // K steps per barrier interval (2 with SG_LA = 2: 0.485-0.488 vs 0.482-0.483 ms -- the barriers are not what the loop waits for)
+constexpr int SG_GBUFS = SG_SPB_ * (SG_LA_ + 1);   // G tiles
 constexpr int SG_OFF_MRING = SG_GBUFS * SG_GTILE;
 constexpr int SG_OFF_RED = SG_OFF_MRING + 2 * SG_RINGP * SG_RPITCH;
 constexpr int SG_LDS = SG_OFF_RED + 8 * 3 * 4;
@@ -257,13 +261,13 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
     return n;
   };
 
-  // ---- prologue: the mask rows and G tiles of the first SG_LA steps ----
+  // ---- prologue: the mask rows and G tiles of the first SG_LA barrier intervals ----
   const int h_first = 2 * oh_lo - 2;
-  int h_req = hmax_of(min(SG_LA_ - 1, nsteps - 1));  // highest mask row requested
+  int h_req = hmax_of(min(SG_SPB_ * SG_LA_ - 1, nsteps - 1));  // highest mask row requested
   if (producer) {
     mask_issue(h_first, h_req);
 #pragma unroll
-    for (int j = 0; j < SG_LA_; ++j)
+    for (int j = 0; j < SG_SPB_ * SG_LA_; ++j)
       if (j < nsteps) g_issue(j, j);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -271,17 +275,22 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
 
   float sum[3] = {0.f, 0.f, 0.f};
   if (producer) {
-    // ================= producer wave: one barrier per K step, like the consumers =================
-    // Step s issues the mask rows and the G tile of step s + SG_LA, then waits until only the DMA of the last SG_LA - 1 steps is still in
-    // flight: everything issued earlier -- what step s+1 reads -- has landed (vmcnt retires in issue order).
-    int prev = 0;                                      // pieces issued in step s - 1
-    for (int s = 0; s < nsteps; ++s) {
+    // ================= producer wave: one barrier per interval of SG_SPB K steps, like the consumers =================
+    // Interval d issues the mask rows and the G tiles of interval d + SG_LA, then waits until only the DMA of the last SG_LA - 1 intervals
+    // is still in flight: everything issued earlier -- what interval d+1 reads -- has landed (vmcnt retires in issue order).
+    int prev = 0;                                      // pieces issued in interval d - 1
+    const int nint = (nsteps + SG_SPB_ - 1) / SG_SPB_;
+    for (int d = 0; d < nint; ++d) {
       int mine = 0;
-      if (s + SG_LA_ < nsteps) {
-        const int hm = hmax_of(s + SG_LA_);
-        if (hm > h_req && !(p.dbg & 1)) mine += mask_issue(h_req + 1, hm);
-        if (hm > h_req) h_req = hm;
-        if (!(p.dbg & 4)) { g_issue(s + SG_LA_, (s + SG_LA_) % SG_GBUFS); mine += 16; }      // that buffer was last read in step s-1
+#pragma unroll
+      for (int j = 0; j < SG_SPB_; ++j) {
+        const int st = SG_SPB_ * (d + SG_LA_) + j;
+        if (st < nsteps) {
+          const int hm = hmax_of(st);
+          if (hm > h_req && !(p.dbg & 1)) mine += mask_issue(h_req + 1, hm);
+          if (hm > h_req) h_req = hm;
+          if (!(p.dbg & 4)) { g_issue(st, st % SG_GBUFS); mine += 16; }      // that buffer was last read in interval d - 1
+        }
       }
       const int allow = SG_LA_ >= 3 ? mine + prev : mine;
       prev = mine;
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
       }
       m_col += 4;
       if (m_col >= gpr) { m_col -= gpr; ++m_row; }
-      __syncthreads();
+      if (SG_SPB_ == 1 || (s + 1) % SG_SPB_ == 0 || s == nsteps - 1) __syncthreads();
     }
     // contract the accumulators with the fp32 weights of this wave's tap kt = 2*plane + q
     const float* const wk = p.Wf + (size_t)(2 * pl + q) * SG_NPAD * SG_CO + 4 * g;
