@@ -1000,17 +1000,30 @@ __global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd
   const float scale = __uint_as_float((unsigned)(127 + 24 + 127 - ex) << 23);
   const float inv_scale = __uint_as_float((unsigned)(127 - 24 - 127 + ex) << 23);
   if (P > 0) {
+    // Branch-free: the 8 table reads of a window are requested together, and an element whose cell is outside the tile adds into a
+    // dummy word of its own thread instead of being skipped.  (Written as  if (inside) atomicAdd(.. + lut[tap] ..)  hipcc emitted, per
+    // element, exec-mask branch -> ds_read_b32 -> s_waitcnt lgkmcnt(0) -> ds_add_u32: 64 exposed LDS round trips per lane.)
+    unsigned* const dummy = lut + 256 + tid;
+    if (!(pg.dbg & 1)) {
 #pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      char* const plane0 = (char*)acc + (size_t)(q * 4 * RS) * 4 + org[i];
+      for (int i = 0; i < NIT; ++i) {
+        char* const plane0 = (char*)acc + (size_t)(q * 4 * RS) * 4 + org[i];
+        unsigned off[2][4];
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned tap = (ib[i][f] >> (8 * j)) & 255u;               // 255 ("no cell"): bit 31 of the mask, never set
-          if (((okm[i] >> (tap & 31u)) & 1u) && !(pg.dbg & 1))
-            atomicAdd((unsigned*)(plane0 + (size_t)((f * 16 + j) * RS) * 4 + lut[tap]), (unsigned)__float2int_rn(v[i][f][j] * scale));
-        }
+          for (int j = 0; j < 4; ++j) off[f][j] = lut[(ib[i][f] >> (8 * j)) & 255u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned tap = (ib[i][f] >> (8 * j)) & 255u;             // 255 ("no cell"): bit 31 of the mask, never set
+            const bool inside = (okm[i] >> (tap & 31u)) & 1u;
+            unsigned* const cell = (unsigned*)(plane0 + (size_t)((f * 16 + j) * RS) * 4 + off[f][j]);
+            atomicAdd(inside ? cell : dummy, (unsigned)__float2int_rn(v[i][f][j] * scale));
+          }
+      }
     }
   }
   __syncthreads();
@@ -1265,7 +1278,7 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   const char* const reg_env = getenv("FLK_POOL_GEMM_REG");     // (read per call: the tests compare the two forms)
   const bool reg_form = !(reg_env && atoi(reg_env) == 0);
   if (reg_form && reach <= 512 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
-    const size_t lds_reg = lds + (size_t)(64 + 256) * sizeof(unsigned);      // + the tap table
+    const size_t lds_reg = lds + (size_t)(64 + 256 + 256) * sizeof(unsigned);      // + the tap table + one dummy word per thread
     switch (pg.KS) {
       case 1: FLK_LAUNCH_KERNEL((maxpool_scatter_gemm_bwd_reg<1, 8, 4>), grid, dim3(256), lds_reg, s, pg, m1, m2); break;
       case 2: FLK_LAUNCH_KERNEL((maxpool_scatter_gemm_bwd_reg<2, 8, 4>), grid, dim3(256), lds_reg, s, pg, m1, m2); break;
