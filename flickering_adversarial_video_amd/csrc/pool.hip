@@ -442,14 +442,28 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
   constexpr int WH = WT + 2;                                   // = p.Wh
   const int HW = p.Hh * WH;
   const float inv_HW = 1.0f / (float)HW;                       // (hp + 0.5) / HW is never within 0.5 / HW of an integer: the float quotient truncates exactly
-  for (int hp = tid >> 2; hp < p.P; hp += 64) {                // (integer divisions by run-time values here were as many VALU operations as the pooling itself)
-    const int a = (int)(((float)hp + 0.5f) * inv_HW), rem = hp - a * HW, bq = rem / WH, c = rem - bq * WH;
-    const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
-    uint4 v = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);     // -inf
-    if (chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi && !(p.dbg & 1))
-      v = *(const uint4*)(k.in + ((((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw) * k.in_ld + k.in_coff + c0) * 2);
-    v.x = bf16x2_to_keys(v.x); v.y = bf16x2_to_keys(v.y); v.z = bf16x2_to_keys(v.z); v.w = bf16x2_to_keys(v.w);
-    *(uint4*)(smem + pplane_off(ch, p.plane_b) + hp * 16) = v;
+  // staging, SU halo positions per thread and pass (the whole halo in one pass: P <= 1008): the loads are requested together (as a
+  // plain loop hipcc emitted load -> wait -> convert -> ds_write per position: 14 exposed memory round trips per workgroup)
+  constexpr int SU = 16;
+  for (int hp0 = tid >> 2; hp0 < p.P; hp0 += 64 * SU) {
+    uint4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int hp = hp0 + 64 * u;
+      const int a = (int)(((float)hp + 0.5f) * inv_HW), rem = hp - a * HW, bq = rem / WH, c = rem - bq * WH;
+      const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
+      v[u] = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);     // -inf
+      if (hp < p.P && chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi && !(p.dbg & 1))
+        v[u] = *(const uint4*)(k.in + ((((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw) * k.in_ld + k.in_coff + c0) * 2);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int hp = hp0 + 64 * u;
+      if (hp >= p.P) break;
+      uint4 w = v[u];
+      w.x = bf16x2_to_keys(w.x); w.y = bf16x2_to_keys(w.y); w.z = bf16x2_to_keys(w.z); w.w = bf16x2_to_keys(w.w);
+      *(uint4*)(smem + pplane_off(ch, p.plane_b) + hp * 16) = w;
+    }
   }
   __syncthreads();
   if (!chvalid) return;
@@ -463,6 +477,12 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
     auto colmax = [&](int c, uint32_t (&m)[8]) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) m[e] = 0;
+      uint4 tapv[9];                                  // the 9 reads of the column are requested together
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh) tapv[dt * 3 + dh] = *(const uint4*)(base + ((dt * p.Hh + dh) * WH + c) * 16);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
           // tag = 27 - tap of (dt, dh, dw = 0): small enough for an inline constant, so the high-half key is ONE v_and_or_b32
           // (with 255 - tap the mask and the tag were two literals: v_and + v_or)
           const uint32_t tag = 27u - 3u * (uint32_t)(dt * 3 + dh);
-          const uint4 v = *(const uint4*)(base + ((dt * p.Hh + dh) * WH + c) * 16);
+          const uint4 v = tapv[dt * 3 + dh];
           const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
