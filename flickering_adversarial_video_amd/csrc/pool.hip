@@ -103,6 +103,61 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const PoolKP p) {
   PV<T>::stidx(p.idx + opos * p.C + cg * EPL, bi);
 }
 
+// The same with the window as template arguments (the I3D pools: 1x3x3, 3x3x3, 2x2x2): the tap loop unrolls and ALL tap loads of a thread
+// are requested before the first compare -- with run-time loop bounds hipcc emits load -> wait -> compare per tap, KT*KH*KW exposed memory
+// round trips per thread.  Same scan order, same tie rule (strict >), same bits.
+template <typename T, int KT, int KH, int KW>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel_k(const PoolKP p) {
+  constexpr int EPL = PV<T>::EPL, NT = KT * KH * KW;
+  const int ng = p.C / EPL;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)(p.Wo * ng)) return;
+  const int ow = i / ng, cg = i - ow * ng;
+  const int oh = blockIdx.y, ot = blockIdx.z % p.To, b = blockIdx.z / p.To;
+  uint4 raw[NT];
+  bool ok[NT];
+#pragma unroll
+  for (int dt = 0; dt < KT; ++dt)
+#pragma unroll
+    for (int dh = 0; dh < KH; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < KW; ++dw) {
+        const int tap = (dt * KH + dh) * KW + dw;
+        const int it = ot * p.st - p.pt + dt, ih = oh * p.sh - p.ph + dh, iw = ow * p.sw - p.pw + dw;
+        ok[tap] = (unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi;
+        const size_t pos = ok[tap] ? (((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw) : 0;      // (position 0 is always readable)
+        if constexpr (sizeof(T) == 2) raw[tap] = *(const uint4*)(p.in + (pos * p.in_ld + p.in_coff + cg * EPL) * sizeof(T));
+        else raw[tap] = *(const uint4*)(p.in + (pos * p.in_ld + p.in_coff + cg * EPL) * sizeof(T));
+      }
+  float best[EPL];
+  int bi[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+  for (int tap = 0; tap < NT; ++tap) {
+    float v[EPL];
+    if constexpr (sizeof(T) == 2) {
+      const uint32_t w[4] = {raw[tap].x, raw[tap].y, raw[tap].z, raw[tap].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[2 * k] = __uint_as_float(w[k] << 16); v[2 * k + 1] = __uint_as_float(w[k] & 0xffff0000u); }
+    } else {
+      v[0] = __uint_as_float(raw[tap].x); v[1] = __uint_as_float(raw[tap].y); v[2] = __uint_as_float(raw[tap].z); v[3] = __uint_as_float(raw[tap].w);
+    }
+    if (ok[tap]) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        if (v[e] > best[e]) { best[e] = v[e]; bi[e] = tap; }
+    }
+  }
+  if (p.relu_input) {
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) bi[e] = best[e] > 0.f ? bi[e] : 255;
+  }
+  const size_t opos = (((size_t)(b * p.To + ot) * p.Ho + oh) * p.Wo + ow);
+  PV<T>::st(p.out + (opos * p.out_ld + p.out_coff + cg * EPL) * sizeof(T), best);
+  PV<T>::stidx(p.idx + opos * p.C + cg * EPL, bi);
+}
+
 // grid: x = chunks of 256 over (w, channel group) of one INPUT row; y = h; z = b*T + t
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
@@ -1176,8 +1231,18 @@ extern "C" int flk_maxpool3d_fwd(const flk_pool_args* a, int dtype, void* stream
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   FLK_REQUIRE(a->Ho < 65536 && (long)a->B * a->To < 65536, "flk_maxpool3d_fwd: grid too large");
   const dim3 grid((unsigned)((a->Wo * (a->C / epl) + 255) / 256), (unsigned)a->Ho, (unsigned)(a->B * a->To));
-  if (dtype == FLK_BF16) FLK_LAUNCH_KERNEL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
-  else FLK_LAUNCH_KERNEL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  static const bool fixed_k = !(getenv("FLK_POOL_FWD_FIXED") && atoi(getenv("FLK_POOL_FWD_FIXED")) == 0);
+  const int kcode = fixed_k ? a->kt * 100 + a->kh * 10 + a->kw : 0;
+  if (dtype == FLK_BF16) {
+    if (kcode == 133) FLK_LAUNCH_KERNEL((maxpool_fwd_kernel_k<bf16_t, 1, 3, 3>), grid, dim3(256), 0, (hipStream_t)stream, kp);
+    else if (kcode == 333) FLK_LAUNCH_KERNEL((maxpool_fwd_kernel_k<bf16_t, 3, 3, 3>), grid, dim3(256), 0, (hipStream_t)stream, kp);
+    else if (kcode == 222) FLK_LAUNCH_KERNEL((maxpool_fwd_kernel_k<bf16_t, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, kp);
+    else FLK_LAUNCH_KERNEL(maxpool_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  } else {
+    if (kcode == 133) FLK_LAUNCH_KERNEL((maxpool_fwd_kernel_k<float, 1, 3, 3>), grid, dim3(256), 0, (hipStream_t)stream, kp);
+    else if (kcode == 222) FLK_LAUNCH_KERNEL((maxpool_fwd_kernel_k<float, 2, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream, kp);
+    else FLK_LAUNCH_KERNEL(maxpool_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  }
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
