@@ -272,6 +272,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   // ---- staging plan: pair n of this thread = (halo position (tid>>2) + 64 n, chunk tid&3) ----
   const int ch = tid & 3;
   constexpr int NPK = K1 ? 4 : NPAIR;   // 1x1x1 tiles have P <= 256: 4 pairs per thread
+#ifndef FLK_HALO_BATCH
+#define FLK_HALO_BATCH 4
+#endif
+  constexpr int HB = K1 ? 4 : FLK_HALO_BATCH;   // halo pieces requested together when a slab is staged (NPK % HB == 0); 8 / 16: the same times
+                                                // (Conv3d_2c 0.240 / 0.241 / 0.243 ms, the step 6.09-6.11 ms for all three)
   int goff[NPK];  // linear input position of the pair, -1 = zero fill (padding), -2 = beyond the halo
   {
     const int HW = p.Hh * p.Wh;
@@ -377,13 +382,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
         const char* src; int ld;
         const bool chvalid = slab_src(s, src, ld);
   #pragma unroll
-        for (int n0 = 0; n0 < NPK; n0 += 4) {
+        for (int n0 = 0; n0 < NPK; n0 += HB) {
           if (n0 * 64 >= p.P) break;
-          uint4 v[4];
+          uint4 v[HB];
   #pragma unroll
-          for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+          for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
   #pragma unroll
-          for (int n = 0; n < 4; ++n)
+          for (int n = 0; n < HB; ++n)
             if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
         }
       }
@@ -437,13 +442,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       const char* src; int ld;
       const bool chvalid = slab_src(0, src, ld);
 #pragma unroll
-      for (int n0 = 0; n0 < NPK; n0 += 4) {
+      for (int n0 = 0; n0 < NPK; n0 += HB) {
         if (n0 * 64 >= p.P) break;
-        uint4 v[4];
+        uint4 v[HB];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+        for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < HB; ++n)
           if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
       }
     }
@@ -655,13 +660,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
             const char* src; int ld;
             const bool chvalid = slab_src(s, src, ld);
 #pragma unroll
-            for (int n0 = 0; n0 < NPK; n0 += 4) {
+            for (int n0 = 0; n0 < NPK; n0 += HB) {
               if (n0 * 64 >= p.P) break;
-              uint4 v[4];
+              uint4 v[HB];
 #pragma unroll
-              for (int n = 0; n < 4; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+              for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
 #pragma unroll
-              for (int n = 0; n < 4; ++n)
+              for (int n = 0; n < HB; ++n)
                 if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
             }
             __syncthreads();
