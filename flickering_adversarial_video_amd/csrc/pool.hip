@@ -235,6 +235,22 @@ __global__ __launch_bounds__(256) void maxpool_strided_bwd(const PoolKP p) {
         PV<T>::ldidx(p.idx + opos * p.C + cg * EPL, id[w]);
         PV<T>::ld(p.gout + (opos * p.gout_ld + p.gout_coff + cg * EPL) * sizeof(T), go[w]);
       }
+  // the ReLU-mask operand of every owned cell, requested with the loads above (inside the cell loop each was load -> wait -> store):
+  // 1x3x3 / 2 (4 cells) 57.9 -> 54.4 us; with 8 cells the registers cost more than the round trips (3x3x3 / 2: 64.1 -> 67.6 us): not there
+  constexpr bool HOIST = ST * SH * SW <= 4;
+  float mk[HOIST ? ST * SH * SW : 1][EPL];
+  if (HOIST && p.mask) {
+#pragma unroll
+    for (int at = 0; at < ST; ++at)
+#pragma unroll
+      for (int ah = 0; ah < SH; ++ah)
+#pragma unroll
+        for (int aw = 0; aw < SW; ++aw) {
+          const int it = min(ot * ST + at, p.Ti - 1), ih = min(oh * SH + ah, p.Hi - 1), iw = min(ow * SW + aw, p.Wi - 1);
+          const size_t ipos = (((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw);
+          PV<T>::ld(p.mask + (ipos * p.mask_ld + p.mask_coff + cg * EPL) * sizeof(T), mk[(at * SH + ah) * SW + aw]);
+        }
+  }
 #pragma unroll
   for (int at = 0; at < ST; ++at)
 #pragma unroll
@@ -262,10 +278,9 @@ __global__ __launch_bounds__(256) void maxpool_strided_bwd(const PoolKP p) {
             }
         const size_t ipos = (((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw);
         if (p.mask) {
-          float mk[EPL];
-          PV<T>::ld(p.mask + (ipos * p.mask_ld + p.mask_coff + cg * EPL) * sizeof(T), mk);
+          if (!HOIST) PV<T>::ld(p.mask + (ipos * p.mask_ld + p.mask_coff + cg * EPL) * sizeof(T), mk[0]);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) g[e] = mk[e] > 0.f ? g[e] : 0.f;
+          for (int e = 0; e < EPL; ++e) g[e] = mk[HOIST ? (at * SH + ah) * SW + aw : 0][e] > 0.f ? g[e] : 0.f;
         }
         PV<T>::st(p.gin + (ipos * p.gin_ld + p.gin_coff + cg * EPL) * sizeof(T), g);
       }
