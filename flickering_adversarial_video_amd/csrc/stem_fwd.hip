@@ -297,12 +297,37 @@ __global__ __launch_bounds__(256, NI == 4 ? 3 : 2) void stem_fwd_u8_kernel(const
   const int ot = ot0 + rt, ow = ow0 + 2 * wi + par;
   if (ot >= p.To) return;
   const int wc = ow == 0 ? 0 : ow == 111 ? 3 : ow == 110 ? 2 : 1;
+  // the batch-norm scale / bias of the lane's 16 channels once, and per output row the position-class bias of both store groups before the
+  // first store (written per store group, hipcc re-requested scale and bias behind every store -- it must assume they alias -- and waited
+  // for each: 32 exposed round trips per wave)
+  float4 sc[2][2], bi[2][2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      sc[g][h] = *(const float4*)(p.scale + g * 32 + q * 8 + 4 * h);
+      bi[g][h] = *(const float4*)(p.bias + g * 32 + q * 8 + 4 * h);
+    }
+  // (the position-class bias of row i + 1 is requested BEFORE row i is stored: vmcnt retires in order, so waiting for loads issued behind
+  // stores would wait for the stores as well)
+  auto load_pb = [&](int i, float4 (&t)[2][2]) {
+    const int oh = oh0 + NI * hsel + i;
+    const int hc = oh == 0 ? 0 : oh == 111 ? 3 : oh == 110 ? 2 : 1;
+    const float* pb = p.pos_bias ? p.pos_bias + (size_t)b * p.pos_bias_bstride + (size_t)((ot * 4 + hc) * 4 + wc) * 64 : nullptr;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) t[g][h] = pb ? *(const float4*)(pb + g * 32 + q * 8 + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  float4 tq[2][2][2];
+  load_pb(0, tq[0]);
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int oh = oh0 + NI * hsel + i;
-    const int hc = oh == 0 ? 0 : oh == 111 ? 3 : oh == 110 ? 2 : 1;
     const size_t opos = ((size_t)(b * p.To + ot) * 112 + oh) * 112 + ow;
-    const float* pb = p.pos_bias ? p.pos_bias + (size_t)b * p.pos_bias_bstride + (size_t)((ot * 4 + hc) * 4 + wc) * 64 : nullptr;
+    if (i + 1 < NI) load_pb(i + 1, tq[(i + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 (&t4)[2][2] = tq[i & 1];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const int c0 = g * 32 + q * 8;
@@ -310,22 +335,17 @@ __global__ __launch_bounds__(256, NI == 4 ? 3 : 2) void stem_fwd_u8_kernel(const
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = acc[(g * 8 + e) >> 2][i][(g * 8 + e) & 3];
 #pragma unroll
-      for (int e = 0; e < 8; e += 4) {
-        const float4 sc = *(const float4*)(p.scale + c0 + e), bi = *(const float4*)(p.bias + c0 + e);
-        v[e] = v[e] * sc.x + bi.x; v[e + 1] = v[e + 1] * sc.y + bi.y; v[e + 2] = v[e + 2] * sc.z + bi.z; v[e + 3] = v[e + 3] * sc.w + bi.w;
-      }
-      if (pb) {
-#pragma unroll
-        for (int e = 0; e < 8; e += 4) {
-          const float4 t4 = *(const float4*)(pb + c0 + e);
-          v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
-        }
+      for (int h = 0; h < 2; ++h) {
+        const int e = 4 * h;
+        v[e] = v[e] * sc[g][h].x + bi[g][h].x + t4[g][h].x; v[e + 1] = v[e + 1] * sc[g][h].y + bi[g][h].y + t4[g][h].y;
+        v[e + 2] = v[e + 2] * sc[g][h].z + bi[g][h].z + t4[g][h].z; v[e + 3] = v[e + 3] * sc[g][h].w + bi[g][h].w + t4[g][h].w;
       }
       bf16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (bf16_t)fmaxf(v[e], 0.f);
       if (SF_ON(5) || v[0] == 12345.f) *(bf16x8*)(p.out + (opos * p.out_ld + c0) * sizeof(bf16_t)) = o;
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
