@@ -211,6 +211,54 @@ __device__ static inline void finish_store_row(const ConvKP& p, size_t opos, con
   }
 }
 
+// finish_store_row with the batch-norm scale / bias of the lane's NG store groups already in registers (loaded once per lane: inside the
+// row loop hipcc re-requests them behind every store -- it must assume they alias the output -- and waits for each)
+template <typename T, int NG>
+__device__ static inline void finish_store_row_pre(const ConvKP& p, size_t opos, int c0, float (&v)[NG][Prec<T>::EPL],
+                                                   const float4 (&sc)[NG][2], const float4 (&bi)[NG][2]) {
+  typedef Prec<T> PR;
+  constexpr int EPL = PR::EPL;
+  static_assert(EPL == 8, "bf16 only");
+  uint4 av[NG], mv[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = c0 + g * 4 * EPL;
+    const bool in = c < p.cout;
+    if (p.add) av[g] = *(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + (in ? c : 0)) * sizeof(T));
+    if (p.mask) mv[g] = *(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + (in ? c : 0)) * sizeof(T));
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = c0 + g * 4 * EPL;
+    if (c >= p.cout) continue;
+    float* w = v[g];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = 4 * h;
+      w[e] *= sc[g][h].x; w[e + 1] *= sc[g][h].y; w[e + 2] *= sc[g][h].z; w[e + 3] *= sc[g][h].w;
+      w[e] += bi[g][h].x; w[e + 1] += bi[g][h].y; w[e + 2] += bi[g][h].z; w[e + 3] += bi[g][h].w;
+    }
+    if (p.add) {
+      float a[EPL];
+      PR::to_f32(av[g], a);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] += a[e];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] = fmaxf(w[e], 0.f);
+    }
+    if (p.mask) {
+      float a[EPL];
+      PR::to_f32(mv[g], a);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] = a[e] > 0.f ? w[e] : 0.f;
+    }
+    if (c < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c) * sizeof(T)) = PR::from_f32(w);
+    else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c - p.cout1)) * sizeof(T)) = PR::from_f32(w);
+  }
+}
+
 constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pairs staged per thread (16)
 
 // WN = waves along N: the 4 waves form a (4/WN) x WN grid; the workgroup tile is 64*(4/WN) rows x 16*NF channels and
@@ -892,6 +940,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
   // ---- epilogue ----
   constexpr int NG = 4 * NF / EPL;
   const int cbase = ntile * 16 * NF + q * EPL;
+  constexpr bool PRE = NG <= 3;                    // (NG = 4: 64 more registers would spill)
+  float4 sc[PRE ? NG : 1][2], bi[PRE ? NG : 1][2];
+  if (PRE) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int c = cbase + g * 4 * EPL, cc = c < p.cout ? c : 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        sc[g][h] = p.scale ? *(const float4*)(p.scale + cc + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);
+        bi[g][h] = p.bias ? *(const float4*)(p.bias + cc + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const unsigned pos = pos0 + (unsigned)(64 * wave + 16 * i + m);
@@ -901,7 +962,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
     for (int g = 0; g < NG; ++g)
 #pragma unroll
       for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
-    finish_store_row<bf16_t, NG>(p, (size_t)pos, nullptr, cbase, v);
+    if constexpr (PRE) finish_store_row_pre<bf16_t, NG>(p, (size_t)pos, cbase, v, sc, bi);
+    else finish_store_row<bf16_t, NG>(p, (size_t)pos, nullptr, cbase, v);
   }
 }
 
