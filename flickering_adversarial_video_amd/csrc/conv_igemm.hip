@@ -102,25 +102,31 @@ __device__ static inline const float* pos_bias_row(const ConvKP& p, int b, int o
   return p.pos_bias + (size_t)b * p.pos_bias_bstride + (size_t)((ot * 4 + hc) * 4 + wc) * p.cout;
 }
 
+// acc * scale, rounded, + bias, rounded -- NEVER one fused multiply-add, in every epilogue variant (finish_store, finish_store_row,
+// finish_store_row_pre): left to fp-contract, whether hipcc fuses the two steps depends on the shape of the surrounding code, and the same
+// layer run through two kernels (128- against 64-channel tiles, a batch-1 against a batch-8 plan) would differ in the last bit.  (Two
+// roundings are also what the oracle's separate multiply and add do.)
+__device__ static inline float epi_scale_bias(float v, float sc, float bi, bool has_scale, bool has_bias) {
+#pragma clang fp contract(off)
+  float t = v;
+  if (has_scale) t = t * sc;
+  if (has_bias) t = t + bi;
+  return t;
+}
+
 // the epilogue of EPL consecutive output channels [c0, c0 + EPL) of physical output position opos: v = acc*scale + bias (+ position
 // bias) (+ add); relu; mask; 16-byte store into the first or second output segment
 template <typename T>
 __device__ static inline void finish_store(const ConvKP& p, size_t opos, const float* pb, int c0, float* v) {
   typedef Prec<T> PR;
   constexpr int EPL = PR::EPL;
-  if (p.scale) {
+  const bool hs = p.scale != nullptr, hb = p.bias != nullptr;
 #pragma unroll
-    for (int e = 0; e < EPL; e += 4) {
-      const float4 sc = *(const float4*)(p.scale + c0 + e);
-      v[e] *= sc.x; v[e + 1] *= sc.y; v[e + 2] *= sc.z; v[e + 3] *= sc.w;
-    }
-  }
-  if (p.bias) {
-#pragma unroll
-    for (int e = 0; e < EPL; e += 4) {
-      const float4 bi = *(const float4*)(p.bias + c0 + e);
-      v[e] += bi.x; v[e + 1] += bi.y; v[e + 2] += bi.z; v[e + 3] += bi.w;
-    }
+  for (int e = 0; e < EPL; e += 4) {
+    const float4 sc = hs ? *(const float4*)(p.scale + c0 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bi = hb ? *(const float4*)(p.bias + c0 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[e] = epi_scale_bias(v[e], sc.x, bi.x, hs, hb); v[e + 1] = epi_scale_bias(v[e + 1], sc.y, bi.y, hs, hb);
+    v[e + 2] = epi_scale_bias(v[e + 2], sc.z, bi.z, hs, hb); v[e + 3] = epi_scale_bias(v[e + 3], sc.w, bi.w, hs, hb);
   }
   if (pb) {
 #pragma unroll
@@ -169,19 +175,13 @@ __device__ static inline void finish_store_row(const ConvKP& p, size_t opos, con
     const int c = c0 + g * 4 * EPL;
     if (c >= p.cout) continue;
     float* w = v[g];
-    if (p.scale) {
+    const bool hs = p.scale != nullptr, hb = p.bias != nullptr;
 #pragma unroll
-      for (int e = 0; e < EPL; e += 4) {
-        const float4 sc = *(const float4*)(p.scale + c + e);
-        w[e] *= sc.x; w[e + 1] *= sc.y; w[e + 2] *= sc.z; w[e + 3] *= sc.w;
-      }
-    }
-    if (p.bias) {
-#pragma unroll
-      for (int e = 0; e < EPL; e += 4) {
-        const float4 bi = *(const float4*)(p.bias + c + e);
-        w[e] += bi.x; w[e + 1] += bi.y; w[e + 2] += bi.z; w[e + 3] += bi.w;
-      }
+    for (int e = 0; e < EPL; e += 4) {
+      const float4 sc = hs ? *(const float4*)(p.scale + c + e) : make_float4(1.f, 1.f, 1.f, 1.f);
+      const float4 bi = hb ? *(const float4*)(p.bias + c + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+      w[e] = epi_scale_bias(w[e], sc.x, bi.x, hs, hb); w[e + 1] = epi_scale_bias(w[e + 1], sc.y, bi.y, hs, hb);
+      w[e + 2] = epi_scale_bias(w[e + 2], sc.z, bi.z, hs, hb); w[e + 3] = epi_scale_bias(w[e + 3], sc.w, bi.w, hs, hb);
     }
     if (pb) {
 #pragma unroll
@@ -235,8 +235,9 @@ __device__ static inline void finish_store_row_pre(const ConvKP& p, size_t opos,
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int e = 4 * h;
-      w[e] *= sc[g][h].x; w[e + 1] *= sc[g][h].y; w[e + 2] *= sc[g][h].z; w[e + 3] *= sc[g][h].w;
-      w[e] += bi[g][h].x; w[e + 1] += bi[g][h].y; w[e + 2] += bi[g][h].z; w[e + 3] += bi[g][h].w;
+      const bool hs = p.scale != nullptr, hb = p.bias != nullptr;
+      w[e] = epi_scale_bias(w[e], sc[g][h].x, bi[g][h].x, hs, hb); w[e + 1] = epi_scale_bias(w[e + 1], sc[g][h].y, bi[g][h].y, hs, hb);
+      w[e + 2] = epi_scale_bias(w[e + 2], sc[g][h].z, bi[g][h].z, hs, hb); w[e + 3] = epi_scale_bias(w[e + 3], sc[g][h].w, bi[g][h].w, hs, hb);
     }
     if (p.add) {
       float a[EPL];

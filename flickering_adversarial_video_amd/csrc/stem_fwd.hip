@@ -337,8 +337,8 @@ __global__ __launch_bounds__(256, NI == 4 ? 3 : 2) void stem_fwd_u8_kernel(const
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = 4 * h;
-        v[e] = v[e] * sc[g][h].x + bi[g][h].x + t4[g][h].x; v[e + 1] = v[e + 1] * sc[g][h].y + bi[g][h].y + t4[g][h].y;
-        v[e + 2] = v[e + 2] * sc[g][h].z + bi[g][h].z + t4[g][h].z; v[e + 3] = v[e + 3] * sc[g][h].w + bi[g][h].w + t4[g][h].w;
+        v[e] = __fadd_rn(__fmaf_rn(v[e], sc[g][h].x, bi[g][h].x), t4[g][h].x); v[e + 1] = __fadd_rn(__fmaf_rn(v[e + 1], sc[g][h].y, bi[g][h].y), t4[g][h].y);
+        v[e + 2] = __fadd_rn(__fmaf_rn(v[e + 2], sc[g][h].z, bi[g][h].z), t4[g][h].z); v[e + 3] = __fadd_rn(__fmaf_rn(v[e + 3], sc[g][h].w, bi[g][h].w), t4[g][h].w);
       }
       bf16x8 o;
 #pragma unroll
