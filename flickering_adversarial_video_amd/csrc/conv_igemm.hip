@@ -801,12 +801,21 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvKP p)
   float v[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) v[e] = 0.f;
-  for (int k = 0; k < p.ksplit; ++k) {
-    const float* src = p.part + ((size_t)k * p.npos + opos) * p.part_ld + c0;
+  // slices four at a time: their loads are requested together, the sums stay in slice order (a run-time-bounded loop is load -> wait -> add)
+  for (int k0 = 0; k0 < p.ksplit; k0 += 4) {
+    float4 t[4][EPL / 4];
 #pragma unroll
-    for (int e = 0; e < EPL; e += 4) {
-      const float4 t = *(const float4*)(src + e);
-      v[e] += t.x; v[e + 1] += t.y; v[e + 2] += t.z; v[e + 3] += t.w;
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u < p.ksplit ? k0 + u : k0;             // (a slice past the end re-reads slice k0 and is not added)
+      const float* src = p.part + ((size_t)k * p.npos + opos) * p.part_ld + c0;
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) t[u][e / 4] = *(const float4*)(src + e);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (k0 + u >= p.ksplit) break;
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) { v[e] += t[u][e / 4].x; v[e + 1] += t[u][e / 4].y; v[e + 2] += t[u][e / 4].z; v[e + 3] += t[u][e / 4].w; }
     }
   }
   const float* pb = nullptr;
