@@ -293,8 +293,8 @@ def _self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (BASELINE: bs=8)")
     ap.add_argument("--frames", type=int, default=64, help="frames per clip (BASELINE: 64; reference default 90)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
