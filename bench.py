@@ -460,6 +460,7 @@ def main():
             pk = per_kind["pool"]
             out["pool_GBps"] = pk["bytes"] / (pk["ms"] * 1e-3) / 1e9
 
+    parity_failed = []
     if rank == 0 and world == 1:
         x_host = x.cpu()
         del eng, x
@@ -469,18 +470,24 @@ def main():
         if not a.no_parity:
             out["parity"] = parity_check(local_rank)
             if not out["parity"]["ok"]:
+                parity_failed.append("parity")
                 print(f"[bench] PARITY CHECK FAILED: {out['parity']}", file=sys.stderr)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cb = cpu_baseline(W, x_host, local_rank)
             out["gpu_over_cpu"] = out["value"] / cb.get(f"bs{B}", cb)["value"]
             bad = [k for k in (cb, cb.get(f"bs{B}", {})) for dt in ("f32", "bf16") if "parity_same_clip" in k and not k["parity_same_clip"][dt]["ok"]]
             if bad:
+                parity_failed.append("parity_same_clip")
                 print(f"[bench] SAME-CLIP PARITY FAILED: {[b['parity_same_clip'] for b in bad]}", file=sys.stderr)
 
     if rank == 0:
-        print(json.dumps(out))
+        # a throughput line from a numerically broken build must not read as a result: the line says so and the process fails
+        out["parity_ok"] = not parity_failed
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

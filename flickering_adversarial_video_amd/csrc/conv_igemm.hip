@@ -1172,6 +1172,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   // workgroups per CU.  Everything else shares the weights through the LDS ring (mode 0).
   int mode = 0;
   {
+    static const bool no_k1 = getenv("FLK_CONV_NO_K1") != nullptr;
     static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
     const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);      // (nf = 6 is never narrow)
     const bool k1 = kp.ntaps == 1 && kp.P <= 256;
@@ -1183,7 +1184,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     if (force_da == 1 && da_ok) da = true;
     if (w->stem4) mode = 4;
     else if (da) mode = k1 ? 2 : 1;
-    else if (k1 && kp.nslab >= 4 && !getenv("FLK_CONV_NO_K1")) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
+    else if (k1 && kp.nslab >= 4 && !no_k1) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
   }
   // 1x1x1 GEMMs over a flat position grid: both operands through the LDS-DMA ring (conv1x1_dma_kernel).  FLK_CONV_DMA=0: modes 2 / 3.
   {

@@ -1225,8 +1225,11 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
     const bool taken = arm[i] && !flk_stop_event;
     flk_stop_event = nullptr;
     if (rc) return rc;
-    if (arm[i] && !taken) FLK_CHECK_HIP(hipEventRecord(arm[i], st));      // (armed but the operator launched nothing: record the plain way)
     op.nlaunch = (int)(flk_launch_count - lc0);
+    // armed on the strength of the PREVIOUS run's launch count: if the operator launched nothing (event never taken) or more than one
+    // kernel this time (the event rode on its FIRST kernel), record it the plain way behind the last one -- the waits on it are
+    // enqueued later and see the re-record
+    if (arm[i] && (!taken || op.nlaunch != 1)) FLK_CHECK_HIP(hipEventRecord(arm[i], st));
     if (n->profile) { FLK_CHECK_HIP(hipEventRecord(ev[i].second, st)); tags[i] = flk_last_kernel_tag; }
   }
   ev_valid = n->profile;
@@ -1338,6 +1341,8 @@ extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const fl
 extern "C" int flk_net_prepare_backward_delta(flk_net* n, const flk_apply_args* a, float* scratch, void* stream) {
   FLK_REQUIRE(n && n->finalized && a && scratch, "flk_net_prepare_backward_delta: bad argument / not finalized");
   FLK_REQUIRE(n->d_stem_wf && n->stem_dgrad_op >= 0, "flk_net_prepare_backward_delta: only the I3D plan in bf16 has the fused stem delta-gradient");
+  FLK_REQUIRE(a->B == n->B && a->T == n->T && a->H == n->H && a->W == n->W, "flk_net_prepare_backward_delta: apply args (%d,%d,%d,%d) do not match "
+              "the net (%d,%d,%d,%d)", a->B, a->T, a->H, a->W, n->B, n->T, n->H, n->W);
   n->premask = false;
   static const bool off = getenv("FLK_PREMASK") && atoi(getenv("FLK_PREMASK")) == 0;
   if (off || !(n->multi_stream && n->mask_stream && !n->profile)) return FLK_OK;

@@ -12,6 +12,16 @@
 #include <string.h>
 #include "flk_internal.h"
 
+// Timing ablations (skip loads / atomics / stores: WRONG results) exist only in -DFLK_ABLATE builds (tools/*_time.py pass it through
+// FLK_HIPCC_EXTRA); in the product library the switches are compile-time zeros and the kernels carry no such branch.
+#ifdef FLK_ABLATE
+#define PF_DBG(bit) (p.dbg & (bit))
+#define PG_DBG(bit) (pg.dbg & (bit))
+#else
+#define PF_DBG(bit) (0)
+#define PG_DBG(bit) (0)
+#endif
+
 struct PoolKP {
   const char* in; char* out; uint8_t* idx;
   const char* gout; char* gin; const char* mask; const char* add;
@@ -523,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
       const int a = (int)(((float)hp + 0.5f) * inv_HW), rem = hp - a * HW, bq = rem / WH, c = rem - bq * WH;
       const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
       v[u] = make_uint4(0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u);     // -inf
-      if (hp < p.P && chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi && !(p.dbg & 1))
+      if (hp < p.P && chvalid && (unsigned)it < (unsigned)k.Ti && (unsigned)ih < (unsigned)k.Hi && (unsigned)iw < (unsigned)k.Wi && !PF_DBG(1))
         v[u] = *(const uint4*)(k.in + ((((size_t)(b * k.Ti + it) * k.Hi + ih) * k.Wi + iw) * k.in_ld + k.in_coff + c0) * 2);
     }
 #pragma unroll
@@ -569,14 +579,14 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
           }
         }
     };
-    if (p.dbg & 2) {
+    if PF_DBG(2) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) cm[0][e] = cm[1][e] = cm[2][e] = (unsigned)(tid + e) << 8;
     }
-    if (!(p.dbg & 2)) { colmax(0, cm[0]); colmax(1, cm[1]); }
+    if (!PF_DBG(2)) { colmax(0, cm[0]); colmax(1, cm[1]); }
 #pragma unroll
     for (int rw = 0; rw < WT; ++rw) {
-      if (!(p.dbg & 2)) colmax(rw + 2, cm[(rw + 2) % 3]);
+      if (!PF_DBG(2)) colmax(rw + 2, cm[(rw + 2) % 3]);
       const int ow = ow0 + rw;
       if (ow >= k.Wo) continue;
       const uint32_t (&l)[8] = cm[rw % 3];
@@ -602,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
       id.x = ix[0] | (ix[1] << 8) | (ix[2] << 16) | (ix[3] << 24);
       id.y = ix[4] | (ix[5] << 8) | (ix[6] << 16) | (ix[7] << 24);
       const size_t opos = (((size_t)(b * k.To + ot) * k.Ho + oh) * k.Wo + ow);
-      if (p.dbg & 4) { if (o.x == 0x12345u && id.x == 0x777u) *(uint2*)(k.idx + opos * k.C + c0) = id; continue; }
+      if PF_DBG(4) { if (o.x == 0x12345u && id.x == 0x777u) *(uint2*)(k.idx + opos * k.C + c0) = id; continue; }
       *(uint4*)(k.out + (opos * k.out_ld + k.out_coff + c0) * 2) = o;
       *(uint2*)(k.idx + opos * k.C + c0) = id;
     }
@@ -633,7 +643,9 @@ static int launch_wrun_fwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t
   const size_t lds = 4 * (size_t)tp.plane_b + 64;
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
   tp.interleave = pool_interleave();
+#ifdef FLK_ABLATE
   { const char* e = getenv("FLK_PF_DBG"); tp.dbg = e ? atoi(e) : 0; }
+#endif
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   static bool attr_set[FLK_MAX_DEVICES] = {};
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_wrun_fwd_bf16<WT>, 96 * 1024, attr_set)) return rc;
@@ -1015,7 +1027,7 @@ __global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd
   const int nt = max(0, o_t1 - o_t0 + 1), nh = max(0, o_h1 - o_h0 + 1), nw = max(0, o_w1 - o_w0 + 1);
   const int nhw = nh * nw, P = nt * nhw;                       // <= 64 * NIT (the host checks the tile)
   const float inv_hw = 1.0f / (float)max(nhw, 1), inv_w = 1.0f / (float)max(nw, 1);
-  if (!(pg.dbg & 16)) for (int i = tid; i < 32 * RS; i += 256) acc[i] = 0u;
+  if (!PG_DBG(16)) for (int i = tid; i < 32 * RS; i += 256) acc[i] = 0u;
   unsigned* const smax = acc + 32 * RS;
   if (tid == 0) *smax = 0u;
   unsigned* const lut = smax + 64;                             // byte offset of tap's cell relative to the window origin's cell
@@ -1059,10 +1071,10 @@ __global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd
         const unsigned et = (bt3 & 1u) | ((bt3 & 2u) << 8) | ((bt3 & 4u) << 16);         // spread by 9
         okm[i] = live ? bw3 * eh * et : 0u;
 #pragma unroll
-        for (int f = 0; f < 2; ++f) ib[i][f] = (pg.dbg & 8) ? (unsigned)(m * 0x01010101u) & 0x0f0f0f0fu : *(const unsigned*)(k.idx + opos * k.C + cslab * 32 + f * 16 + q * 4);
+        for (int f = 0; f < 2; ++f) ib[i][f] = PG_DBG(8) ? (unsigned)(m * 0x01010101u) & 0x0f0f0f0fu : *(const unsigned*)(k.idx + opos * k.C + cslab * 32 + f * 16 + q * 4);
         const char* gp = pg.g + (opos * pg.g_ld + pg.g_coff + q * 8) * 2;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bf[u][ks] = (pg.dbg & 4) ? af[ks][0] : *(const frag8*)(gp + ks * 64);
+        for (int ks = 0; ks < KS; ++ks) bf[u][ks] = PG_DBG(4) ? af[ks][0] : *(const frag8*)(gp + ks * 64);
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
@@ -1094,7 +1106,7 @@ __global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd
     // dummy word of its own thread instead of being skipped.  (Written as  if (inside) atomicAdd(.. + lut[tap] ..)  hipcc emitted, per
     // element, exec-mask branch -> ds_read_b32 -> s_waitcnt lgkmcnt(0) -> ds_add_u32: 64 exposed LDS round trips per lane.)
     unsigned* const dummy = lut + 256 + tid;
-    if (!(pg.dbg & 1)) {
+    if (!PG_DBG(1)) {
 #pragma unroll
       for (int i = 0; i < NIT; ++i) {
         char* const plane0 = (char*)acc + (size_t)(q * 4 * RS) * 4 + org[i];
@@ -1119,7 +1131,7 @@ __global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd
   __syncthreads();
   // ---- write the tile: thread = (cell, 16-byte channel chunk) ----
   const int ch = tid & 3, c0 = cslab * 32 + ch * 8;
-  if (c0 >= k.C || (pg.dbg & 2)) return;
+  if (c0 >= k.C || PG_DBG(2)) return;
   const int hw = p.Ht * p.Wt;
   for (int r = tid >> 2; r < p.rows; r += 64) {
     int rt, rh, rw; split3(r, hw, 1.0f / (float)hw, p.Wt, 1.0f / (float)p.Wt, rt, rh, rw);
@@ -1196,8 +1208,9 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
   static bool attr_fwd[FLK_MAX_DEVICES] = {}, attr_bwd[FLK_MAX_DEVICES] = {};
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_fwd<T>, 96 * 1024, attr_fwd)) return rc;
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_bwd<T>, 96 * 1024, attr_bwd)) return rc;
+  static const bool no_wrun = getenv("FLK_POOL_NO_WRUN") != nullptr;
   if (bwd) FLK_LAUNCH_KERNEL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
-  else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3 && a->pt == 1 && a->ph == 1 && a->pw == 1 && !getenv("FLK_POOL_NO_WRUN")) {
+  else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3 && a->pt == 1 && a->ph == 1 && a->pw == 1 && !no_wrun) {
     return a->Wo % 7 == 0 ? launch_wrun_fwd<7>(kp, a, s) : launch_wrun_fwd<8>(kp, a, s);
   } else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
     static bool attr2[FLK_MAX_DEVICES] = {};
@@ -1355,7 +1368,9 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   fill(pg.t.k, a);
   pg.t.k.gin = (char*)gin; pg.t.k.gin_ld = gin_ld; pg.t.k.gin_coff = gin_coff;
   pg.g = (const char*)g; pg.g_ld = g_ld; pg.g_coff = g_coff; pg.KS = K / 32; pg.wpack = (const char*)wpack;
+#ifdef FLK_ABLATE
   { const char* e = getenv("FLK_PG_DBG"); pg.dbg = e ? atoi(e) : 0; }
+#endif
   const flk_tile t = choose_scatter_tile(a);
   PoolTP& tp = pg.t;
   tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
@@ -1366,8 +1381,8 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
   { // accumulator plane stride in words: 4 (mod 64) -- the four lane groups q of an atomic (planes 4 q + j) start 16 banks apart
     // (16 (mod 64), the stride of maxpool_scatter_bwd, puts all four on the same banks); FLK_POOL_PLANE_MOD overrides the residue
-    const char* e = getenv("FLK_POOL_PLANE_MOD");
-    const int res = e ? atoi(e) & 63 : 4;
+    static const char* const e = getenv("FLK_POOL_PLANE_MOD");
+    static const int res = e ? atoi(e) & 63 : 4;
     tp.plane_b = (tp.rows - res + 63) / 64 * 64 + res;
   }
   const size_t lds = (size_t)(32 * tp.plane_b + 64) * sizeof(float);

@@ -392,23 +392,23 @@ extern "C" int flk_stem_fwd_u8(const flk_apply_args* a, const flk_conv_weights* 
   kp.scale = bn_scale; kp.bias = bn_bias; kp.pos_bias = pos_bias; kp.pos_bias_bstride = (long)pos_bias_bstride;
   kp.out = (char*)out; kp.out_ld = out_ld;
   kp.To = a->T / 2; kp.nTt = (kp.To + SF_TT - 1) / SF_TT;
-  static const int ni = getenv("FLK_STEM_NI") ? atoi(getenv("FLK_STEM_NI")) : 4;
+#ifdef SF_ABLATE
   kp.ablate = getenv("FLK_SF_ABLATE") ? atoi(getenv("FLK_SF_ABLATE")) : 0;
   kp.stagger = getenv("FLK_SF_STAGGER") ? atoi(getenv("FLK_SF_STAGGER")) : 0;
+#endif
   hipStream_t st = (hipStream_t)stream;
-  if (ni == 4) {
-    kp.ntiles = a->B * kp.nTt * SfGeo<4>::NTH * 14;
-    kp.chunk = (kp.ntiles + 7) / 8;
-    static bool attr_set[FLK_MAX_DEVICES] = {};
-    if (int rc = flk_raise_lds_limit((const void*)stem_fwd_u8_kernel<4>, SfGeo<4>::LDS, attr_set)) return rc;
-    FLK_LAUNCH_KERNEL(stem_fwd_u8_kernel<4>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<4>::LDS, st, kp);
-  } else {
-    kp.ntiles = a->B * kp.nTt * SfGeo<8>::NTH * 14;
-    kp.chunk = (kp.ntiles + 7) / 8;
-    static bool attr_set[FLK_MAX_DEVICES] = {};
-    if (int rc = flk_raise_lds_limit((const void*)stem_fwd_u8_kernel<8>, SfGeo<8>::LDS, attr_set)) return rc;
-    FLK_LAUNCH_KERNEL(stem_fwd_u8_kernel<8>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<8>::LDS, st, kp);
-  }
+  // (NI = 8 -- 128 positions per wave, 32 MFMAs per 12 fragment reads, two workgroups per CU -- measured 0.273 vs 0.258 ms: only in
+  //  -DFLK_STEM_NI8 timing builds)
+#ifdef FLK_STEM_NI8
+  constexpr int NI = 8;
+#else
+  constexpr int NI = 4;
+#endif
+  kp.ntiles = a->B * kp.nTt * SfGeo<NI>::NTH * 14;
+  kp.chunk = (kp.ntiles + 7) / 8;
+  static bool attr_set[FLK_MAX_DEVICES] = {};
+  if (int rc = flk_raise_lds_limit((const void*)stem_fwd_u8_kernel<NI>, SfGeo<NI>::LDS, attr_set)) return rc;
+  FLK_LAUNCH_KERNEL(stem_fwd_u8_kernel<NI>, dim3((unsigned)(kp.chunk * 8)), dim3(256), SfGeo<NI>::LDS, st, kp);
   FLK_CHECK_HIP(hipGetLastError());
   flk_last_kernel_tag = "stem_fwd_u8_kernel";
   return FLK_OK;

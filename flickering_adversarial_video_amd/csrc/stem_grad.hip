@@ -42,6 +42,13 @@
 #include <stdlib.h>
 #include "flk_internal.h"
 
+// timing ablations (WRONG results) only in -DFLK_ABLATE builds; compile-time zero in the product library
+#ifdef FLK_ABLATE
+#define SG_DBG(bit) (p.dbg & (bit))
+#else
+#define SG_DBG(bit) (0)
+#endif
+
 namespace {
 
 constexpr int SG_THREADS = 512;
@@ -287,9 +294,9 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
         const int st = SG_SPB_ * (d + SG_LA_) + j;
         if (st < nsteps) {
           const int hm = hmax_of(st);
-          if (hm > h_req && !(p.dbg & 1)) mine += mask_issue(h_req + 1, hm);
+          if (hm > h_req && !SG_DBG(1)) mine += mask_issue(h_req + 1, hm);
           if (hm > h_req) h_req = hm;
-          if (!(p.dbg & 4)) { g_issue(st, st % SG_GBUFS); mine += 16; }      // that buffer was last read in interval d - 1
+          if (!SG_DBG(4)) { g_issue(st, st % SG_GBUFS); mine += 16; }      // that buffer was last read in interval d - 1
         }
       }
       const int allow = SG_LA_ >= 3 ? mine + prev : mine;
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
 #pragma unroll
       for (int f = 0; f < SG_NF; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < nsteps; ++s) {
-      if (!(p.dbg & 2)) {
+      if (!SG_DBG(2)) {
         const char* const gb = gbuf + (s % SG_GBUFS) * SG_GTILE;
         bf16x8 af[4];
 #pragma unroll
@@ -496,7 +503,9 @@ extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g
   kp.To = a->T / 2; kp.Ho = a->H / 2; kp.Wo = a->W / 2;
   kp.mask = (const char*)scratch + sg_partial_bytes(a->B, a->T, a->H);
   FLK_REQUIRE((size_t)a->B * kp.To * kp.Ho * kp.Wo * g_ld < (1ull << 31), "flk_stem_delta_grad: tensor too large");
+#ifdef FLK_ABLATE
   { static const char* e = getenv("FLK_SG_DBG"); kp.dbg = e ? atoi(e) : 0; }
+#endif
   kp.nchunk = sg_nchunk(a->delta_per_clip ? 1 : a->B, a->T, kp.Ho);      // per-clip perturbations: the chunking of a batch-1 call
   { static const char* e = getenv("FLK_SG_NCHUNK"); if (e && atoi(e) > 0) kp.nchunk = atoi(e) < 16 ? atoi(e) : 16; }
   kp.rows_per_chunk = (kp.Ho + kp.nchunk - 1) / kp.nchunk;

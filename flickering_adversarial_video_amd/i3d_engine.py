@@ -261,6 +261,9 @@ class FlickerI3D:
         self._it += 1
         red, sm, pc = slot["payload"], slot["sm"], slot["pc"]
         self._red = red
+        # (labels are validated BEFORE the mask pre-pass starts: a raise between prepare_backward_delta and backward_delta would leave
+        #  the pre-pass running on the net's mask stream, unjoined, while torch frees or reuses the clip and the scratch buffer)
+        ops.check_labels(labels, self.B, self.net.num_classes)
         if self.fused_delta_grad:
             self.net.prepare_backward_delta(a, self._scratch)      # the clip mask of this iteration's backward pass: beside the stem
         self._forward(a)
@@ -299,6 +302,7 @@ class FlickerI3D:
         slot = self._slots[self._it % RESULT_SLOTS]
         self._it += 1
         sm, pc, g = slot["sm"], slot["pc"], slot["gclip"]
+        ops.check_labels(labels, self.B, self.net.num_classes)
         if self.fused_delta_grad:
             self.net.prepare_backward_delta(a, self._scratch)
         self._forward(a)

@@ -467,7 +467,8 @@ class Net:
 
     def forward_apply(self, apply_args, x_s2d, logits=None):
         """perturbation apply + forward in one call: the plan applies each batch slice on the stream its stem convolution runs on
-        (x_s2d receives the space-to-depth clip, as perturb_apply_s2d would have written it)"""
+        (x_s2d is scratch: it receives the space-to-depth clip unless the stem reads the uint8 clip itself -- the bf16 I3D plan with a
+        centred uint8 clip -- in which case it is left untouched; call perturb_apply_s2d when the tensor itself is needed)"""
         if logits is None:
             logits = torch.empty((self.B, self.num_classes), dtype=torch.float32, device=x_s2d.device)
         assert x_s2d.is_contiguous() and x_s2d.numel() == self.input_numel and dtype_code(x_s2d.dtype) == self.dtype

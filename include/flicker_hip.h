@@ -318,7 +318,9 @@ int flk_net_forward_flicker(flk_net* n, const void* x_in, const flk_apply_args* 
 /* apply + forward in one call: the plan launches flk_perturb_apply_s2d itself, per batch slice on the stream that slice's stem
  * convolution runs on (I3D at bs >= 4: the two half-batches -- the second half's apply overlaps the first half's stem), writing the
  * space-to-depth clip into x_s2d_out; with a->center = 1 (flk_net_has_forward_flicker) the position-class bias path is taken.
- * a->fold_t must be the plan's layout (3 for I3D, 1 for VideoResNet).  Same results as apply followed by flk_net_forward[_flicker]. */
+ * a->fold_t must be the plan's layout (3 for I3D, 1 for VideoResNet).  Same logits as apply followed by flk_net_forward[_flicker].
+ * x_s2d_out is SCRATCH: when the stem reads the uint8 clip itself (I3D plan in bf16, a->x_is_u8 with a->center = 1 -- the default
+ * engine path) it is left untouched, so a caller that needs the space-to-depth tensor calls flk_perturb_apply_s2d itself. */
 int flk_net_forward_apply(flk_net* n, const flk_apply_args* a, void* x_s2d_out, float* logits, void* stream);
 /* dlogits fp32 [B,C] -> gradient w.r.t. the network input (same layout/dtype as x_in) */
 int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream);

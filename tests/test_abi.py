@@ -55,3 +55,12 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.FlickerHipError):
         _lib.load()
+
+
+def test_product_library_has_no_timing_ablation_switches():
+    """The wrong-result timing ablations (skip loads / atomics / MFMAs) exist in -DFLK_ABLATE / -DSF_ABLATE / -DFLK_STEM_NI8 builds only
+    (tools/*_time.py): the shipped library must not even contain the names of their environment switches."""
+    from flickering_adversarial_video_amd import build
+    blob = open(build.build(verbose=False), "rb").read()
+    for name in (b"FLK_PF_DBG", b"FLK_PG_DBG", b"FLK_SG_DBG", b"FLK_SF_ABLATE", b"FLK_SF_STAGGER", b"FLK_STEM_NI"):
+        assert name not in blob, name

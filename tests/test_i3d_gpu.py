@@ -789,3 +789,32 @@ def test_forward_apply_equals_apply_then_forward(dtype, batch, monkeypatch):
         x2 = torch.zeros_like(x1)
         l2 = net.forward_apply(a, x2)
         assert torch.equal(x1, x2) and torch.equal(l1, l2), shape
+
+
+def test_operator_launch_count_may_change_between_runs():
+    """The plan arms fork / join stop events on operators that launched ONE kernel in the previous run (net.cpp run_ops).  The stem
+    operator varies: flk_net_forward launches the convolution only, flk_net_forward_apply (fp32: apply + convolution) two kernels.
+    Alternating the two entry points -- the armed operator launches more kernels than the run before -- must give the bits of a
+    fresh plan that only ever ran one of them (an event riding on the FIRST of two kernels would let the waiting stream start early)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec, ops
+    from flickering_adversarial_video_amd._lib import FLK_NET_I3D
+    B = 4                                                 # the stem segment runs per half-batch on two streams
+    W = i3d_spec.synthetic_i3d_weights(42)
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(B, T, seed=9)).cuda()
+    d = torch.from_numpy(np.random.default_rng(3).uniform(-0.2, 0.2, (T, 3)).astype(np.float32)).cuda()
+
+    def run(seq):
+        net = ops.Net(FLK_NET_I3D, "f32", B, T, 224, 224, W)
+        a = ops.make_apply_args(xu, d, fold_t=ops.I3D_FOLD, center=False)
+        x = ops.perturb_apply_s2d(a, "f32", torch.empty((B, T // 2, 112, 112, 32), dtype=torch.float32, device="cuda"))
+        outs = []
+        for kind in seq:
+            outs.append((net.forward(x) if kind == "fwd" else net.forward_apply(a, torch.empty_like(x))).clone())
+        torch.cuda.synchronize()
+        return outs
+
+    ref = run(["fwd"])[0]
+    for got in run(["fwd", "apply", "fwd", "apply", "apply", "fwd"]):
+        assert torch.equal(got, ref)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Isolated timing of the stride-1 3x3x3 max-pool forward (csrc/pool.hip: the W-run kernel of the Inception Branch_3 pools) at the geometry
 of an I3D block of the benchmark (default Mixed_3c: 8 x 32 x 28 x 28 positions, 256 channels), with the debug knob FLK_PF_DBG of the
-library (set it in the environment): A/B work on the kernel's phases."""
+library (set it in the environment; timing builds only: FLK_HIPCC_EXTRA=-DFLK_ABLATE python -m flickering_adversarial_video_amd.build
+--force -- the product build has no such switch): A/B work on the kernel's phases."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Isolated timing of the fused Branch_3 backward (csrc/pool.hip: flk_maxpool3d_bwd_gemm) at the geometry of an I3D block of the benchmark
 (default Mixed_3c: 8 x 32 x 28 x 28 positions, 256 pooled channels, K = 64), with the debug knobs FLK_PG_DBG / FLK_POOL_GEMM_REG of the
-library (set them in the environment): A/B work on the kernel's phases."""
+library (set them in the environment): A/B work on the kernel's phases.  FLK_PG_DBG needs a timing build of the library
+(FLK_HIPCC_EXTRA=-DFLK_ABLATE python -m flickering_adversarial_video_amd.build --force): the product build has no such switch."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time flk_stem_fwd_u8 alone (HIP events; bs clips of 64x224x224).  FLK_STEM_NI / FLK_SF_ABLATE (timing-only -DSF_ABLATE builds)
-select the variant; the output of an ablated run is garbage and goes nowhere."""
+"""Time flk_stem_fwd_u8 alone (HIP events; bs clips of 64x224x224).  FLK_SF_ABLATE (timing-only -DSF_ABLATE builds) selects the
+ablation, a -DFLK_STEM_NI8 build the 128-positions-per-wave instance; the output of an ablated run is garbage and goes nowhere."""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Isolated timing of the fused stem delta-gradient kernel (csrc/stem_grad.hip) at the benchmark shape, with the debug knobs
-FLK_SG_DBG / FLK_SG_NCHUNK of the library (set them in the environment): A/B work on the kernel's phases."""
+FLK_SG_DBG / FLK_SG_NCHUNK of the library (set them in the environment): A/B work on the kernel's phases.  FLK_SG_DBG needs a timing
+build (FLK_HIPCC_EXTRA=-DFLK_ABLATE python -m flickering_adversarial_video_amd.build --force): the product build has no such switch."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
