@@ -50,6 +50,7 @@ struct ConvKP {
   // deterministic split-K (blockIdx.y = slice of the input-channel slabs): raw fp32 partial sums [ksplit][positions][part_ld],
   // summed in slice order and finished by conv_splitk_finish_kernel
   float* part; int ksplit, part_ld; unsigned npos;
+  int wn;            // grouped launches (conv_igemm_group_kernel): waves along N of THIS member (1 / 2 / 4), a run-time value there
 };
 
 template <typename T> struct Prec;
@@ -269,9 +270,15 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // ("direct A").  MODE 2: direct A for a 1x1x1 convolution (activation slabs prefetched in depth as well).  MODE 3: LDS ring
 // for a 1x1x1 convolution with wide wave tiles, activations and weights prefetched in depth with hand-counted waits.
 // MODE 4: the folded 7x7x7 stem (4x4x4 taps over ONE 32-channel slab): K steps built from the non-zero 16-byte chunks only.
+// The kernel body: block (bx, by) of the launch described by p.  WN = 0 is the GROUPED form (conv_igemm_group_kernel: several
+// convolutions in one grid): NF then counts the channel fragments of ONE WAVE, the waves-along-N count is the member's run-time p.wn
+// and the workgroup tile is 16 * NF * p.wn channels wide -- direct-A weights (MODE 1) only, where the tile width appears in two
+// address computations and nowhere in the loop structure.
 template <typename T, int NF, int WN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
+__device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, const int by) {
   constexpr bool K1 = MODE == 2 || MODE == 3;
+  constexpr bool RTWN = WN == 0;
+  static_assert(!RTWN || MODE == 1, "run-time wave layouts: direct-A weights only");
   typedef Prec<T> PR;
   typedef typename PR::frag frag;
   constexpr int EPL = PR::EPL;
@@ -281,8 +288,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   // (a valid address) and do not store it
   const bool w2ok = NF % 4 == 0 || threadIdx.x + 256 < NF * 64;
   const int w2off = w2ok ? 4096 : 0;
-  constexpr int WM = 4 / WN, NFW = NF / WN;   // waves along M; channel fragments per wave
-  static_assert(NF % WN == 0 && 4 * NFW >= EPL, "wave tile too narrow for 16-byte epilogue groups");
+  constexpr int NFW = RTWN ? NF : NF / (RTWN ? 1 : WN);   // channel fragments per wave
+  const int WNr = RTWN ? p.wn : WN;                       // waves along N
+  const int WM = 4 / WNr;                                 // waves along M
+  const int NFT = NFW * WNr;                              // channel fragments of the workgroup tile (= NF unless grouped)
+  static_assert(RTWN || (NF % (RTWN ? 1 : WN) == 0), "channel tile does not divide over the waves");
+  static_assert(4 * NFW >= EPL, "wave tile too narrow for 16-byte epilogue groups");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // small halos (P <= 256: all 1x1x1 convolutions) keep TWO halo images so the K loop needs one barrier per slab
   const bool small_halo = p.P <= 256;
@@ -300,12 +311,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   if (p.xcd_chunk > 0) {
     // chunked form: XCD x (= id % 8 under round-robin dispatch) works through the position tiles [x * chunk, (x + 1) * chunk) in order,
     // all N tiles of a position tile back to back -- neighbouring tiles, whose halos overlap, meet in ONE L2 instead of eight
-    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    const int id = bx, xcd = id & 7, slot = id >> 3;
     const int k = slot / p.ntile_n;
     ntile = slot - k * p.ntile_n;
     bid = xcd * p.xcd_chunk + k;
   } else {
-    const int per = 8 * p.ntile_n, id = blockIdx.x;
+    const int per = 8 * p.ntile_n, id = bx;
     const int grp = id / per, r = id - grp * per;
     ntile = r >> 3;
     bid = grp * 8 + (r & 7);
@@ -376,9 +387,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     return v;
   };
   // slab s -> (segment base pointer incl. channel offset, ld, chunk validity)
-  // split-K: this workgroup reduces the slabs [s_lo, s_lo + nslab) only (blockIdx.y = slice; one slice = everything)
-  const int s_lo = (int)blockIdx.y * p.nslab / p.ksplit;
-  const int nslab = ((int)blockIdx.y + 1) * p.nslab / p.ksplit - s_lo;
+  // split-K: this workgroup reduces the slabs [s_lo, s_lo + nslab) only (block y = slice; one slice = everything)
+  const int s_lo = by * p.nslab / p.ksplit;
+  const int nslab = (by + 1) * p.nslab / p.ksplit - s_lo;
   auto slab_src = [&](int s, const char*& src, int& ld) -> bool {
     s += s_lo;
     if (s < p.nslab1) {
@@ -640,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
     constexpr int D = (NFW <= 2 && !K1) ? 8 : 4;   // K1 also keeps D activation slabs (16 VGPRs each) in flight
 #endif
     // fragment f of this wave at step k = w + (k*cout_frags + ntile*NF + wn*NFW + f) KiB + lane*16
-    const char* const wfirst = wbase + (size_t)ntile * NF * 1024 + (wn * NFW * 64 + lane) * 16;
+    const char* const wfirst = wbase + (size_t)ntile * NFT * 1024 + (wn * NFW * 64 + lane) * 16;
     const char* const wlast = wfirst + (size_t)(nsteps - 1) * wstep;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: inline asm takes it in registers
     u32x4 wq[D][NFW];
@@ -758,7 +769,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
   if (!wave_active) return;
   // store group g of this wave = global group wn*NG + g: channels ntile*16NF + (wn*NG + g)*4*EPL + q*EPL + [0, EPL)
   constexpr int NG = 4 * NFW / EPL;   // 16-byte channel groups per lane
-  const int cbase = ntile * 16 * NF + wn * NG * 4 * EPL + q * EPL;
+  const int cbase = ntile * 16 * NFT + wn * NG * 4 * EPL + q * EPL;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = wm * 64 + i * 16 + m;
@@ -778,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
 #pragma unroll
       for (int e = 0; e < EPL; ++e) v[e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
       if (p.ksplit > 1) {                                // raw partial sums of this slice; conv_splitk_finish_kernel does the rest
-        float* dst = p.part + ((size_t)blockIdx.y * p.npos + opos) * p.part_ld + c0;
+        float* dst = p.part + ((size_t)by * p.npos + opos) * p.part_ld + c0;
 #pragma unroll
         for (int e = 0; e < EPL; e += 4) *(float4*)(dst + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
         continue;
@@ -786,6 +797,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
       finish_store<T>(p, opos, pb, c0, v);
     }
   }
+}
+
+template <typename T, int NF, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvKP p) {
+  conv_igemm_body<T, NF, WN, MODE>(p, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// Several convolutions in ONE grid (an Inception block's Branch_1 and Branch_2 3x3x3 units, i3d.py:201-209, forward or data-gradient):
+// blocks [start[i], start[i + 1]) work on member i exactly as a launch of their own would (same tiles, same K order per output: bitwise the
+// results of separate launches).  The members share the template instance -- NFW channel fragments per wave, direct-A weights -- and
+// differ in everything ConvKP holds, the wave layout included (p.wn).  One launch instead of two on two streams: no fork for the small
+// member, whose latency-bound workgroups (a 27-step K loop for Branch_2) fill the tail of the large one instead of running beside it.
+constexpr int FLK_MAX_GROUP = 3;
+struct ConvGroupKP {
+  ConvKP m[FLK_MAX_GROUP];
+  int start[FLK_MAX_GROUP + 1];      // first block of member i; members past the last hold INT_MAX
+};
+template <typename T, int NFW>
+__global__ __launch_bounds__(256, 2) void conv_igemm_group_kernel(const ConvGroupKP g) {
+  const int bx = (int)blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < FLK_MAX_GROUP; ++k) i += bx >= g.start[k];
+  conv_igemm_body<T, NFW, 0, 1>(g.m[i], bx - g.start[i], 0);
 }
 
 // second launch of a split-K convolution: sum the slices in slice order (fixed: bitwise reproducible), then the epilogue.
@@ -1046,8 +1081,13 @@ extern "C" int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_
   return ks > 1 ? (int64_t)ks * a->B * a->OT * a->OH * a->OW * a->cout * (int64_t)sizeof(float) : 0;
 }
 
+// what conv3d_impl decided for a launch (plan-only calls: the members of a grouped launch)
+struct ConvPlan { ConvKP kp; dim3 grid; size_t lds; int nf, wn, mode; };
+
 // force_wn: 0 = heuristic, else 1 / 2 / 4.  force_da: -1 = heuristic, 0 = LDS weight ring, 1 = direct A.  force_ks: 0 = heuristic.
-static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream, int force_wn, int force_da, int force_ks = 0) {
+// plan != nullptr: validate and plan only -- nothing is launched, the decisions land in *plan (no split-K, no LDS-DMA GEMM route).
+static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream, int force_wn, int force_da, int force_ks = 0,
+                       ConvPlan* plan = nullptr) {
   FLK_REQUIRE(a && w && w->dev, "flk_conv3d: null argument");
   FLK_REQUIRE(dtype == w->dtype, "flk_conv3d: dtype %d != packed weight dtype %d", dtype, w->dtype);
   FLK_REQUIRE(a->kt == w->kt && a->kh == w->kh && a->kw == w->kw && a->cin == w->cin && a->cout == w->cout,
@@ -1094,7 +1134,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   int wn = 1;
   // split-K decision first: a split launch keeps 256-row tiles (wn = 1) and gets its parallelism from the K slices
   int ksplit = 1;
-  if (a->splitk_ws && splitk_eligible(a, w)) {
+  if (a->splitk_ws && splitk_eligible(a, w) && !plan) {
     static const char* force = getenv("FLK_CONV_KSPLIT");
     ksplit = force ? atoi(force) : force_ks > 0 ? force_ks : plan_ksplit(a, w);
     ksplit = ksplit > w->nslab ? w->nslab : ksplit > FLK_MAX_KSPLIT ? FLK_MAX_KSPLIT : ksplit < 1 ? 1 : ksplit;
@@ -1193,7 +1233,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
                       a->oot == 0 && a->ooh == 0 && a->oow == 0 && a->To == a->Ti && a->Ho == a->Hi && a->Wo == a->Wi && a->OT == a->To &&
                       a->OH == a->Ho && a->OW == a->Wo;
     const long npos = (long)a->B * a->To * a->Ho * a->Wo;
-    if (dma_on && dtype == FLK_BF16 && kp.ntaps == 1 && flat && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
+    if (!plan && dma_on && dtype == FLK_BF16 && kp.ntaps == 1 && flat && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
         (nf == 8 || nf == 6 || nf == 4) && kp.nslab >= 2 && npos >= (dma_on >= 2 ? 1 : 2048) && npos < (1l << 23)) {
       kp.npos = (unsigned)npos;
       const long pt = (npos + 255) / 256;
@@ -1224,6 +1264,11 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
               a->kt, a->kh, a->kw, a->st, a->sh, a->sw, a->cin, a->cout, a->B, a->To, a->Ho, a->Wo, nf, wn, kp.Tt, kp.Ht, kp.Wt,
               kp.rows, kp.P, ptiles * ntile_n, mode, lds);
     if (dbg && kp.ksplit > 1) fprintf(stderr, "   split-K x%d (%d slabs)\n", kp.ksplit, kp.nslab);
+  }
+  if (plan) {
+    kp.wn = wn;
+    plan->kp = kp; plan->grid = grid; plan->lds = lds; plan->nf = nf; plan->wn = wn; plan->mode = mode;
+    return FLK_OK;
   }
   if (kp.ksplit > 1) {
     const int rc = launch_any(kp, grid, lds, s, dtype, nf, wn, mode);
@@ -1261,6 +1306,65 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
 #undef FLK_LAUNCHD
   flk_set_error("flk_conv3d: unsupported dtype %d / nf %d / wn %d / mode %d", dtype, nf, wn, mode);
   return FLK_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped launch: n <= 3 convolutions (bf16, more than one tap, no split-K) in one grid of conv_igemm_group_kernel<NFW>.  Every member
+// is planned as a launch of its own would be, with direct-A weights and wn = (its weights' nf) / nfw waves along N, so member i's blocks
+// compute exactly what flk_conv3d would have with that layout.  Members in the order given: put the longest K loops first.
+extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int dtype, void* stream) {
+  FLK_REQUIRE(a && w && n >= 1 && n <= FLK_MAX_GROUP, "flk_conv3d_group: 1..%d members", FLK_MAX_GROUP);
+  FLK_REQUIRE(dtype == FLK_BF16 && (nfw == 2 || nfw == 4), "flk_conv3d_group: bf16 with 2 or 4 channel fragments per wave");
+  ConvGroupKP g{};
+  size_t lds = 0;
+  long total = 0;
+  for (int i = 0; i <= FLK_MAX_GROUP; ++i) g.start[i] = 0x7fffffff;
+  for (int i = 0; i < n; ++i) {
+    FLK_REQUIRE(a[i] && w[i] && w[i]->dev, "flk_conv3d_group: null member %d", i);
+    FLK_REQUIRE(w[i]->nf % nfw == 0 && (w[i]->nf / nfw == 1 || w[i]->nf / nfw == 2 || w[i]->nf / nfw == 4),
+                "flk_conv3d_group: member %d packed with nf %d, not 1 / 2 / 4 waves of %d fragments", i, w[i]->nf, nfw);
+    FLK_REQUIRE(w[i]->ntaps > 1 && !w[i]->stem4 && !a[i]->pos_bias, "flk_conv3d_group: member %d is not a multi-tap convolution", i);
+    ConvPlan pl{};
+    if (int rc = conv3d_impl(a[i], w[i], dtype, stream, w[i]->nf / nfw, 1, 0, &pl)) return rc;
+    FLK_REQUIRE(pl.mode == 1 && pl.wn * nfw == pl.nf && pl.kp.ksplit == 1 && pl.grid.y == 1, "flk_conv3d_group: member %d planned as mode %d, wn %d",
+                i, pl.mode, pl.wn);
+    g.m[i] = pl.kp;
+    g.start[i] = (int)total;
+    total += pl.grid.x;
+    lds = pl.lds > lds ? pl.lds : lds;
+    if (dbg_on())
+      fprintf(stderr, "group member %d: conv %dx%dx%d cin %d cout %d out %dx%dx%dx%d | nfw %d wn %d tile %dx%dx%d rows %d halo %d wgs %u lds %zu\n", i,
+              a[i]->kt, a[i]->kh, a[i]->kw, a[i]->cin, a[i]->cout, a[i]->B, a[i]->To, a[i]->Ho, a[i]->Wo, nfw, pl.wn, pl.kp.Tt, pl.kp.Ht, pl.kp.Wt,
+              pl.kp.rows, pl.kp.P, pl.grid.x, pl.lds);
+  }
+  FLK_REQUIRE(total < (1l << 31), "flk_conv3d_group: grid too large");
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr2[FLK_MAX_DEVICES] = {}, attr4[FLK_MAX_DEVICES] = {};
+  if (nfw == 2) {
+    if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, 2>, 96 * 1024, attr2)) return rc;
+    FLK_LAUNCH_KERNEL((conv_igemm_group_kernel<bf16_t, 2>), dim3((unsigned)total), dim3(256), lds, s, g);
+  } else {
+    if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, 4>, 96 * 1024, attr4)) return rc;
+    FLK_LAUNCH_KERNEL((conv_igemm_group_kernel<bf16_t, 4>), dim3((unsigned)total), dim3(256), lds, s, g);
+  }
+  flk_last_kernel_tag = "conv_igemm_group_kernel";
+  FLK_CHECK_HIP(hipGetLastError());
+  return FLK_OK;
+}
+
+// the (waves along N, weight path) flk_conv3d's heuristics pick for this geometry with weights packed at `nf` (plan builders decide how to
+// pack a grouped launch's members before any weights exist)
+extern "C" int flk_conv_layout_query(const flk_conv_args* a, int nf, int dtype, int force_da, int* wn_out, int* mode_out) {
+  FLK_REQUIRE(a && wn_out && mode_out && nf > 0, "flk_conv_layout_query: bad argument");
+  flk_conv_weights w{};
+  w.dev = (void*)1; w.kt = a->kt; w.kh = a->kh; w.kw = a->kw; w.cin = a->cin; w.cout = a->cout; w.dtype = dtype; w.nf = nf;
+  const int epl = dtype == FLK_BF16 ? 8 : 4;
+  w.nslab = (a->cin + 4 * epl - 1) / (4 * epl); w.ntaps = a->kt * a->kh * a->kw;
+  w.cout_frags = ((a->cout + 15) / 16 + nf - 1) / nf * nf; w.nslab1 = w.nslab;
+  ConvPlan pl{};
+  if (int rc = conv3d_impl(a, &w, dtype, nullptr, 0, force_da, 0, &pl)) return rc;
+  *wn_out = pl.wn; *mode_out = pl.mode;
+  return FLK_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

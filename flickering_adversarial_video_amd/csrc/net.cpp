@@ -241,13 +241,14 @@ struct flk_net {
     return (dtype == FLK_BF16 && taps == 1 && nf == 2) ? 4 : nf;
   }
   static int small_nf() { static const int v = getenv("FLK_SMALL_NF") ? atoi(getenv("FLK_SMALL_NF")) : 4; return v == 4 || v == 8 ? (v == 8 ? 0 : 4) : 0; }
-  int pack(ConvLayer* L, long rows = 0) {
+  // (nf_f / nf_b > 0: the channel-tile width of the forward / data-gradient operator is given -- members of a grouped launch)
+  int pack(ConvLayer* L, long rows = 0, int nf_f = 0, int nf_b = 0) {
     const int taps = L->kt * L->kh * L->kw;
     int rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, nullptr, 0, dtype,
-                                          nf_for(L->cout, taps, rows), 0, &L->wf);
+                                          nf_f > 0 ? nf_f : nf_for(L->cout, taps, rows), 0, &L->wf);
     if (rc) return rc;
     rc = flk_conv_weights_create_impl(L->w.data(), L->kt, L->kh, L->kw, L->cin, L->cout, L->scale.data(), 1, dtype,
-                                      nf_for(L->cin, taps, rows), 0, &L->wb);
+                                      nf_b > 0 ? nf_b : nf_for(L->cin, taps, rows), 0, &L->wb);
     if (rc) return rc;
     if ((rc = upload(&L->d_scale, L->scale))) return rc;
     if ((rc = upload(&L->d_bias, L->bias))) return rc;
@@ -347,6 +348,78 @@ struct flk_net {
     if (mask) mp = bp(*mask);
     bwd.push_back(Op{name + "/grad", K_POOL, 0.0, bytes, [a, dt, gop, gip, gout, gin, mp, mld](hipStream_t s) {
                        return flk_maxpool3d_bwd(&a, gop, gout.ld, 0, gip, gin.ld, 0, mp, mld, 0, dt, s);
+                     }});
+  }
+
+  // ---- grouped launches: Branch_1's and Branch_2's 3x3x3 units of an Inception block in ONE grid (flk_conv3d_group) ----
+  // Layout of a group over a [B,T,H,W] grid: the LARGE member (cin1 -> cout1) keeps the layout flk_conv3d's heuristics give it with
+  // direct-A weights (nf1 channels x wn1 waves); that fixes the fragments per wave nfw = nf1 / wn1 every member shares.  The small member
+  // (cout2 <= 128) takes the narrowest tile of wn2 in {1, 2, 4} waves x nfw fragments that holds its channels -- with the large member
+  // filling the chip it no longer has to manufacture workgroups out of 64-row tiles.  nfw = 0: no group (fp32, a geometry the group
+  // kernel has no instance for, FLK_GROUP=0).
+  struct GroupLayout { int nfw = 0, nf1 = 0, nf2 = 0; };
+  GroupLayout plan_group(const Act& geom, int cin1, int cout1, int cout2) const {
+    GroupLayout g;
+    static const int on = getenv("FLK_GROUP") ? atoi(getenv("FLK_GROUP")) : 3;
+    if (!on || dtype != FLK_BF16) return g;
+    flk_conv_args a{};
+    a.B = B; a.Ti = a.To = a.OT = geom.T; a.Hi = a.Ho = a.OH = geom.H; a.Wi = a.Wo = a.OW = geom.W;
+    a.kt = a.kh = a.kw = 3; a.st = a.sh = a.sw = 1; a.pt = a.ph = a.pw = 1; a.ost = a.osh = a.osw = 1;
+    a.cin = cin1; a.cout = cout1; a.in_ld = cin1; a.out_ld = cout1;
+    const long rows = (long)B * geom.T * geom.H * geom.W;
+    int nf1 = nf_for(cout1, 27, rows);
+    if (nf1 == 6) nf1 = 4;
+    int wn1 = 1, mode = 0;
+    if (flk_conv_layout_query(&a, nf1, dtype, 1, &wn1, &mode) != FLK_OK || mode != 1) return g;
+    int nfw = nf1 / wn1;
+    if (nfw == 8) nfw = 4;                              // (nf 8 on 256-row tiles: two waves along the channels instead)
+    // measured (bs 8, same box, interleaved runs): no groups 5.94-5.96 ms per step; Mixed_4* grouped with the heuristic's fragments per
+    // wave 5.89-5.92; with four fragments per wave everywhere (the data-gradients of Mixed_4b-d on 128- instead of 64-row tiles) 5.88;
+    // Mixed_5* grouped as well 5.98-6.04 (their split-K launches are faster than any one-slice layout); Mixed_3* too 5.97
+    static const int force_nfw = getenv("FLK_GROUP_NFW") ? atoi(getenv("FLK_GROUP_NFW")) : 4;
+    if (force_nfw == 2 || force_nfw == 4) { if (nf1 < force_nfw) nf1 = force_nfw; nfw = force_nfw; }
+    if (nfw != 2 && nfw != 4) return g;
+    if (nf1 / nfw > 4) nf1 = 4 * nfw;
+    int wn2 = 1;
+    while (wn2 < 4 && 16 * nfw * wn2 < cout2) wn2 *= 2;
+    g.nfw = nfw; g.nf1 = nf1; g.nf2 = nfw * wn2;
+    return g;
+  }
+  // arguments of a stride-1 SAME Unit3D forward / data-gradient (emit_conv_fwd / emit_conv_bwd without the launch)
+  flk_conv_args conv_fwd_args(ConvLayer* L, const Act& in, int in_coff, const Act& out, int out_coff) const {
+    flk_conv_args a{};
+    a.in = bp(in); a.in_ld = in.ld; a.in_coff = in_coff; a.cin = L->cin;
+    a.B = nbatch(); a.Ti = in.T; a.Hi = in.H; a.Wi = in.W;
+    a.kt = L->kt; a.kh = L->kh; a.kw = L->kw; a.st = a.sh = a.sw = 1;
+    a.pt = (L->kt - 1) / 2; a.ph = (L->kh - 1) / 2; a.pw = (L->kw - 1) / 2;
+    a.To = out.T; a.Ho = out.H; a.Wo = out.W;
+    a.out = bp(out); a.out_ld = out.ld; a.out_coff = out_coff; a.cout = L->cout;
+    a.OT = out.T; a.OH = out.H; a.OW = out.W; a.ost = a.osh = a.osw = 1;
+    a.scale = L->d_scale; a.bias = L->d_bias; a.relu = 1;
+    return a;
+  }
+  flk_conv_args conv_bwd_args(ConvLayer* L, const Act& G, int g_coff, const Act& gin, int gin_coff, const Act* mask, int mask_coff) const {
+    flk_conv_args a{};
+    a.in = bp(G); a.in_ld = G.ld; a.in_coff = g_coff; a.cin = L->cout;
+    a.B = nbatch(); a.Ti = G.T; a.Hi = G.H; a.Wi = G.W;
+    a.kt = L->kt; a.kh = L->kh; a.kw = L->kw; a.st = a.sh = a.sw = 1;
+    a.pt = L->kt - 1 - (L->kt - 1) / 2; a.ph = L->kh - 1 - (L->kh - 1) / 2; a.pw = L->kw - 1 - (L->kw - 1) / 2;
+    a.To = gin.T; a.Ho = gin.H; a.Wo = gin.W;
+    a.out = bp(gin); a.out_ld = gin.ld; a.out_coff = gin_coff; a.cout = L->cin;
+    a.OT = gin.T; a.OH = gin.H; a.OW = gin.W; a.ost = a.osh = a.osw = 1;
+    if (mask) { a.mask = bp(*mask); a.mask_ld = mask->ld; a.mask_coff = mask_coff; }
+    return a;
+  }
+  // one operator = the two members in one launch (the large member first: its long K loops start first, the small member's
+  // workgroups fill the tail)
+  void emit_group(std::vector<Op>& ops, const std::string& name, const flk_conv_args& a1, const flk_conv_weights* w1, const flk_conv_args& a2,
+                  const flk_conv_weights* w2, int nfw) {
+    auto macs = [](const flk_conv_args& a) { return (double)a.B * a.To * a.Ho * a.Wo * a.kt * a.kh * a.kw * a.cin * a.cout; };
+    const int dt = dtype;
+    ops.push_back(Op{name, K_CONV, 2.0 * (macs(a1) + macs(a2)), conv_bytes(a1) + conv_bytes(a2), [a1, w1, a2, w2, nfw, dt](hipStream_t s) {
+                       const flk_conv_args* av[2] = {&a1, &a2};
+                       const flk_conv_weights* wv[2] = {w1, w2};
+                       return flk_conv3d_group(av, wv, 2, nfw, dt, s);
                      }});
   }
 
@@ -551,7 +624,18 @@ int flk_net::build_i3d() {
     if ((rc = make_unit3d(bn + "/Branch_0/Conv3d_0a_1x1", 1, 1, 1, cur_c, c0, &L0))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0a_1x1", 1, 1, 1, cur_c, c1a, &L1a))) return rc;
     const long rows_blk = (long)B * cur.T * cur.H * cur.W;
-    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0b_3x3", 3, 3, 3, c1a, c1b, &L1b)) || (rc = pack(L1b, rows_blk))) return rc;
+    // Branch_1 + Branch_2 3x3x3 units as ONE launch per pass (Mixed_4* / Mixed_5* at the benchmark batch: launches of < 256 x 256 positions,
+    // where Branch_2 alone runs at 40-250 TFLOP/s on a 27-step K loop): group layouts of the forward pass and of the data-gradients.
+    // FLK_GROUP_ROWS: largest position count that is grouped (default: below the Mixed_3* size)
+    static const long group_rows = getenv("FLK_GROUP_ROWS") ? atol(getenv("FLK_GROUP_ROWS")) : 256L * 256 - 1;
+    GroupLayout gf, gb;
+    static const long group_min_rows = getenv("FLK_GROUP_MIN_ROWS") ? atol(getenv("FLK_GROUP_MIN_ROWS")) : 4096;
+    static const int group_dirs = getenv("FLK_GROUP") ? atoi(getenv("FLK_GROUP")) : 3;      // bit 0: forward, bit 1: data-gradients
+    if (rows_blk <= group_rows && rows_blk >= group_min_rows) {
+      if (group_dirs & 1) gf = plan_group(cur, c1a, c1b, bk.c[4]);
+      if (group_dirs & 2) gb = plan_group(cur, c1b, c1a, bk.c[3]);
+    }
+    if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0b_3x3", 3, 3, 3, c1a, c1b, &L1b)) || (rc = pack(L1b, rows_blk, gf.nf1, gb.nf1))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_2/Conv3d_0a_1x1", 1, 1, 1, cur_c, c2a, &L2a))) return rc;
     // The three 1x1x1 units reading the block input (i3d.py:197-207) run as ONE GEMM [b0 | b1a | b2a]: one launch, the
     // input read once; columns [0,c0) land in the concat buffer, the rest in `mid`.  Its data-gradient is one GEMM too,
@@ -581,7 +665,7 @@ int flk_net::build_i3d() {
       Lf = L.get();
       convs.push_back(std::move(L));
     }
-    if ((rc = make_unit3d(bn + "/Branch_2/" + b2name, 3, 3, 3, c2a, c2b_, &L2b)) || (rc = pack(L2b, rows_blk))) return rc;
+    if ((rc = make_unit3d(bn + "/Branch_2/" + b2name, 3, 3, 3, c2a, c2b_, &L2b)) || (rc = pack(L2b, rows_blk, gf.nf2, gb.nf2))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_3/Conv3d_0b_1x1", 1, 1, 1, cur_c, c3, &L3)) || (rc = pack(L3, rows_blk))) return rc;
     Act out, Gout, mid, Gmid, pl, Gpl, gxa;
     if ((rc = new_act(out, cur.T, cur.H, cur.W, cout_total)) || (rc = new_act(Gout, cur.T, cur.H, cur.W, cout_total))) return rc;
@@ -615,14 +699,21 @@ int flk_net::build_i3d() {
       if ((rc = emit_pool_fwd(bn + "/Branch_3/MaxPool3d_0a_3x3", cur, cur_c, 3, 3, 3, 1, 1, 1, pl, pr3))) return rc;
       set_lane(fwd, m0, 2);
     }
+    const bool grp_f = gf.nfw > 0 && !pool_late, grp_b = gb.nfw > 0;
     if (!pool_late) {
       fwd.push_back(std::move(fused));
-      push_sync(fwd, K_FORK, 1);
+      if (!grp_f) push_sync(fwd, K_FORK, 1);
     }
-    emit_conv_fwd(L1b, mid, 0, out, c0);
-    { const size_t m0 = fwd.size(); emit_conv_fwd(L2b, mid, c1a, out, c0 + c1b); set_lane(fwd, m0, 1); }
+    if (grp_f) {
+      // Branch_1 and Branch_2 in one launch on the caller's stream; only Branch_3's pool -> 1x1x1 chain runs beside it (side stream 2)
+      emit_group(fwd, bn + "/Branch_1+2/Conv3d_0b_3x3", conv_fwd_args(L1b, mid, 0, out, c0), L1b->wf, conv_fwd_args(L2b, mid, c1a, out, c0 + c1b),
+                 L2b->wf, gf.nfw);
+    } else {
+      emit_conv_fwd(L1b, mid, 0, out, c0);
+      { const size_t m0 = fwd.size(); emit_conv_fwd(L2b, mid, c1a, out, c0 + c1b); set_lane(fwd, m0, 1); }
+    }
     { const size_t m0 = fwd.size(); emit_conv_fwd(L3, pl, 0, out, c0 + c1b + c2b_); set_lane(fwd, m0, 2); }
-    push_sync(fwd, K_JOIN);
+    push_sync(fwd, K_JOIN, grp_f ? 2 : ~0);
     named[bn] = {out, cout_total};
     named["grad:" + bn] = {Gout, cout_total};
     named["mid:" + bn] = {mid, c1a + c2a};
@@ -649,7 +740,7 @@ int flk_net::build_i3d() {
     const int cur_c_blk = cur_c;
     bwd_emit.push_back([=]() {
       if (b3_early && !b3_fused) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
-      push_sync(bwd, K_FORK);
+      push_sync(bwd, K_FORK, grp_b ? 2 : ~0);
       {
         const size_t m0 = bwd.size();
         if (b3_fused) {
@@ -668,9 +759,14 @@ int flk_net::build_i3d() {
         }
         set_lane(bwd, m0, 2);
       }
-      { const size_t m0 = bwd.size(); emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a); set_lane(bwd, m0, 1); }
-      emit_conv_bwd(L1b, Gout, c0, Gmid, 0, nullptr, 0, 0, &mid, 0);
-      push_sync(bwd, K_JOIN);
+      if (grp_b) {
+        emit_group(bwd, bn + "/Branch_1+2/Conv3d_0b_3x3/dgrad", conv_bwd_args(L1b, Gout, c0, Gmid, 0, &mid, 0), L1b->wb,
+                   conv_bwd_args(L2b, Gout, c0 + c1b, Gmid, c1a, &mid, c1a), L2b->wb, gb.nfw);
+      } else {
+        { const size_t m0 = bwd.size(); emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a); set_lane(bwd, m0, 1); }
+        emit_conv_bwd(L1b, Gout, c0, Gmid, 0, nullptr, 0, 0, &mid, 0);
+      }
+      push_sync(bwd, K_JOIN, grp_b ? 2 : ~0);
       {
         flk_conv_args a{};
         a.in = Gout.p; a.in_ld = Gout.ld; a.in_coff = 0; a.cin = c0 + c1a + c2a; a.cin1 = c0;

@@ -63,11 +63,28 @@ class ConvWeights:
             pass
 
 
-def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
-           out_stride=(1, 1, 1), out_offset=(0, 0, 0), scale=None, bias=None, add=None, add_coff=0, mask=None,
-           mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0, splitk=False, pos_bias=None):
+def conv3d(x, w, **kw):
     """x: [B,T,H,W,ld] channels-last; returns / fills out [B,OT,OH,OW,ld_out].  pad = pad-before per dim
-    (default: TF SAME).  out_grid = logical output grid (default: SAME output size)."""
+    (default: TF SAME).  out_grid = logical output grid (default: SAME output size).  Keywords: conv3d_args."""
+    a, out = conv3d_args(x, w, **kw)
+    check(load().flk_conv3d(C.byref(a), w.handle, dtype_code(x.dtype), stream_ptr()))
+    return out
+
+
+def conv3d_group(members, nfw):
+    """members: [(x, w, kwargs)] -- up to three multi-tap bf16 convolutions in ONE launch (flk_conv3d_group); returns their outputs"""
+    built = [conv3d_args(x, w, **kw) for x, w, kw in members]
+    n = len(built)
+    ap = (C.POINTER(ConvArgs) * n)(*[C.pointer(a) for a, _ in built])
+    wp = (C.c_void_p * n)(*[w.handle for _, w, _ in members])
+    check(load().flk_conv3d_group(ap, wp, n, nfw, dtype_code(members[0][0].dtype), stream_ptr()))
+    return [o for _, o in built]
+
+
+def conv3d_args(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
+                out_stride=(1, 1, 1), out_offset=(0, 0, 0), scale=None, bias=None, add=None, add_coff=0, mask=None,
+                mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0, splitk=False, pos_bias=None):
+    """the flk_conv_args of conv3d(x, w, ...) and the output tensor it will fill"""
     B, Ti, Hi, Wi, in_ld = x.shape
     cin = w.cin if cin is None else cin
     k = (w.kt, w.kh, w.kw)
@@ -108,8 +125,7 @@ def conv3d(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, o
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             a.splitk_ws, a.splitk_ws_bytes = ptr(ws), nbytes
             a._keepalive = ws
-    check(load().flk_conv3d(C.byref(a), w.handle, dtype_code(x.dtype), stream_ptr()))
-    return out
+    return a, out
 
 
 def _pool_args(x, C_, k, s, pad, out, idx, in_coff=0, out_coff=0):

@@ -112,6 +112,16 @@ typedef struct {
 } flk_conv_args;
 int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream);
 int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_weights* w);
+/* n <= 3 multi-tap convolutions in ONE grid (bf16): an Inception block's Branch_1 and Branch_2 3x3x3 units (i3d.py:201-209), forward or
+ * data-gradient, which the reference's graph runs as independent ops.  Member i is computed exactly as flk_conv3d(a[i], w[i]) would with
+ * direct-A weights and (w[i]'s nf) / nfw waves along the channels -- bitwise the same outputs -- but its workgroups share the launch: no
+ * second stream, no fork / join, and the short member fills the tail of the long one.  nfw (2 or 4) = channel fragments per wave, the
+ * one template argument the members share; every w[i] must have been packed with nf in {nfw, 2 nfw, 4 nfw}.  Longest K loops first. */
+int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int dtype, void* stream);
+/* the (waves along the channels, weight path: 0 LDS ring / 1 direct A / ...) flk_conv3d's heuristics choose for this geometry when the
+ * weights are packed at `nf` (force_da: -1 heuristic, 0 ring, 1 direct A): lets a plan builder pick the packing of a grouped launch's
+ * members before any weights exist.  No device work. */
+int flk_conv_layout_query(const flk_conv_args* a, int nf, int dtype, int force_da, int* wn_out, int* mode_out);
 
 /* tf.nn.max_pool3d SAME (i3d.py:174,189,212,252,398): padded cells never win; argmax = FIRST
  * maximum in (t,h,w) scan order, stored as a uint8 window index for the backward pass.

@@ -50,6 +50,9 @@ def test_audit_flags_the_pre_fix_k_loops(tmp_path):
     p.write_text(s)
     r = _audit(str(p))
     assert r.returncode == 1, r.stdout[-2000:] + r.stderr[-2000:]
-    # the violations are epilogue address arithmetic built in queue registers whose tail loads have not landed
-    assert "touches in-flight" in r.stdout and "v_lshl_add_u64" in r.stdout
-    assert "30 kernels with asm loads audited, 30 with violations" in r.stdout or "with violations" in r.stdout
+    # the violations are epilogue index / address arithmetic (v_lshl_add_u64, v_mul_lo_u32, v_mad_u64_u32 ... -- which one depends on
+    # hipcc's register allocation of the day) built in queue registers whose tail loads have not landed
+    import re
+    assert "touches in-flight" in r.stdout
+    m = re.search(r"(\d+) kernels with asm loads audited, (\d+) with violations", r.stdout)
+    assert m and int(m.group(1)) >= 30 and int(m.group(2)) >= 10, r.stdout[-500:]

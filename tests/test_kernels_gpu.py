@@ -530,3 +530,56 @@ def test_stem_delta_grad_in_engine():
     # fp32 engines and dense perturbations keep the two-kernel path
     assert not FlickerI3D(W, batch_size=1, frames=T, dtype="f32").fused_delta_grad
     assert not FlickerI3D(W, batch_size=1, frames=T, dtype="bf16", dense_delta=True).fused_delta_grad
+
+
+GROUP_CASES = [
+    # name, B,T,H,W, (cin1, cout1, nf1), (cin2, cout2, nf2), nfw      -- an Inception block's Branch_1 / Branch_2 3x3x3 pair in ONE launch
+    ("4b_fwd", 2, 4, 14, 14, (96, 208, 8), (16, 48, 4), 4),            # wn 2 + wn 1 on four fragments per wave
+    ("4b_dgrad", 2, 4, 14, 14, (208, 96, 8), (48, 16, 2), 2),          # wn 4 + wn 1 on two fragments per wave
+    ("4f_fwd", 1, 4, 14, 14, (160, 320, 4), (32, 128, 8), 4),          # wn 1 + wn 2, five channel tiles + one
+    ("5b_fwd", 2, 2, 7, 7, (160, 320, 4), (32, 128, 8), 2),            # wn 2 + wn 4 (the Mixed_5 tiles: 7 x 7 planes)
+    ("5c_dgrad_ragged", 1, 3, 7, 9, (384, 192, 4), (128, 48, 4), 2),   # ragged tiles, a partial channel tile in member 2
+]
+
+
+@pytest.mark.parametrize("case", GROUP_CASES, ids=[c[0] for c in GROUP_CASES])
+def test_conv_group(ops, case):
+    """flk_conv3d_group: two 3x3x3 convolutions over the same position grid in one grid of conv_igemm_group_kernel.  Each member against
+    the torch-CPU oracle (bf16 tolerances) with the epilogue the plan uses (scale, bias, ReLU forward; ReLU mask backward), and BITWISE
+    against flk_conv3d launched separately on the same packed weights (the members keep their own K order and tiles)."""
+    _, B, T, H, W, m1, m2, nfw = case
+    dtype = torch.bfloat16
+    ctot = m1[0] + m2[0]
+    xin = q(rnd((B, T, H, W, ctot), 11), dtype)                       # one input buffer, two channel slices (the plan's `mid`)
+    otot = m1[1] + m2[1] + 8
+    members, refs, singles = [], [], []
+    out_g = torch.zeros((B, T, H, W, otot), dtype=dtype, device="cuda")
+    out_s = torch.zeros_like(out_g)
+    xg = xin.to(dtype).cuda()
+    maskt = q(rnd((B, T, H, W, otot), 12), dtype)
+    in_off, out_off = 0, 8
+    for i, (cin, cout, nf) in enumerate((m1, m2)):
+        w = q(rnd((3, 3, 3, cin, cout), 20 + i, (2.0 / (27 * cin)) ** 0.5), dtype)
+        sc = rnd((cout,), 30 + i).abs() + 0.5
+        bi = rnd((cout,), 40 + i, 0.1)
+        ref = ref_conv(xin[..., in_off:in_off + cin].contiguous(), w, (1, 1, 1), (1, 1, 1), (T, H, W)) * sc + bi
+        ref = torch.relu(ref) * (maskt[..., out_off:out_off + cout] > 0)
+        refs.append((ref, out_off, cout))
+        pw = ops.ConvWeights(w.numpy(), dtype, nf)
+        kw = dict(in_coff=in_off, cin=cin, out_coff=out_off, scale=sc.cuda(), bias=bi.cuda(), relu=True, mask=maskt.to(dtype).cuda(),
+                  mask_coff=out_off)
+        members.append((xg, pw, dict(kw, out=out_g)))
+        singles.append((pw, dict(kw, out=out_s)))
+        in_off += cin
+        out_off += cout
+    ops.conv3d_group(members, nfw)
+    for pw, kw in singles:
+        ops.conv3d(xg, pw, **kw)
+    torch.cuda.synchronize()
+    for ref, off, cout in refs:
+        r, a = tol(dtype, ref)
+        torch.testing.assert_close(out_g[..., off:off + cout].float().cpu(), ref, rtol=r, atol=a)
+    assert torch.equal(out_g, out_s)                                    # bitwise the separate launches (untouched channels stay zero)
+    again = torch.zeros_like(out_g)
+    ops.conv3d_group([(x_, w_, dict(k_, out=again)) for x_, w_, k_ in members], nfw)
+    assert torch.equal(again, out_g)
