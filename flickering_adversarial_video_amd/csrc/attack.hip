@@ -124,6 +124,44 @@ __global__ __launch_bounds__(256) void apply_s2d_kernel(const flk_apply_args a, 
   }
 }
 
+// fold_t = 4: the (h,w) fold of fold_t = 1 with every value split into TWO bf16 numbers, [B,T,H/2,W/2,32]: channel k = bf16(x_adv),
+// channel 16 + k = bf16(x_adv - channel k).  The VideoResNet stems (bf16 plans) read both halves against the same weights, i.e. they
+// see the perturbed clip to ~16 mantissa bits at the MFMA cost of the 16 -> 32 channel padding their K step had anyway: rounding
+// x + delta/std to ONE bf16 swallows a small flicker perturbation (|delta| = 1e-4 moved the logits with the wrong sign), and the
+// centred-clip + position-bias form of the I3D stem is exact only where the clamp bounds are bf16 numbers -- here 5-8 % of the
+// values of a clip sit AT a bound, and bf16(bound - p) jumps by a whole ulp for all of them at once (measured: wrong sign at
+// |delta| = 5e-4).
+__global__ __launch_bounds__(256) void apply_s2d_hilo_kernel(const flk_apply_args a, char* out) {
+  const int H2 = a.H / 2, W2 = a.W / 2;
+  const long total = (long)a.B * a.T * H2 * W2;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    long r = gid;
+    const int w2 = r % W2; r /= W2;
+    const int h2 = r % H2; r /= H2;
+    const int t = r % a.T;
+    const int b = r / a.T;
+    const int tx = wrap(t - a.shift_x, a.T);
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      const int h = 2 * h2 + qh;
+      float x[6];
+      load6(a, ((((size_t)b * a.T + tx) * a.H + h) * a.W + 2 * w2) * 3, x);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float pv = a.adv_flag != 0.f ? a.adv_flag * pert_at(a, b, t, h, 2 * w2 + k / 3, k % 3) : 0.f;
+        const float u = applied(a, x[k], pv);
+        const float hi = (float)(bf16_t)u;
+        v[S2D<1>::ch(0, qh, k)] = hi;                    // (stored again as bf16: exact)
+        v[16 + S2D<1>::ch(0, qh, k)] = u - hi;
+      }
+    }
+    store_ch<bf16_t, 32>(out + (size_t)gid * 32 * sizeof(bf16_t), v);
+  }
+}
+
 // Fast path of the headline configuration (uint8 clip, flicker delta [T,3], FT = 2, W % 8 == 0): one thread = 4
 // consecutive output positions.  It reads its 24 source bytes of each of the 4 (frame, row) pairs as three aligned
 // 8-byte loads (the generic kernel above issues 2-byte loads), evaluates the 6 perturbation values (2 frames x RGB) once,
@@ -176,8 +214,8 @@ __global__ __launch_bounds__(256) void apply_s2d_u8_flicker_kernel(const flk_app
 
 static int check_apply(const flk_apply_args* a) {
   FLK_REQUIRE(a && a->x && a->delta, "flk_perturb: null argument");
-  FLK_REQUIRE(a->fold_t >= 0 && a->fold_t <= 3, "flk_perturb: fold_t must be 0, 1, 2 or 3");
-  FLK_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && (a->fold_t == 1 || a->T % 2 == 0) && a->H % 2 == 0 && a->W % 2 == 0,
+  FLK_REQUIRE(a->fold_t >= 0 && a->fold_t <= 4, "flk_perturb: fold_t must be 0 .. 4");
+  FLK_REQUIRE(a->B > 0 && a->T > 0 && a->H > 0 && a->W > 0 && (a->fold_t == 1 || a->fold_t == 4 || a->T % 2 == 0) && a->H % 2 == 0 && a->W % 2 == 0,
               "flk_perturb: H,W (and T when folded) must be positive and even (got %d,%d,%d)", a->T, a->H, a->W);
   FLK_REQUIRE(a->lo <= a->hi, "flk_perturb: lo > hi");
   FLK_REQUIRE(!(a->center && a->delta_dense), "flk_perturb: center = 1 is defined for the flicker perturbation [T,3] only");
@@ -190,11 +228,17 @@ extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dty
   int rc = check_apply(a);
   if (rc) return rc;
   FLK_REQUIRE(out, "flk_perturb_apply_s2d: null out");
-  const int ftl = a->fold_t == 1 ? 1 : a->fold_t == 3 ? 3 : 2, ft = ftl == 1 ? 1 : 2;
+  const int ftl = (a->fold_t == 1 || a->fold_t == 4) ? 1 : a->fold_t == 3 ? 3 : 2, ft = ftl == 1 ? 1 : 2;
   const long total = (long)a->B * (a->T / ft) * (a->H / 2) * (a->W / 2);
   const unsigned grid = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   hipStream_t st = (hipStream_t)stream;
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_perturb_apply_s2d: bad dtype");
+  if (a->fold_t == 4) {
+    FLK_REQUIRE(dtype == FLK_BF16 && !a->center, "flk_perturb_apply_s2d: fold_t = 4 (two bf16 numbers per value) writes bf16, uncentred");
+    FLK_LAUNCH_KERNEL(apply_s2d_hilo_kernel, dim3(grid), dim3(256), 0, st, *a, (char*)out);
+    FLK_CHECK_HIP(hipGetLastError());
+    return FLK_OK;
+  }
   const bool bf = dtype == FLK_BF16;
   static const bool apply_generic = getenv("FLK_APPLY_GENERIC") != nullptr;
   if (ft == 2 && a->x_is_u8 && !a->delta_dense && a->W % 8 == 0 && a->T / 2 < 65536 && a->B < 65536 && !apply_generic) {
@@ -277,7 +321,7 @@ __global__ __launch_bounds__(256) void grad_reduce_stage1(const flk_apply_args a
 __global__ void grad_reduce_stage2(const flk_apply_args a, int nchunk, const float* partials, float* gdelta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.T * 3) return;
-  const int FT = a.fold_t == 1 ? 1 : 2;                 // frames per folded position (fold_t 0, 2, 3: two)
+  const int FT = (a.fold_t == 1 || a.fold_t == 4) ? 1 : 2;      // frames per folded position (fold_t 0, 2, 3: two)
   const int t = i / 3, c = i % 3, t2 = t / FT, qt = t % FT, T2 = a.T / FT;
   const int b_lo = a.delta_per_clip ? (int)blockIdx.y : 0, b_hi = a.delta_per_clip ? b_lo + 1 : a.B;
   float s = 0.f;
@@ -358,7 +402,8 @@ extern "C" int flk_perturb_grad_reduce(const flk_apply_args* a, const void* gx_s
   FLK_REQUIRE(gx_s2d && gdelta, "flk_perturb_grad_reduce: null argument");
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_perturb_grad_reduce: bad dtype");
   hipStream_t s = (hipStream_t)stream;
-  const int ftl = a->fold_t == 1 ? 1 : a->fold_t == 3 ? 3 : 2, ft = ftl == 1 ? 1 : 2;
+  // (fold_t = 4: the clip went in as two bf16 numbers per value; its gradient comes back in the 16-channel fold_t = 1 layout)
+  const int ftl = (a->fold_t == 1 || a->fold_t == 4) ? 1 : a->fold_t == 3 ? 3 : 2, ft = ftl == 1 ? 1 : 2;
   const bool bf = dtype == FLK_BF16;
   if (a->delta_dense) {
     const long total = (long)(a->T / ft) * (a->H / 2) * (a->W / 2);

@@ -135,6 +135,8 @@ struct flk_net {
   // (stem_fwd.hip: perturbation apply + 7x7x7 / 2 convolution in one kernel, 37 K steps instead of apply + 49); the space-to-depth
   // tensor is then neither written nor read.  FLK_STEM_U8=0 (read per call): the two-kernel path.
   flk_conv_weights* stem_u8_w = nullptr;
+  flk_conv_weights* stem_hilo_w = nullptr;      // VideoResNet stems in bf16: forward weights over the two-bf16-numbers-per-value input (fold_t = 4)
+  int in_ch = 16;                               // VideoResNet plans: channels of the input tensor (16, or 32 in bf16)
   bool stem_from_u8() const {
     return stem_u8_w && cur_apply && cur_pos_bias && cur_apply->x_is_u8 && cur_apply->center == 1 && !cur_apply->delta_dense &&
            !(getenv("FLK_STEM_U8") && atoi(getenv("FLK_STEM_U8")) == 0);
@@ -963,17 +965,31 @@ int flk_net::build_videoresnet() {
     convs.push_back(std::move(L));
   }
   if ((rc = pack_generic(stem))) return rc;
+  // bf16: the clip arrives as TWO bf16 numbers per value (flk_apply_args.fold_t = 4: channels [0,16) = bf16(x_adv), [16,32) = the
+  // remainder), both halves against the same weights -- the stem's K step had 32 channels anyway (16 padded): same MFMA work, the
+  // perturbed clip to ~16 bits.  The data-gradient keeps the 16-channel operator (its output is the gradient of x_adv).
+  const bool hilo = dtype == FLK_BF16;
+  flk_conv_weights* stem_wf = stem->wf;
+  if (hilo) {
+    std::vector<float> w2((size_t)skt * 16 * 32 * stem->cout);
+    for (int t = 0; t < skt * 16; ++t)
+      for (int half = 0; half < 2; ++half)
+        memcpy(&w2[((size_t)t * 32 + half * 16) * stem->cout], &stem->w[(size_t)t * 16 * stem->cout], (size_t)16 * stem->cout * sizeof(float));
+    if ((rc = flk_conv_weights_create_impl(w2.data(), skt, 4, 4, 32, stem->cout, nullptr, 0, dtype, choose_nf(stem->cout, skt * 16), 0, &stem_hilo_w))) return rc;
+    stem_wf = stem_hilo_w;
+  }
+  in_ch = hilo ? 32 : 16;
   Act a_st, G_st;
   if ((rc = new_act(a_st, T, H2, W2, stem->cout)) || (rc = new_act(G_st, T, H2, W2, stem->cout))) return rc;
   named[r21 ? "stem.mid" : "stem"] = {a_st, sc_out};
   {
     flk_conv_args a{};
-    a.in_ld = 16; a.cin = 16; a.B = B; a.Ti = T; a.Hi = H2; a.Wi = W2;
+    a.in_ld = in_ch; a.cin = in_ch; a.B = B; a.Ti = T; a.Hi = H2; a.Wi = W2;
     a.kt = skt; a.kh = a.kw = 4; a.st = a.sh = a.sw = 1; a.pt = (skt - 1) / 2; a.ph = a.pw = 2;
     a.To = T; a.Ho = H2; a.Wo = W2; a.OT = T; a.OH = H2; a.OW = W2; a.ost = a.osh = a.osw = 1;
     a.out = a_st.p; a.out_ld = a_st.ld; a.cout = stem->cout; a.scale = stem->d_scale; a.bias = stem->d_bias; a.relu = 1;
     const double macs = (double)B * T * H2 * W2 * skt * 49.0 * 3 * sc_out;
-    flk_conv_weights* wf = stem->wf;
+    flk_conv_weights* wf = stem_wf;
     const int dt = dtype;
     fwd.push_back(Op{"stem.0", K_CONV, 2.0 * macs, conv_bytes(a), [this, a, wf, dt](hipStream_t s) mutable {
                        a.in = x_in;
@@ -1156,6 +1172,7 @@ extern "C" int flk_net_destroy(flk_net* n) {
   flk_stem_delta_grad_weights_destroy(n->d_stem_wf);
   flk_stem_delta_grad_weights_destroy(n->d_stem_sums);
   flk_conv_weights_destroy(n->stem_u8_w);
+  flk_conv_weights_destroy(n->stem_hilo_w);
   for (void* p : n->allocs) (void)hipFree(p);
   for (void* p : n->pool_gemm_weights) flk_pool_gemm_weights_destroy(p);
   for (auto& L : n->convs) {
@@ -1211,7 +1228,7 @@ extern "C" int64_t flk_net_workspace_bytes(const flk_net* n) { return n ? (int64
 extern "C" int64_t flk_net_input_numel(const flk_net* n) {
   if (!n) return 0;
   return n->arch == FLK_NET_I3D ? (int64_t)n->B * (n->T / 2) * (n->H / 2) * (n->W / 2) * 32
-                                : (int64_t)n->B * n->T * (n->H / 2) * (n->W / 2) * 16;
+                                : (int64_t)n->B * n->T * (n->H / 2) * (n->W / 2) * n->in_ch;
 }
 extern "C" int flk_net_num_classes(const flk_net* n) { return n ? n->num_classes : 0; }
 
@@ -1357,7 +1374,7 @@ extern "C" int flk_net_forward_apply(flk_net* n, const flk_apply_args* a, void* 
   FLK_REQUIRE(n && n->finalized && a && x_s2d_out && logits, "flk_net_forward_apply: bad argument / not finalized");
   FLK_REQUIRE(a->B == n->B && a->T == n->T && a->H == n->H && a->W == n->W, "flk_net_forward_apply: apply args (%d,%d,%d,%d) do not match the "
               "net (%d,%d,%d,%d)", a->B, a->T, a->H, a->W, n->B, n->T, n->H, n->W);
-  FLK_REQUIRE(a->fold_t == (n->arch == FLK_NET_I3D ? 3 : 1), "flk_net_forward_apply: fold_t %d is not this plan's input layout", a->fold_t);
+  FLK_REQUIRE(a->fold_t == (n->arch == FLK_NET_I3D ? 3 : n->in_ch == 32 ? 4 : 1), "flk_net_forward_apply: fold_t %d is not this plan's input layout", a->fold_t);
   n->cur_apply = a;
   const int rc = a->center ? flk_net_forward_flicker(n, x_s2d_out, a, logits, stream) : flk_net_forward(n, x_s2d_out, logits, 1, stream);
   n->cur_apply = nullptr;

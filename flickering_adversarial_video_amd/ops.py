@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (FLK_BF16, FLK_F32, AdamArgs, ApplyArgs, ConvArgs, DenseAdamArgs, LossArgs, PoolArgs, check, dtype_code, load, ptr,
+from ._lib import (FLK_BF16, FLK_F32, FLK_NET_I3D, AdamArgs, ApplyArgs, ConvArgs, DenseAdamArgs, LossArgs, PoolArgs, check, dtype_code, load, ptr,
                    stream_ptr, torch_dtype)
 
 
@@ -226,8 +226,9 @@ def make_apply_args(x, delta, *, dialect="tf", dclip=0.4, adv_flag=1.0, shift_x=
 
 def perturb_apply_s2d(args, dtype, out=None):
     if out is None:
-        ft = 1 if args.fold_t == 1 else 2
-        out = torch.empty((args.B, args.T // ft, args.H // 2, args.W // 2, 16 * ft), dtype=torch_dtype(dtype_code(dtype)), device="cuda")
+        ft = 1 if args.fold_t in (1, 4) else 2
+        out = torch.empty((args.B, args.T // ft, args.H // 2, args.W // 2, 32 if args.fold_t == 4 else 16 * ft), dtype=torch_dtype(dtype_code(dtype)),
+                          device="cuda")
     check(load().flk_perturb_apply_s2d(C.byref(args), ptr(out), dtype_code(dtype), stream_ptr()))
     return out
 
@@ -459,6 +460,11 @@ class Net:
         check(load().flk_net_finalize(h))
         self.num_classes = load().flk_net_num_classes(h)
         self.input_numel = load().flk_net_input_numel(h)
+        # VideoResNet plans: channels of the (h,w)-folded input tensor -- 16, or 32 in bf16 (two bf16 numbers per value, fold_t = 4);
+        # the input GRADIENT always has the 16-channel layout
+        self.input_channels = self.input_numel // (B * (T // 2 if arch == FLK_NET_I3D else T) * (H // 2) * (W // 2))
+        self.input_fold = I3D_FOLD if arch == FLK_NET_I3D else (4 if self.input_channels == 32 else 1)
+        self.grad_numel = self.input_numel if arch == FLK_NET_I3D else self.input_numel // self.input_channels * 16
         self.workspace_bytes = load().flk_net_workspace_bytes(h)
 
     def forward(self, x_in, logits=None):
@@ -493,7 +499,7 @@ class Net:
 
     def backward(self, dlogits, gx=None):
         if gx is None:
-            gx = torch.empty(self.input_numel, dtype=torch_dtype(self.dtype), device="cuda")
+            gx = torch.empty(self.grad_numel, dtype=torch_dtype(self.dtype), device="cuda")
         check(load().flk_net_backward(self.handle, ptr(dlogits), ptr(gx), stream_ptr()))
         return gx
 

@@ -81,13 +81,14 @@ class Perturbation:
             p = perturbation
         self.perturbation = torch.from_numpy(self._to_dev(p)).cuda()
 
-    def apply_args(self, x, adversarial=True):
+    def apply_args(self, x, adversarial=True, fold_t=1):
+        """fold_t: 1 = the (h,w)-folded 16-channel tensor; 4 = the same as two bf16 numbers per value (the input of bf16 plans)"""
         shift = int(self._rng.integers(0, self.T)) if (self.cyclic_pert and adversarial) else 0   # model.py:91-92
         inf = float("inf")
         return ops.make_apply_args(x, self.perturbation, dialect="torch", dclip=self.dynamic_max_norm,
                                    adv_flag=1.0 if adversarial else 0.0, shift_p=shift,
                                    inv_std=tuple(1.0 / s for s in DEFAULT_STD),
-                                   lo=self.min_value if adversarial else -inf, hi=self.max_value if adversarial else inf, fold_t=1,
+                                   lo=self.min_value if adversarial else -inf, hi=self.max_value if adversarial else inf, fold_t=fold_t,
                                    dclip_dev=self.dyn_max_norm_dev if self.batch is not None else None)
 
     def forward(self, input):
@@ -253,8 +254,10 @@ class FlickerVideoResNet:
                                        max_norm=l_inf_pert_norm, cyclic_pert=cyclic_pert, batch=self.B if self.per_clip else None)
         dev = torch.device("cuda", device)
         tdt = torch.bfloat16 if dtype in ("bf16", torch.bfloat16) else torch.float32
-        self._xs = torch.empty((self.B, self.T, self.H // 2, self.W // 2, 16), dtype=tdt, device=dev)
-        self._gx = torch.empty_like(self._xs)
+        # bf16 plans take the clip as TWO bf16 numbers per value (32 channels, fold_t = 4: the stem sees x + delta/std to ~16 bits -- one
+        # bf16 per value swallowed |delta| = 1e-4 outright; the reference STARTS at U(+-1e-6), model.py:71); gradients: 16 channels
+        self._xs = torch.empty((self.B, self.T, self.H // 2, self.W // 2, self.net.input_channels), dtype=tdt, device=dev)
+        self._gx = torch.empty((self.B, self.T, self.H // 2, self.W // 2, 16), dtype=tdt, device=dev)
         self._logits = torch.empty((self.B, num_classes), dtype=torch.float32, device=dev)
         self._red = torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev)
         self._scratch = torch.empty(max(1, ops.load().flk_perturb_grad_scratch_bytes(self.B, self.T, self.H, self.W) // 4), dtype=torch.float32, device=dev)
@@ -266,6 +269,12 @@ class FlickerVideoResNet:
             self.adam_steps = torch.zeros(self.B, dtype=torch.int32, device=dev)
             self.active = torch.ones(self.B, dtype=torch.int32, device=dev)
 
+    def _forward(self, x, adversarial):
+        """Perturbation -> network: the apply arguments of this call (the backward pass masks with the same) ; logits in self._logits"""
+        a = self.pert_model.apply_args(self._check_x(x), adversarial, fold_t=self.net.input_fold)
+        self.net.forward_apply(a, self._xs, self._logits)           # the plan applies the perturbation in front of its stem
+        return a
+
     def _check_x(self, x):
         if tuple(x.shape) != (self.B, self.T, self.H, self.W, 3) or x.dtype != torch.float32 or not x.is_cuda:
             raise ValueError(f"clip must be a CUDA float32 channels-last tensor {(self.B, self.T, self.H, self.W, 3)}, got {tuple(x.shape)} {x.dtype}")
@@ -273,9 +282,8 @@ class FlickerVideoResNet:
 
     def logits(self, x, adversarial=False):
         """model([x, adversarial]) (model.py:1028,1073)"""
-        a = self.pert_model.apply_args(self._check_x(x), adversarial)
-        ops.perturb_apply_s2d(a, self.dtype, self._xs)
-        return self.net.forward(self._xs, self._logits)
+        self._forward(x, adversarial)
+        return self._logits
 
     def step(self, x, labels, criterion, lr=1e-3, update=True):
         """one iteration of fit_single_video_attack (model.py:1073-1101): forward, Losses, backward, torch-Adam step.
@@ -288,7 +296,6 @@ class FlickerVideoResNet:
             return self._step_dense(x, labels, criterion, lr, update)
         if self.per_clip:
             return self._step_per_clip(x, labels, criterion, lr, update)
-        a = self.pert_model.apply_args(self._check_x(x), True)
         if not hasattr(self, "_slots"):
             dev = self._logits.device
             self._slots = [dict(payload=torch.zeros(parallel.payload_size(self.T), dtype=torch.float32, device=dev),
@@ -300,8 +307,7 @@ class FlickerVideoResNet:
         self._it += 1
         red, sm, pc = slot["payload"], slot["sm"], slot["pc"]
         self._red = red
-        ops.perturb_apply_s2d(a, self.dtype, self._xs)
-        self.net.forward(self._xs, self._logits)
+        a = self._forward(x, True)
         gbatch = self.B * self.world
         criterion.adv(labels, self._logits, gbatch, out=(sm, self._dl, pc))
         self.net.backward(self._dl, self._gx)
@@ -326,7 +332,6 @@ class FlickerVideoResNet:
         """one iteration of B independent single-video attacks (torch dialect): per-clip loss / gradient / Adam, everything [B]-shaped.
         Per clip the arithmetic is that of ``step`` on a batch of one (bitwise in fp32)."""
         from .i3d_engine import RESULT_SLOTS, StepResult
-        a = self.pert_model.apply_args(self._check_x(x), True)
         if not hasattr(self, "_slots"):
             dev = self._logits.device
             self._slots = [dict(sm=torch.empty_like(self._logits), pc=torch.empty((self.B, 4), dtype=torch.float32, device=dev),
@@ -337,8 +342,7 @@ class FlickerVideoResNet:
         slot = self._slots[self._it % RESULT_SLOTS]
         self._it += 1
         sm, pc, g = slot["sm"], slot["pc"], slot["g"]
-        ops.perturb_apply_s2d(a, self.dtype, self._xs)
-        self.net.forward(self._xs, self._logits)
+        a = self._forward(x, True)
         criterion.adv(labels, self._logits, 1, out=(sm, self._dl, pc))            # every clip is its own batch of one
         self.net.backward(self._dl, self._gx)
         ops.perturb_grad_reduce(a, self._gx, g, self._scratch)
@@ -362,9 +366,7 @@ class FlickerVideoResNet:
         """the dense "L12" attack (model.py:211-214,380-384): loss = adv + lambda * L12(clamped delta); the data-parallel payload
         is the dense gradient [T,H,W,3] (2.4 MB at 16 x 112 x 112)"""
         from .i3d_engine import StepResult
-        a = self.pert_model.apply_args(self._check_x(x), True)
-        ops.perturb_apply_s2d(a, self.dtype, self._xs)
-        self.net.forward(self._xs, self._logits)
+        a = self._forward(x, True)
         gbatch = self.B * self.world
         sm, dl, pc = criterion.adv(labels, self._logits, gbatch)
         self._dl = dl

@@ -180,7 +180,11 @@ typedef struct {
                                 3: the same fold with chunk-aligned channels (qt*2+qh)*8 + qw*3+c, 6 and 7 of every 8
                                 zero (one (qt,qh) parity per 16-byte chunk: flk_conv_weights_create_s2d_stem);
                                 1: fold (h,w) only -> [B,T,H/2,W/2,16], channel (qh*2+qw)*3+c, 12..15 zero
-                                (VideoResNet stems, stride 1x2x2) */
+                                (VideoResNet stems, stride 1x2x2);
+                                4 (bf16 output only): the fold of 1 with every value as TWO bf16 numbers -> [B,T,H/2,W/2,32]: channel k =
+                                bf16(x_adv), channel 16 + k = bf16(x_adv - channel k) -- the input of the VideoResNet stems in bf16
+                                plans (both halves against the same weights: the perturbed clip to ~16 bits at no extra MFMA work;
+                                one bf16 per value swallows |delta| < 1e-3 / std).  Gradients come back in the layout of 1. */
   int center;                /* 1 (flicker delta only): write x' = x_adv - a*p' instead of x_adv, i.e. the CLEAN value wherever the
                                 clip is inactive (exactly representable in bf16 for uint8 clips) -- the perturbation then reaches the stem
                                 through flk_conv_args.pos_bias in fp32 (flk_stem_delta_bias) instead of being rounded away with the

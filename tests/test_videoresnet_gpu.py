@@ -62,7 +62,10 @@ def test_videoresnet_forward_backward(arch):
         e = rel_err(eng._logits.cpu(), r32["logits"])
         print(f"[{arch} {dtype}] logits: max rel err {e:.3e}")
         assert e < (1e-3 if f32 else 5e-2)
-        assert float(res["adv_loss"]) == pytest.approx(r32["adv"], rel=1e-3 if f32 else 1e-1, abs=1e-5)
+        # (bf16: the improve loss on logits is a difference of two logits + margin -- 2-Lipschitz in the max norm of the logits -- and on
+        #  this random-sign fixture the two are close: the bound is derived from the measured logit error, not from the loss's size)
+        abs_l = float((eng._logits.cpu() - r32["logits"]).abs().max())
+        assert float(res["adv_loss"]) == pytest.approx(r32["adv"], rel=1e-3, abs=1e-5) if f32 else abs(float(res["adv_loss"]) - r32["adv"]) <= 2 * abs_l + 1e-5
         # ---- backward, link by link (see tests/test_i3d_gpu.py): stem <- layer1.0 <- ... <- layer4.1 <- logits ----
         Wd = {k: (torch.from_numpy(v).to(torch.bfloat16).double() if (not f32 and v.ndim == 5) else torch.from_numpy(v).double()) for k, v in W.items()}
         # (bf16: this oracle rounds the block ENDPOINTS to bf16 only; the HIP path also stores the activations inside a block in
@@ -75,7 +78,10 @@ def test_videoresnet_forward_backward(arch):
         links.append(("logits", lambda x, fr: torch.nn.functional.linear(x.mean(dim=(2, 3, 4)), Wd["fc.weight"], Wd["fc.bias"])))
         d0 = delta.double().clone().requires_grad_(True)
         xa = am.torch_apply(x_cl.double().permute(0, 4, 1, 2, 3).contiguous(), d0, 0.2)
-        prev_name, prev = "delta", (xa.detach().to(torch.bfloat16).double() + (xa - xa.detach())) if not f32 else xa     # bf16: stored input, straight-through
+        # bf16: the stem reads the perturbed clip as TWO bf16 numbers per value (hi = bf16(x_adv), lo = bf16(x_adv - hi); fold_t = 4):
+        # value hi + lo, gradient x_adv's (straight through)
+        hi16 = xa.detach().to(torch.bfloat16).double()
+        prev_name, prev = "delta", (hi16 + (xa.detach() - hi16).to(torch.bfloat16).double() + (xa - xa.detach())) if not f32 else xa
         for name, fn in links:
             with torch.no_grad():
                 out = fn(prev, True)
@@ -102,7 +108,9 @@ def test_videoresnet_forward_backward(arch):
         cos = float(torch.nn.functional.cosine_similarity(g.double().flatten(), r64["g"].flatten(), 0))
         print(f"[{arch} {dtype}] d(adv)/d(delta) end to end vs fp64: HIP {e_hip:.3e} (fp32 CPU {e_cpu:.3e}) cosine {cos:.6f}")
         assert g[:, 2].abs().max() == 0
-        assert cos > (0.999 if f32 else 0.8)
+        # (bf16, measured: r2plus1d_18 0.946, r3d_18 0.992, mc3_18 0.988 -- accumulated bf16 rounding of the gradient through 20 / 40 layers on
+        #  the random-sign fixture; the links above bound every layer's own error)
+        assert cos > (0.999 if f32 else 0.92 if arch == "r2plus1d_18" else 0.975)
         # one real update: torch-Adam on (adv + lambda*reg) -- first step is a pure sign step of the total gradient
         before = eng.pert_model.perturbation.clone()
         eng.step(x_cl.cuda(), r32["label"].cuda(), crit)
@@ -113,8 +121,8 @@ def test_videoresnet_forward_backward(arch):
         del eng
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_videoresnet_attack_trajectory_well_conditioned(dtype):
+@pytest.mark.parametrize("arch,dtype", [("r2plus1d_18", "f32"), ("r2plus1d_18", "bf16"), ("mc3_18", "bf16"), ("r3d_18", "bf16")])
+def test_videoresnet_attack_trajectory_well_conditioned(arch, dtype):
     """BASELINE config 3 (r2plus1d_18, bs 1, 16 x 112 x 112, torch dialect) at the north-star bar: logits, adversarial loss and the
     LEARNED DELTA of the fp32 mode within 1e-3 of the reference maths (fp64 oracle) over 6 iterations of the single-video loop
     (model.py:1073-1101: Perturbation -> net -> Losses -> backward -> torch-Adam) on the well-conditioned fixture
@@ -125,7 +133,7 @@ def test_videoresnet_attack_trajectory_well_conditioned(dtype):
     from flickering_adversarial_video_amd import videoresnet_spec as vs
     from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet, Losses
     from oracle import fixtures
-    arch, steps, LR = "r2plus1d_18", 6, 1e-3
+    steps, LR = 6, 1e-3
     x_cl = torch.from_numpy(vs.synthetic_clip(1, T, HW, HW, seed=5))
     x = x_cl.permute(0, 4, 1, 2, 3).contiguous()
     W = fixtures.coherent_videoresnet_weights(vs.synthetic_weights(arch, 42), x, arch, label=233)
@@ -151,11 +159,14 @@ def test_videoresnet_attack_trajectory_well_conditioned(dtype):
     assert int(label) == int(label32) == 233
     for it in range(steps):
         assert rel_err(t32[it]["delta"], t64[it]["delta"]) < 1e-4, "fixture is not well-conditioned"
-    # bf16 (the dtype config 3 is benchmarked in): the same trajectory at stated bf16 tolerances
-    # measured on MI355X (r2plus1d_18): delta 2.5e-2, adversarial loss 1.2e-3; logits 9e-2 already at delta = 0 (the fixture's FC
-    # has random signs: the logits are cancelling sums of the positive features, which amplifies the bf16 rounding of 40 layers --
-    # the loss, a difference of two logits of the favoured classes, is 100x better conditioned)
-    TOL_D, TOL_L, TOL_A = (1e-3, 1e-3, 1e-3) if dtype == "f32" else (4e-2, 1.5e-1, 5e-3)
+    # bf16 (the dtype config 3 is benchmarked in; mc3_18 is the reference's universal-attack model, r2plus1d_main_universal_attack.py:
+    # 30-33): the same trajectory at stated bf16 tolerances.  Round 3 (the clip rounded to ONE bf16 per value) measured delta 2.5e-2, logits
+    # 9e-2 -- at delta = 0 already: it was the rounding of the CLIP, on a fixture whose logits are cancelling sums -- against bars of 4e-2 /
+    # 1.5e-1.  Round 4: the bf16 plans read the clip as two bf16 numbers per value (fold_t = 4, ~16 bits).  Measured on MI355X:
+    #   r2plus1d_18  delta 6.9e-3   logits 1.6e-2   adversarial loss 1.0e-4      (the (2+1)D mid tensors: twice the bf16 layers)
+    #   mc3_18       delta 1.1e-4   logits 3.4e-4   adversarial loss 3.2e-6
+    #   r3d_18       delta 1.0e-3   logits 1.2e-3   adversarial loss 7.9e-7
+    TOL_D, TOL_L, TOL_A = (1e-3, 1e-3, 1e-3) if dtype == "f32" else (1e-2, 2.5e-2, 5e-4) if arch == "r2plus1d_18" else (3e-3, 4e-3, 5e-5)
     eng = FlickerVideoResNet(arch, W, batch_size=1, sample_length=T, image_size=HW, dtype=dtype, l_inf_pert_norm=0.2)
     eng.pert_model.init_perturbation(np.zeros((3, T, 1, 1), np.float32))      # (the default start is U(-1,1)*1e-6, model.py:121-126)
     crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)
@@ -168,7 +179,7 @@ def test_videoresnet_attack_trajectory_well_conditioned(dtype):
         worst = [max(a, b) for a, b in zip(worst, (e_d, e_l, e_a))]
         print(f"[{dtype}] iter {it + 1}: adv {res['adv_loss']:.7f} (fp64 oracle {t64[it]['adv']:.7f}); delta max-rel {e_d:.2e}; logits max-rel {e_l:.2e} "
               f"(torch-CPU fp32 oracle delta {rel_err(t32[it]['delta'], t64[it]['delta']):.2e})")
-    print(f"[{dtype}] worst over {steps} iterations: delta {worst[0]:.2e}, logits {worst[1]:.2e}, adversarial loss {worst[2]:.2e}")
+    print(f"[{arch} {dtype}] worst over {steps} iterations: delta {worst[0]:.2e}, logits {worst[1]:.2e}, adversarial loss {worst[2]:.2e}")
     assert worst[0] < TOL_D and worst[1] < TOL_L and worst[2] < TOL_A
 
 
@@ -178,7 +189,10 @@ def test_videoresnet_bf16_small_delta_reaches_the_logits():
     inside its ulp: a delta far below half an ulp still flips the fraction delta/ulp of the pixels, and the change of the logits
     -- a sum over 2e5 pixels per frame -- follows the fp32 change.  Measured here for |delta| from 1e-4 up to the reference's start value
     (U(+-0.005), model.py:946-948) and beyond: relative error of the bf16 logit CHANGE against the fp32 engine's, on the
-    well-conditioned fixture.  Asserted: at the reference's start amplitude 0.005 and above the change agrees within 25 %."""
+    well-conditioned fixture.
+    Round 4: the bf16 plans read the clip as TWO bf16 numbers per value (flk_apply_args.fold_t = 4: hi + lo against the same stem weights),
+    i.e. x + delta/std to ~16 bits, so the bf16 logit CHANGE follows the fp32 engine's from |delta| = 1e-4 (where one bf16 per value
+    moved the logits with the WRONG SIGN) upwards.  Asserted at every amplitude: right direction (cosine > 0.9) and within 25 %."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from flickering_adversarial_video_amd import videoresnet_spec as vs
@@ -205,7 +219,7 @@ def test_videoresnet_bf16_small_delta_reaches_the_logits():
         cos = float(torch.nn.functional.cosine_similarity(c16.flatten(), c32.flatten(), 0))
         errs.append(e)
         print(f"|delta| = {a:g}: logit change fp32 |.| {float(c32.norm()):.3e}, bf16 {float(c16.norm()):.3e}; rel-L2 error {e:.3f}, cosine {cos:.4f}")
-    assert errs[3] < 0.25 and errs[4] < 0.25
+        assert cos > 0.9 and e < 0.25, (a, e, cos)
 
 
 @pytest.mark.gpu
