@@ -183,8 +183,30 @@ def parity_check(device):
     return out
 
 
+def _plan_roofline(net, stepfn, reps=2):
+    """roofline block of a plan from its per-launch profile (HIP events around every launch, serial mode): the convolution-class
+    launches' algorithmic flops over their summed durations against the bf16 MFMA peak, and the three slowest launches"""
+    net.profile(True)
+    acc = {}
+    for _ in range(reps):
+        stepfn()
+        for i, r in enumerate(net.profile_read()):
+            e = acc.setdefault((i, r["name"], r["pass"], r["kind"]), {"ms": 0.0, "flops": r["flops"]})
+            e["ms"] += r["ms"] / reps
+    net.profile(False)
+    conv = {k: v for k, v in acc.items() if k[3] == "conv"}
+    ms, fl = sum(v["ms"] for v in conv.values()), sum(v["flops"] for v in conv.values())
+    slow = sorted(conv.items(), key=lambda kv: -kv[1]["ms"])[:3]
+    return {"kernel": "conv_igemm_kernel family (every convolution-class launch of the plan)", "bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_TFLOPS["bf16"],
+            "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_TFLOPS["bf16"], "traffic": None, "launches_per_step": len(conv), "conv_ms_per_step": ms,
+            "serial_ms_all_kernels": sum(v["ms"] for v in acc.values()),
+            "slowest": [{"op": k[1], "pass": k[2], "ms": v["ms"], "TFLOPs": v["flops"] / v["ms"] / 1e9} for k, v in slow]}
+
+
 def other_configs(device, steps=10, warmup=3):
-    """BASELINE configs 2 and 3 in the same run (single-video attacks: no collective): ms per iteration and conv TFLOP/s"""
+    """BASELINE configs 2 and 3 in the same run (single-video attacks: no collective): ms per iteration and conv TFLOP/s; the reference's
+    own shapes beside them -- I3D at its default clip length T = 90 (kinetics_i3d_utils.py:12) and the universal attack's mc3_18 at 16
+    clips per device (r2plus1d_main_universal_attack.py:30-33,130-149) -- each with a roofline block from its per-launch profile"""
     from flickering_adversarial_video_amd import i3d_spec, videoresnet_spec as vs
     from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
     from flickering_adversarial_video_amd.torch_attack import FlickerVideoResNet, Losses
@@ -205,7 +227,8 @@ def other_configs(device, steps=10, warmup=3):
     labels = eng.logits(x, adv_flag=0.0).argmax(-1).clone()
     sec = timed(lambda: eng.step(x, labels))
     out["config2_i3d_single_video_bs1_64x224x224_bf16"] = {"ms_per_iter": sec * 1e3, "iters_per_s": 1 / sec, "conv_tflops": conv_gflop_per_clip(64) / sec / 1e3,
-                                                          "conv_frac_of_mfma_peak": conv_gflop_per_clip(64) / sec / 1e3 / PEAK_TFLOPS["bf16"]}
+                                                          "conv_frac_of_mfma_peak": conv_gflop_per_clip(64) / sec / 1e3 / PEAK_TFLOPS["bf16"],
+                                                          "roofline": _plan_roofline(eng.net, lambda: eng.step(x, labels))}
     del eng
     # config 2 as the reference's users run it -- MANY videos, one after another (i3d_adversarial_main_single_video_npy.py:103-337) -- with 8
     # independent single-video attacks advancing in one batch (per-clip perturbations / Adam states; each video's trajectory is the one
@@ -226,7 +249,8 @@ def other_configs(device, steps=10, warmup=3):
     crit = Losses(beta_1=0.5, lambda_=1.0, margin=0.05, improve_loss=True, logits=True)
     sec = timed(lambda: eng.step(xv, lab, crit))
     out["config3_r2plus1d_18_single_video_bs1_16x112x112_bf16"] = {"ms_per_iter": sec * 1e3, "iters_per_s": 1 / sec, "conv_tflops": VRN_GFLOP["r2plus1d_18"] / sec / 1e3,
-                                                                  "conv_frac_of_mfma_peak": VRN_GFLOP["r2plus1d_18"] / sec / 1e3 / PEAK_TFLOPS["bf16"]}
+                                                                  "conv_frac_of_mfma_peak": VRN_GFLOP["r2plus1d_18"] / sec / 1e3 / PEAK_TFLOPS["bf16"],
+                                                                  "roofline": _plan_roofline(eng.net, lambda: eng.step(xv, lab, crit))}
     del eng
     # config 3 with 8 independent single-video attacks per batch (fit_many_videos(batch): per-clip perturbation / clamp bound / Adam state)
     engb = FlickerVideoResNet("r2plus1d_18", W, batch_size=8, sample_length=16, image_size=112, dtype="bf16", device=device, per_clip=True)
@@ -235,9 +259,35 @@ def other_configs(device, steps=10, warmup=3):
     secb = timed(lambda: engb.step(xb, lb, crit))
     out["config3_batched_8_independent_single_video_attacks"] = {"ms_per_iter": secb * 1e3, "clip_iters_per_s": 8 / secb,
                                                                   "speedup_over_one_by_one": (8 / secb) * sec,
-                                                                  "conv_tflops": 8 * VRN_GFLOP["r2plus1d_18"] / secb / 1e3}
-    del engb
+                                                                  "conv_tflops": 8 * VRN_GFLOP["r2plus1d_18"] / secb / 1e3,
+                                                                  "conv_frac_of_mfma_peak": 8 * VRN_GFLOP["r2plus1d_18"] / secb / 1e3 / PEAK_TFLOPS["bf16"],
+                                                                  "roofline": _plan_roofline(engb.net, lambda: engb.step(xb, lb, crit))}
+    del engb, xb
     torch.cuda.empty_cache()
+    # the reference's universal attack on torchvision's mc3_18 (BASE_MODEL = "mc3_18", 16-20 clips per device,
+    # r2plus1d_main_universal_attack.py:30-33,130-149): ONE shared perturbation, batch 16, 16 x 112 x 112
+    Wm = vs.synthetic_weights("mc3_18", 42)
+    engm = FlickerVideoResNet("mc3_18", Wm, batch_size=16, sample_length=16, image_size=112, dtype="bf16", device=device)
+    xm = torch.from_numpy(vs.synthetic_clip(16, 16, seed=1234)).cuda()
+    lm = engm.logits(xm).argmax(-1).clone()
+    secm = timed(lambda: engm.step(xm, lm, crit))
+    out["mc3_18_universal_bs16_16x112x112_bf16"] = {"ms_per_iter": secm * 1e3, "clip_iters_per_s": 16 / secm, "conv_tflops": 16 * VRN_GFLOP["mc3_18"] / secm / 1e3,
+                                                    "conv_frac_of_mfma_peak": 16 * VRN_GFLOP["mc3_18"] / secm / 1e3 / PEAK_TFLOPS["bf16"],
+                                                    "roofline": _plan_roofline(engm.net, lambda: engm.step(xm, lm, crit))}
+    del engm, xm
+    torch.cuda.empty_cache()
+    # I3D at the reference's default clip length (_SAMPLE_VIDEO_FRAMES = 90, kinetics_i3d_utils.py:12): T/2 = 45, 23, 12 are odd, so
+    # the strided pools take their general-shape forms
+    for bsz in (8, 1):
+        e90 = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=bsz, frames=90, dtype="bf16", device=device)
+        x90 = torch.from_numpy(i3d_spec.synthetic_clip_u8(bsz, 90, seed=1234)).cuda()
+        l90 = e90.logits(x90, adv_flag=0.0).argmax(-1).clone()
+        s90 = timed(lambda: e90.step(x90, l90))
+        out[f"i3d_T90_bs{bsz}_90x224x224_bf16"] = {"ms_per_iter": s90 * 1e3, "clip_iters_per_s": bsz / s90, "conv_tflops": bsz * conv_gflop_per_clip(90) / s90 / 1e3,
+                                                    "conv_frac_of_mfma_peak": bsz * conv_gflop_per_clip(90) / s90 / 1e3 / PEAK_TFLOPS["bf16"],
+                                                    "roofline": _plan_roofline(e90.net, lambda: e90.step(x90, l90))}
+        del e90, x90
+        torch.cuda.empty_cache()
     return out
 
 

@@ -40,6 +40,9 @@ def short(name):
     m = re.search(r"conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)E", name)          # mangled: <T, NF, WN, MODE>
     if m:
         return "conv_igemm_kernel<%s,NF=%s,WN=%s,MODE=%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3), m.group(4))
+    m = re.search(r"conv_igemm_group_kernelI(DF16b|f)Li(\d+)E", name)                      # mangled: <T, NFW>
+    if m:
+        return "conv_igemm_group_kernel<%s,NFW=%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2))
     m = re.search(r"conv_igemm_kernel<([^>]*)>", name)
     if m:
         return "conv_igemm_kernel<" + m.group(1).replace("__hip_bfloat16", "bf16").replace(" ", "") + ">"

@@ -12,7 +12,7 @@ def agg(path, counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"]
-        key = next((k for k in ("conv_igemm_kernel", "conv1x1_dma_kernel", "stem_fwd_u8_kernel", "stem_delta_grad_kernel", "stem_mask_kernel") if k in n), None) \
+        key = next((k for k in ("conv_igemm_group_kernel", "conv_igemm_kernel", "conv1x1_dma_kernel", "stem_fwd_u8_kernel", "stem_delta_grad_kernel", "stem_mask_kernel") if k in n), None) \
             or n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
         d[key][0] += 1
         d[key][1] += float(r["Counter_Value"])
