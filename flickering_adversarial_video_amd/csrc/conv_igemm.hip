@@ -296,11 +296,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
   static_assert(4 * NFW >= EPL, "wave tile too narrow for 16-byte epilogue groups");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // small halos (P <= 256: all 1x1x1 convolutions) keep TWO halo images so the K loop needs one barrier per slab
-  // (MODE 5: mode 0 with the two-image pipeline up to 512 halo positions -- eight prefetch registers per thread instead of four -- for
-  //  convolutions with few taps: the (1,3,3) / (3,1,1) halves of a VideoResNet (2+1)D unit run 9 / 3 taps per staged slab, far too
-  //  little work to hide a staging round trip behind)
-  constexpr int NPRE = MODE == 5 ? 8 : 4;
-  const bool small_halo = p.P <= 64 * NPRE;
+  const bool small_halo = p.P <= 256;
   const int halo_bytes = 4 * p.plane_b + 64;
   char* const halo = smem;
   char* const wbuf = smem + (small_halo ? 2 : 1) * halo_bytes;
@@ -407,7 +403,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
   const size_t wstep = (size_t)p.cout_frags * 1024;
   const int nsteps = nslab * p.ntaps;
   const char* const wbase = p.w + (size_t)s_lo * p.ntaps * wstep;
-  if constexpr (MODE == 0 || MODE == 5) {
+  if constexpr (MODE == 0) {
     // ---- wide wave tiles (>= 32 MFMAs per K step): weights through a double-buffered LDS tile shared by the 4 waves,
     // register prefetch one step ahead, nested tap loops.
     // weight stream: (slab, tap) step k lives at w + (k*cout_frags + ntile*NF) KiB.  Every thread moves WCH 16-byte
@@ -423,16 +419,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     // slab s+1 is fetched into named registers while slab s computes, so the K loop does not expose one global-load
     // latency per slab.  Larger halos are staged after the barrier (amortised over kt*kh*kw taps; the second resident
     // workgroup covers the stall).
-    uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0, pre4 = pre0, pre5 = pre0, pre6 = pre0, pre7 = pre0;
+    uint4 pre0 = make_uint4(0, 0, 0, 0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
     auto prefetch = [&](int s) {
       const char* src; int ld;
       const bool chvalid = slab_src(s, src, ld);
       pre0 = ldhalo(src, ld, goff[0], chvalid); pre1 = ldhalo(src, ld, goff[1], chvalid);
       pre2 = ldhalo(src, ld, goff[2], chvalid); pre3 = ldhalo(src, ld, goff[3], chvalid);
-      if constexpr (NPRE == 8) {
-        pre4 = ldhalo(src, ld, goff[4], chvalid); pre5 = ldhalo(src, ld, goff[5], chvalid);
-        pre6 = ldhalo(src, ld, goff[6], chvalid); pre7 = ldhalo(src, ld, goff[7], chvalid);
-      }
     };
     if (small_halo) prefetch(0);
     for (int s = 0; s < nslab; ++s) {
@@ -444,12 +436,6 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         if (goff[1] != -2) *(uint4*)(hd + 1024) = pre1;
         if (goff[2] != -2) *(uint4*)(hd + 2048) = pre2;
         if (goff[3] != -2) *(uint4*)(hd + 3072) = pre3;
-        if constexpr (NPRE == 8) {
-          if (goff[4] != -2) *(uint4*)(hd + 4096) = pre4;
-          if (goff[5] != -2) *(uint4*)(hd + 5120) = pre5;
-          if (goff[6] != -2) *(uint4*)(hd + 6144) = pre6;
-          if (goff[7] != -2) *(uint4*)(hd + 7168) = pre7;
-        }
         if (s + 1 < nslab) prefetch(s + 1);
       } else {
         __syncthreads();  // every wave has finished reading the previous slab's halo
@@ -1156,11 +1142,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   // narrow channel tiles (nf = 2) are latency-bound: keep their halo <= 768 so that 3 workgroups fit a CU's LDS
   // the folded stem (mode 4): 192-row tiles (three computing waves, the fourth only stages) with a halo <= 704 keep the
   // workgroup at 53 KiB of LDS, i.e. THREE per CU instead of two: measured 0.62 vs 0.655 ms (4x6x8 vs 4x8x8 tiles)
-  // few taps per staged slab (the (1,3,3) / (3,1,1) halves of a (2+1)D unit, bf16): halos of at most 512 positions, which the ring
-  // kernels then double-buffer (mode 5) instead of staging each slab behind a barrier.  FLK_CONV_PIPE512=0: off
-  static const int pipe512 = getenv("FLK_CONV_PIPE512") ? atoi(getenv("FLK_CONV_PIPE512")) : 1;
-  const bool few_taps = pipe512 && dtype == FLK_BF16 && !w->stem4 && w->ntaps > 1 && w->ntaps <= 9 && (nf == 2 || nf == 4);      // (nf = 8: 256 VGPRs + scratch with eight prefetch registers)
-  const int max_halo = w->stem4 ? 704 : few_taps ? 512 : nf == 2 ? 768 : FLK_MAX_HALO;
+  const int max_halo = w->stem4 ? 704 : nf == 2 ? 768 : FLK_MAX_HALO;
   // narrow channel tiles (nf = 2) likewise run faster on 192-row tiles (measured -4...-8 % on every nf = 2 layer; nf = 4 / 8
   // layers lose 10-15 % with them)
   const int max_rows = (w->stem4 || nf == 2) ? 192 : FLK_ROWS;
@@ -1273,9 +1255,8 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
 #undef FLK_LAUNCH_DMA
     }
   }
-  if (mode == 0 && few_taps && kp.P > 256 && kp.P <= 512) mode = 5;
   // two halo images for small halos; the LDS weight ring only in mode 0
-  const size_t lds = ((kp.P <= 256 || mode == 5) ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4 || mode == 5) ? 2 * (size_t)nf * 1024 : 0);
+  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4) ? 2 * (size_t)nf * 1024 : 0);
   {
     static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
     if (dbg)
@@ -1313,8 +1294,6 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
     if (mode == 4 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 4>(kp, grid, lds, s);
-    if (mode == 5 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 5>(kp, grid, lds, s);
-    if (mode == 5 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 5>(kp, grid, lds, s);
     FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1); FLK_LAUNCH0(bf16_t, 6, 1);
     FLK_LAUNCHD(bf16_t, 2, 1); FLK_LAUNCHD(bf16_t, 4, 1); FLK_LAUNCHD(bf16_t, 4, 2);
     FLK_LAUNCHD(bf16_t, 8, 2); FLK_LAUNCHD(bf16_t, 8, 4);
