@@ -631,7 +631,7 @@ int flk_net::build_i3d() {
     // FLK_GROUP_ROWS: largest position count that is grouped (default: below the Mixed_3* size)
     static const long group_rows = getenv("FLK_GROUP_ROWS") ? atol(getenv("FLK_GROUP_ROWS")) : 256L * 256 - 1;
     GroupLayout gf, gb;
-    static const long group_min_rows = getenv("FLK_GROUP_MIN_ROWS") ? atol(getenv("FLK_GROUP_MIN_ROWS")) : 4096;
+    static const long group_min_rows = getenv("FLK_GROUP_MIN_ROWS") ? atol(getenv("FLK_GROUP_MIN_ROWS")) : 8192;      // (below: Mixed_5*, 3136 positions at T = 64 and 4704 at T = 90 -- split-K launches)
     static const int group_dirs = getenv("FLK_GROUP") ? atoi(getenv("FLK_GROUP")) : 3;      // bit 0: forward, bit 1: data-gradients
     if (rows_blk <= group_rows && rows_blk >= group_min_rows) {
       if (group_dirs & 1) gf = plan_group(cur, c1a, c1b, bk.c[4]);
@@ -968,7 +968,8 @@ int flk_net::build_videoresnet() {
   // bf16: the clip arrives as TWO bf16 numbers per value (flk_apply_args.fold_t = 4: channels [0,16) = bf16(x_adv), [16,32) = the
   // remainder), both halves against the same weights -- the stem's K step had 32 channels anyway (16 padded): same MFMA work, the
   // perturbed clip to ~16 bits.  The data-gradient keeps the 16-channel operator (its output is the gradient of x_adv).
-  const bool hilo = dtype == FLK_BF16;
+  static const bool hilo_off = getenv("FLK_VRN_HILO") && atoi(getenv("FLK_VRN_HILO")) == 0;      // (A/B: one bf16 number per value, the round-3 input)
+  const bool hilo = dtype == FLK_BF16 && !hilo_off;
   flk_conv_weights* stem_wf = stem->wf;
   if (hilo) {
     std::vector<float> w2((size_t)skt * 16 * 32 * stem->cout);
