@@ -142,7 +142,9 @@ static void plan(int arch, int dtype, int B, int T, int HW, const std::map<std::
   EXPECT(flk_net_set_weight(n, "x", W.begin()->second.data(), 1) == FLK_EINVAL, "%s set_weight after finalize", tag);
   EXPECT(flk_net_workspace_bytes(n) > 0 && flk_net_num_classes(n) == 400, "%s queries", tag);
   const int64_t nin = flk_net_input_numel(n);
-  EXPECT(nin == (arch == FLK_NET_I3D ? (int64_t)B * (T / 2) * (HW / 2) * (HW / 2) * 32 : (int64_t)B * T * (HW / 2) * (HW / 2) * 16), "%s input numel", tag);
+  // (VideoResNet plans: the (h,w)-folded clip, 16 channels -- 32 in bf16, where every value arrives as two bf16 numbers, fold_t = 4)
+  EXPECT(nin == (arch == FLK_NET_I3D ? (int64_t)B * (T / 2) * (HW / 2) * (HW / 2) * 32
+                                     : (int64_t)B * T * (HW / 2) * (HW / 2) * (dtype == FLK_BF16 ? 32 : 16)), "%s input numel", tag);
   std::vector<char> x((size_t)nin * 4), gx((size_t)nin * 4);
   std::vector<float> lg((size_t)B * 400), dl((size_t)B * 400, 0.01f);
   const long l0 = flk_stub_launches();
@@ -196,6 +198,22 @@ static void plan(int arch, int dtype, int B, int T, int HW, const std::map<std::
     EXPECT(flk_net_forward_apply(n, &wrong, x.data(), lg.data(), nullptr) == FLK_EINVAL, "%s forward_apply layout check", tag);
     flk_apply_args bad = a; bad.T = T + 2;
     EXPECT(flk_net_backward_delta(n, dl.data(), &bad, gd.data(), scratch.data(), nullptr) == FLK_EINVAL, "%s backward_delta geometry check", tag);
+  }
+  if (arch != FLK_NET_I3D) {
+    // the VideoResNet input path with a real apply struct: fp32 clip, torch-dialect perturbation; bf16 plans take the clip as two bf16
+    // numbers per value (fold_t = 4, 32 channels), fp32 plans the 16-channel fold; the gradient comes back in the 16-channel layout
+    std::vector<float> clip((size_t)B * T * HW * HW * 3, 0.25f), delta((size_t)T * 3, 0.01f), gd((size_t)T * 3);
+    std::vector<float> scratch((size_t)flk_perturb_grad_scratch_bytes(B, T, HW, HW) / 4 + 16);
+    flk_apply_args a{};
+    a.x = clip.data(); a.x_scale = 1.f; a.delta = delta.data(); a.dclip = 0.2f;
+    a.inv_std[0] = a.inv_std[1] = a.inv_std[2] = 4.5f; a.lo = -1.7f; a.hi = 2.4f; a.adv_flag = 1.f; a.B = B; a.T = T; a.H = HW; a.W = HW;
+    a.fold_t = dtype == FLK_BF16 ? 4 : 1;
+    EXPECT(flk_net_forward_apply(n, &a, x.data(), lg.data(), nullptr) == FLK_OK, "%s forward_apply (fold_t %d)", tag, a.fold_t);
+    EXPECT(flk_net_backward(n, dl.data(), gx.data(), nullptr) == FLK_OK, "%s backward behind forward_apply", tag);
+    EXPECT(flk_perturb_grad_reduce(&a, gx.data(), dtype, gd.data(), scratch.data(), nullptr) == FLK_OK, "%s grad_reduce (16-channel gradient layout)", tag);
+    flk_apply_args wrong = a; wrong.fold_t = dtype == FLK_BF16 ? 1 : 4;
+    EXPECT(flk_net_forward_apply(n, &wrong, x.data(), lg.data(), nullptr) == FLK_EINVAL, "%s forward_apply layout check", tag);
+    if (dtype == FLK_F32) { flk_apply_args hl = a; hl.fold_t = 4; EXPECT(flk_perturb_apply_s2d(&hl, x.data(), FLK_F32, nullptr) == FLK_EINVAL, "%s fold_t 4 is bf16 only", tag); }
   }
   EXPECT(flk_net_destroy(n) == FLK_OK, "%s destroy", tag);
   EXPECT(flk_stub_live_allocs() == a0, "%s: %ld device allocations leaked", tag, flk_stub_live_allocs() - a0);
