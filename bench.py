@@ -477,6 +477,8 @@ def main():
         out["roofline"] = {"kernel": "conv_igemm_kernel (implicit-GEMM conv3d fwd + dgrad with LDS halo tiles: every 3x3x3 / strided layer)", "bound": "mfma",
                            "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.dtype],
                            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, gfx950-corrected)", "traffic_source": traffic_src,
+                           "compulsory_bytes_per_launch": ig["bytes"] / ig["launches"] if ig.get("bytes") else None,
+                           "traffic_over_compulsory": traffic / (ig["bytes"] / ig["launches"]) if (traffic and ig.get("bytes")) else None,
                            "launches_per_step": ig["launches"] // reps, "avg_launch_ms": ig["ms"] / ig["launches"],
                            "conv_ms_per_step": cv["ms"] / reps, "algorithmic_gflop_per_step": cv["flops"] / reps / 1e9,
                            "all_conv_achieved": cv["flops"] / (cv["ms"] * 1e-3) / 1e12}

@@ -372,6 +372,10 @@ struct flk_net {
     int nf1 = nf_for(cout1, 27, rows);
     if (nf1 == 6) nf1 = 4;
     int wn1 = 1, mode = 0;
+    // a large member the heuristics give the LDS weight ring (Mixed_4e / 4f forward: 560 workgroups) stays a launch of its own: as a
+    // direct-A member of a group it ran 0.120 / 0.122 ms against 0.092 + 0.019 / 0.091 + 0.022 ms for the two launches (FLK_GROUP_RING=1: group anyway)
+    static const bool ring_too = getenv("FLK_GROUP_RING") && atoi(getenv("FLK_GROUP_RING"));
+    if (!ring_too && (flk_conv_layout_query(&a, nf1, dtype, -1, &wn1, &mode) != FLK_OK || mode != 1)) return g;
     if (flk_conv_layout_query(&a, nf1, dtype, 1, &wn1, &mode) != FLK_OK || mode != 1) return g;
     int nfw = nf1 / wn1;
     if (nfw == 8) nfw = 4;                              // (nf 8 on 256-row tiles: two waves along the channels instead)
