@@ -426,13 +426,19 @@ __global__ __launch_bounds__(SG_THREADS, 2) void stem_delta_grad_kernel(const St
 // ---- host side ------------------------------------------------------------------------------------------------------------
 int flk_grad_reduce_stage2_launch(const flk_apply_args* a, int nchunk, const float* partials, float* gdelta, hipStream_t s);   // attack.hip
 
+// chunks of output rows per (clip, output frame): one 512-thread workgroup fits a CU, so the launch runs in ceil(workgroups / 256)
+// rounds of 1 / n of a full K loop each.  n minimises rounds / n, with 3 % per extra chunk for the mask rows chunks re-read: 256 (clip,
+// frame) pairs (bs 8, T = 64) keep n = 1; the reference's T = 90 at bs 8 -- 360 pairs, two rounds for 1.41 rounds of work -- takes
+// n = 2 (three rounds of half length: 0.74 -> 0.57 ms); 32 pairs (bs 1, T = 64) n = 8 as before.
 static int sg_nchunk(int B, int T, int Ho) {
   const int pairs = B * (T / 2);
-  int n = (256 + pairs - 1) / pairs;           // one workgroup per CU when the batch fills the chip: the K loop is as long as it gets
-  if (n > 16) n = 16;
-  if (n > Ho) n = Ho;
-  if (n < 1) n = 1;
-  return n;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int n = 1; n <= 16 && n <= Ho; ++n) {
+    const double cost = (double)((pairs * n + 255) / 256) / n * (1.0 + 0.03 * n);
+    if (cost < best_cost - 1e-12) { best_cost = cost; best = n; }
+  }
+  return best;
 }
 
 static int64_t sg_partial_bytes(int B, int T, int H) {
