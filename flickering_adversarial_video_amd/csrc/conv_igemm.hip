@@ -1013,6 +1013,156 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The temporal half of a (2+1)D unit -- a (3,1,1) convolution, stride 1, pad 1 (torchvision Conv2Plus1D, reference call site
+// model.py:421; forward and data-gradient) -- through an LDS-DMA ring like conv1x1_dma_kernel's.  The halo kernels give these layers 3 K
+// steps per staged slab (2.0-2.2 TB/s of compulsory bytes at layer1).  Here a workgroup owns ALL T frames of G groups of 16 consecutive
+// spatial positions (T * G = 16 fragments of 16 positions = 256 rows; T = 16 / 8 / 4 / 2), a ring slot holds one 32-channel slab of them
+// -- 16 one-KiB DMA pieces, one per (group, frame): 16 positions x 64 bytes, contiguous in memory but for the channel stride -- plus the
+// slab's three taps of weights; tap dt of output frame t reads piece t + dt - 1 of its group, the pieces for t = -1 and t = T are zeros
+// written once per slot and never fetched: no halo bytes at all, 48 NF / 4 MFMAs per wave between two barriers, R - 1 slabs in flight.
+template <int NF, int R>
+__global__ __launch_bounds__(256, 1) void conv_t3_dma_kernel(const ConvKP p) {
+  typedef Prec<bf16_t> PR;
+  typedef typename PR::frag frag;
+  constexpr int EPL = 8;
+  constexpr int NWP = 3 * NF / 4;                // weight pieces per wave per slab (three taps)
+  constexpr int NPW = 4 + NWP;                   // DMA instructions per wave per slab
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane >> 4, m = lane & 15;
+  const int T = p.Ti, G = 16 / T, HW = p.Hi * p.Wi, nch = HW >> 4;     // nch 16-position chunks per frame
+  const int WOFF = (16 + 2 * G) * 1024, SLOT = WOFF + 3 * NF * 1024;
+  int ptile, ntile;
+  {
+    const int per = 8 * p.ntile_n, id = blockIdx.x;
+    const int grp = id / per, r = id - grp * per;
+    ntile = r >> 3;
+    ptile = grp * 8 + (r & 7);
+  }
+  const int tpc = (nch + G - 1) / G;             // tiles per clip
+  if (ptile >= p.B * tpc) return;
+  const int b = ptile / tpc, sp = ptile - b * tpc;
+  const unsigned lds0 = lds_addr32(smem);
+
+  // zero pieces (frames -1 and T of every group) of every slot: written once, never overwritten by a DMA
+  for (int i = tid; i < R * 2 * G * 64; i += 256) {
+    const int slot = i / (2 * G * 64), r = i - slot * (2 * G * 64), g = r / 128, e = r - g * 128;
+    const int piece = g * (T + 2) + (e >> 6) * (T + 1);
+    *(uint4*)(smem + slot * SLOT + piece * 1024 + (e & 63) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  }
+
+  // ---- this wave's four fragments f = 4 wave + i = (group g, frame t); a group beyond the frame's last chunk is clamped (never stored) ----
+  const int gsw[4] = {0, 3, 2, 1};
+  const int cs = (lane & 3) ^ gsw[(lane >> 4) & 3];        // the chunk this lane fetches into slot lane & 3 of position lane >> 2
+  unsigned voff[4];
+  int lpiece[4];
+  bool fvalid[4];
+  unsigned fpos[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = 4 * wave + i, g = f / T, t = f - g * T;
+    int c16 = sp * G + g;
+    fvalid[i] = c16 < nch;
+    c16 = c16 < nch ? c16 : nch - 1;
+    const unsigned base = (unsigned)((b * T + t) * HW + c16 * 16);
+    voff[i] = ((base + (unsigned)(lane >> 2)) * (unsigned)p.in_ld + (unsigned)(p.in_coff + cs * EPL)) * 2u;
+    fpos[i] = base + (unsigned)m;
+    lpiece[i] = __builtin_amdgcn_readfirstlane(g * (T + 2) + t + 1);      // (wave-uniform: it goes into m0)
+  }
+  const size_t wstep = (size_t)p.cout_frags * 1024;
+  const int nslab = p.nslab;
+  unsigned wvoff[NWP];                            // byte offset of this lane's 16 bytes of weight piece j = wave + 4 k inside a slab's three taps
+#pragma unroll
+  for (int k = 0; k < NWP; ++k) {
+    const int j = wave + 4 * k, dt = j / NF, f = j - dt * NF;
+    wvoff[k] = (unsigned)dt * (unsigned)wstep + (unsigned)((ntile * NF + f) * 1024 + lane * 16);
+  }
+  auto issue = [&](int sl, int slot) {
+    const char* const base = p.in + (size_t)sl * 64;
+    const unsigned adj = sl * 32 + cs * EPL < p.cin ? 0u : (unsigned)(-(cs * 16));
+    const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(slot * SLOT)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(voff[i] + adj, base, sb + (unsigned)(lpiece[i] * 1024));
+    // weights of (slab sl, tap dt), fragment f of this channel tile: piece j = wave + 4 k of the 3 NF pieces (dt = j / NF, f = j % NF)
+    const char* const wb = p.w + (size_t)sl * 3 * wstep;
+#pragma unroll
+    for (int k = 0; k < NWP; ++k) glds16(wvoff[k], wb, sb + (unsigned)(WOFF + (wave + 4 * k) * 1024));
+  };
+
+  f32x4 acc[NF][4];
+#pragma unroll
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // B fragment of (fragment i, tap dt): piece lpiece[i] + dt - 1, row m, chunk q (swizzled like the DMA image)
+  int boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) boff[i] = (lpiece[i] - 1) * 1024 + m * 64 + ((q ^ gsw[(m >> 2) & 3]) * 16);
+
+  int islot = 0;
+#pragma unroll
+  for (int k = 0; k < R - 1; ++k) {
+    if (k < nslab) issue(k, islot);
+    islot = islot + 1 == R ? 0 : islot + 1;
+  }
+  int cslot = 0;
+  for (int k = 0; k < nslab; ++k) {
+    // this wave's pieces of slab k have landed once at most the pieces of the min(R - 2, nslab - 1 - k) younger slabs are outstanding
+    const int younger = nslab - 1 - k < R - 2 ? nslab - 1 - k : R - 2;
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPW) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                              // everybody's pieces (and, first time, the zero pieces) are visible; the slot issued into next is free
+    if (k + R - 1 < nslab) issue(k + R - 1, islot);
+    islot = islot + 1 == R ? 0 : islot + 1;
+    const char* const sb = smem + cslot * SLOT;
+    cslot = cslot + 1 == R ? 0 : cslot + 1;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      frag bf[4], af[NF];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(sb + boff[i] + dt * 1024);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) af[f] = *(const frag*)(sb + WOFF + ((dt * NF + f) * 64 + lane) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
+    }
+  }
+
+  // ---- epilogue (conv1x1_dma_kernel's) ----
+  constexpr int NG = 4 * NF / EPL;
+  const int cbase = ntile * 16 * NF + q * EPL;
+  constexpr bool PRE = NG <= 3;
+  float4 sc[PRE ? NG : 1][2], bi[PRE ? NG : 1][2];
+  if (PRE) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int c = cbase + g * 4 * EPL, cc = c < p.cout ? c : 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        sc[g][h] = p.scale ? *(const float4*)(p.scale + cc + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);
+        bi[g][h] = p.bias ? *(const float4*)(p.bias + cc + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!fvalid[i]) continue;
+    float v[NG][EPL];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
+    if constexpr (PRE) finish_store_row_pre<bf16_t, NG>(p, (size_t)fpos[i], cbase, v, sc, bi);
+    else finish_store_row<bf16_t, NG>(p, (size_t)fpos[i], nullptr, cbase, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows, int max_halo) {
   if (max_halo <= 0 || max_halo > FLK_MAX_HALO) max_halo = FLK_MAX_HALO;
   if (max_rows <= 0 || max_rows > FLK_ROWS) max_rows = FLK_ROWS;
@@ -1225,6 +1375,38 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     if (w->stem4) mode = 4;
     else if (da) mode = k1 ? 2 : 1;
     else if (k1 && kp.nslab >= 4 && !no_k1) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
+  }
+  // (3,1,1) convolutions, stride 1, pad 1 (the temporal half of a (2+1)D unit) whose frames split into 16-position chunks: the LDS-DMA
+  // ring over whole-T tiles (conv_t3_dma_kernel).  FLK_CONV_T3DMA=0: the halo kernels; =R: ring slots.  Measured (r2plus1d_18, bs 8, same
+  // box): halo kernels 4.72 ms per step; R = 2 (60 KB of LDS at nf 4: two workgroups per CU) 4.42; R = 3 / 4 (one per CU, two / three
+  // slabs in flight) 4.82 / 4.89 -- once more the second resident workgroup is worth more than the deeper pipeline
+  {
+    static const int t3_on = getenv("FLK_CONV_T3DMA") ? atoi(getenv("FLK_CONV_T3DMA")) : 2;
+    const bool flat3 = a->kt == 3 && a->kh == 1 && a->kw == 1 && a->st == 1 && a->sh == 1 && a->sw == 1 && a->pt == 1 && a->ph == 0 && a->pw == 0 &&
+                       a->ost == 1 && a->osh == 1 && a->osw == 1 && a->oot == 0 && a->ooh == 0 && a->oow == 0 && a->To == a->Ti && a->Ho == a->Hi &&
+                       a->Wo == a->Wi && a->OT == a->To && a->OH == a->Ho && a->OW == a->Wo;
+    const long npos = (long)a->B * a->To * a->Ho * a->Wo;
+    const int Tn = a->Ti, hw = a->Hi * a->Wi;
+    if (!plan && t3_on && dtype == FLK_BF16 && flat3 && !a->in2 && !a->out2 && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
+        (nf == 8 || nf == 4) && npos >= 2048 && npos < (1l << 23) && (Tn == 2 || Tn == 4 || Tn == 8 || Tn == 16) && hw % 16 == 0) {
+      const int Gn = 16 / Tn;
+      const long pt = (long)a->B * ((hw / 16 + Gn - 1) / Gn);
+      dim3 g((unsigned)((pt + 7) / 8 * 8 * ntile_n));
+      static bool attr_t3[6][FLK_MAX_DEVICES] = {};
+      const int Rr = t3_on == 3 ? 3 : t3_on == 4 ? 4 : 2;
+      const size_t l5 = (size_t)Rr * ((16 + 2 * Gn) * 1024 + 3 * nf * 1024);
+      if (dbg_on()) fprintf(stderr, "conv 3x1x1 cin %d cout %d positions %ld | nf %d LDS-DMA ring over whole-T tiles, R %d, lds %zu, wgs %ld\n", a->cin, a->cout, npos, nf, Rr, l5, pt * ntile_n);
+#define FLK_LAUNCH_T3(NFv, Rv, idx)                                                                                                \
+      if (nf == NFv && Rr == Rv && l5 <= 160 * 1024) {                                                                              \
+        if (int rc = flk_raise_lds_limit((const void*)conv_t3_dma_kernel<NFv, Rv>, 160 * 1024, attr_t3[idx])) return rc;           \
+        FLK_LAUNCH_KERNEL((conv_t3_dma_kernel<NFv, Rv>), g, dim3(256), l5, s, kp);                                                 \
+        flk_last_kernel_tag = "conv_t3_dma_kernel";                                                                                 \
+        FLK_CHECK_HIP(hipGetLastError());                                                                                           \
+        return FLK_OK;                                                                                                              \
+      }
+      FLK_LAUNCH_T3(4, 2, 0) FLK_LAUNCH_T3(4, 3, 1) FLK_LAUNCH_T3(4, 4, 2) FLK_LAUNCH_T3(8, 2, 3) FLK_LAUNCH_T3(8, 3, 4)
+#undef FLK_LAUNCH_T3
+    }
   }
   // 1x1x1 GEMMs over a flat position grid: both operands through the LDS-DMA ring (conv1x1_dma_kernel).  FLK_CONV_DMA=0: modes 2 / 3.
   {

@@ -583,3 +583,51 @@ def test_conv_group(ops, case):
     again = torch.zeros_like(out_g)
     ops.conv3d_group([(x_, w_, dict(k_, out=again)) for x_, w_, k_ in members], nfw)
     assert torch.equal(again, out_g)
+
+
+T3_CASES = [
+    # name, B, T, H, W, cin, cout, nf     -- (3,1,1) stride 1 pad 1, T in {16, 8, 4, 2}, H * W a multiple of 16, >= 2048 positions: the
+    # whole-T LDS-DMA ring (conv_t3_dma_kernel); tiles = all frames of 16 / T groups of 16 spatial positions
+    ("T16_144_64_layer1", 2, 16, 8, 8, 144, 64, 4),       # one group per tile; K = 4.5 slabs (the half slab fetches chunk 0 against zero weights)
+    ("T8_64_144_ragged", 4, 8, 12, 12, 64, 144, 4),       # two groups per tile, 9 chunks per frame: the last tile of a clip has ONE valid group; 2.25 channel tiles
+    ("T8_288_128_layer2", 2, 8, 16, 16, 288, 128, 8),     # nf = 8
+    ("T4_64_64", 2, 4, 16, 20, 64, 64, 4),                # four groups per tile
+    ("T2_64_64", 8, 2, 12, 12, 64, 64, 4),                # eight groups: every row has a zero-padded tap; partial last tile
+    ("T6_halo_fallback", 2, 6, 14, 14, 144, 64, 4),       # T = 6: the halo kernels (no ring instance), same test
+]
+
+
+@pytest.mark.parametrize("case", T3_CASES, ids=[c[0] for c in T3_CASES])
+def test_conv_temporal_dma(ops, case):
+    """conv_t3_dma_kernel: the temporal half of a (2+1)D unit.  Forward with the plan's epilogue (scale, bias, residual add, ReLU) and the
+    data-gradient form (transposed weights x BN scale, ReLU mask) against torch-CPU conv3d / its autograd at the bf16 tolerances; clip
+    boundaries (zero padding in t only, never across clips) are where a flat-position kernel can go wrong -- several clips per case.  And
+    bitwise against the halo kernel (the same weights packed in 32-channel tiles, which the ring does not take) -- same K order per output."""
+    _, B, T, H, W, cin, cout, nf = case
+    dtype = torch.bfloat16
+    x = q(rnd((B, T, H, W, cin), 51), dtype)
+    w = q(rnd((3, 1, 1, cin, cout), 52, (2.0 / (3 * cin)) ** 0.5), dtype)
+    sc, bi = rnd((cout,), 53).abs() + 0.5, rnd((cout,), 54, 0.1)
+    add = q(rnd((B, T, H, W, cout), 55), dtype)
+    ref = torch.relu(ref_conv(x, w, (1, 1, 1), (1, 0, 0), (T, H, W)) * sc + bi + add)
+    pw = ops.ConvWeights(w.numpy(), dtype, nf)
+    kw = dict(scale=sc.cuda(), bias=bi.cuda(), add=add.to(dtype).cuda(), relu=True)
+    out = ops.conv3d(x.to(dtype).cuda(), pw, **kw)
+    r, a = tol(dtype, ref)
+    torch.testing.assert_close(out.float().cpu(), ref, rtol=r, atol=a)
+    # data-gradient: g [.., cout] -> gx [.., cin], masked
+    a_scale = rnd((cout,), 56).abs() + 0.5
+    g = q(rnd((B, T, H, W, cout), 57), dtype)
+    mask = q(rnd((B, T, H, W, cin), 58), dtype)
+    xz = torch.zeros((B, T, H, W, cin), requires_grad=True)
+    (gx_ref,) = torch.autograd.grad(ref_conv(xz, w, (1, 1, 1), (1, 0, 0), (T, H, W)) * a_scale, xz, g)
+    gx_ref = gx_ref * (mask > 0)
+    nfb = 8 if cin >= 128 else 4
+    pwb = ops.ConvWeights(w.numpy(), dtype, nfb, row_scale=a_scale.numpy(), transpose=True)
+    gx = ops.conv3d(g.to(dtype).cuda(), pwb, pad=(1, 0, 0), out_grid=(T, H, W), mask=mask.to(dtype).cuda())
+    r, a = tol(dtype, gx_ref)
+    torch.testing.assert_close(gx.float().cpu(), gx_ref, rtol=r * 2, atol=a * 2)
+    # the halo kernels compute the same sums in the same order ((slab, tap) steps of 32 channels): weights packed in 32-channel tiles
+    # (nf = 2) are outside the ring's route, so this call runs conv_igemm_kernel -- same bits
+    out_h = ops.conv3d(x.to(dtype).cuda(), ops.ConvWeights(w.numpy(), dtype, 2), **kw)
+    assert torch.equal(out_h, out)
