@@ -110,7 +110,7 @@ _SIGS = {
     "flk_net_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "flk_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_conv_splitk_bytes": (C.c_int64, [C.POINTER(ConvArgs), C.c_void_p]),
-    "flk_conv3d_group": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "flk_conv3d_group": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "flk_conv_layout_query": (C.c_int, [C.POINTER(ConvArgs), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "flk_comm_unique_id": (C.c_int, [C.c_void_p]),
     "flk_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

@@ -814,13 +814,15 @@ struct ConvGroupKP {
   ConvKP m[FLK_MAX_GROUP];
   int start[FLK_MAX_GROUP + 1];      // first block of member i; members past the last hold INT_MAX
 };
-template <typename T, int NFW>
+// MODE 1: direct-A members of NFW fragments per wave and p.wn waves along N each.  MODE 0: ring members, all with the SAME channel tile
+// of NFW fragments (one wave row: the ring is sized by the template) -- the large launches whose weights go through LDS (Mixed_3*).
+template <typename T, int NFW, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_group_kernel(const ConvGroupKP g) {
   const int bx = (int)blockIdx.x;
   int i = 0;
 #pragma unroll
   for (int k = 1; k < FLK_MAX_GROUP; ++k) i += bx >= g.start[k];
-  conv_igemm_body<T, NFW, 0, 1>(g.m[i], bx - g.start[i], 0);
+  conv_igemm_body<T, NFW, MODE == 1 ? 0 : 1, MODE>(g.m[i], bx - g.start[i], 0);
 }
 
 // second launch of a split-K convolution: sum the slices in slice order (fixed: bitwise reproducible), then the epilogue.
@@ -1494,41 +1496,43 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
 // Grouped launch: n <= 3 convolutions (bf16, more than one tap, no split-K) in one grid of conv_igemm_group_kernel<NFW>.  Every member
 // is planned as a launch of its own would be, with direct-A weights and wn = (its weights' nf) / nfw waves along N, so member i's blocks
 // compute exactly what flk_conv3d would have with that layout.  Members in the order given: put the longest K loops first.
-extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int dtype, void* stream) {
+extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype, void* stream) {
   FLK_REQUIRE(a && w && n >= 1 && n <= FLK_MAX_GROUP, "flk_conv3d_group: 1..%d members", FLK_MAX_GROUP);
-  FLK_REQUIRE(dtype == FLK_BF16 && (nfw == 2 || nfw == 4), "flk_conv3d_group: bf16 with 2 or 4 channel fragments per wave");
+  FLK_REQUIRE(dtype == FLK_BF16 && (ring ? (nfw == 4 || nfw == 8) : (nfw == 2 || nfw == 4)),
+              "flk_conv3d_group: bf16; 2 or 4 channel fragments per wave (direct-A members) or channel tiles of 4 or 8 fragments (ring members)");
   ConvGroupKP g{};
   size_t lds = 0;
   long total = 0;
   for (int i = 0; i <= FLK_MAX_GROUP; ++i) g.start[i] = 0x7fffffff;
   for (int i = 0; i < n; ++i) {
     FLK_REQUIRE(a[i] && w[i] && w[i]->dev, "flk_conv3d_group: null member %d", i);
-    FLK_REQUIRE(w[i]->nf % nfw == 0 && (w[i]->nf / nfw == 1 || w[i]->nf / nfw == 2 || w[i]->nf / nfw == 4),
-                "flk_conv3d_group: member %d packed with nf %d, not 1 / 2 / 4 waves of %d fragments", i, w[i]->nf, nfw);
+    if (ring) FLK_REQUIRE(w[i]->nf == nfw, "flk_conv3d_group: ring member %d packed with nf %d, the group's tile is %d", i, w[i]->nf, nfw);
+    else FLK_REQUIRE(w[i]->nf % nfw == 0 && (w[i]->nf / nfw == 1 || w[i]->nf / nfw == 2 || w[i]->nf / nfw == 4),
+                     "flk_conv3d_group: member %d packed with nf %d, not 1 / 2 / 4 waves of %d fragments", i, w[i]->nf, nfw);
     FLK_REQUIRE(w[i]->ntaps > 1 && !w[i]->stem4 && !a[i]->pos_bias, "flk_conv3d_group: member %d is not a multi-tap convolution", i);
     ConvPlan pl{};
-    if (int rc = conv3d_impl(a[i], w[i], dtype, stream, w[i]->nf / nfw, 1, 0, &pl)) return rc;
-    FLK_REQUIRE(pl.mode == 1 && pl.wn * nfw == pl.nf && pl.kp.ksplit == 1 && pl.grid.y == 1, "flk_conv3d_group: member %d planned as mode %d, wn %d",
-                i, pl.mode, pl.wn);
+    if (int rc = conv3d_impl(a[i], w[i], dtype, stream, ring ? 1 : w[i]->nf / nfw, ring ? 0 : 1, 0, &pl)) return rc;
+    FLK_REQUIRE(pl.mode == (ring ? 0 : 1) && pl.wn * (ring ? nfw : nfw) == (ring ? nfw : pl.nf) && pl.kp.ksplit == 1 && pl.grid.y == 1,
+                "flk_conv3d_group: member %d planned as mode %d, wn %d", i, pl.mode, pl.wn);
     g.m[i] = pl.kp;
     g.start[i] = (int)total;
     total += pl.grid.x;
     lds = pl.lds > lds ? pl.lds : lds;
     if (dbg_on())
-      fprintf(stderr, "group member %d: conv %dx%dx%d cin %d cout %d out %dx%dx%dx%d | nfw %d wn %d tile %dx%dx%d rows %d halo %d wgs %u lds %zu\n", i,
-              a[i]->kt, a[i]->kh, a[i]->kw, a[i]->cin, a[i]->cout, a[i]->B, a[i]->To, a[i]->Ho, a[i]->Wo, nfw, pl.wn, pl.kp.Tt, pl.kp.Ht, pl.kp.Wt,
-              pl.kp.rows, pl.kp.P, pl.grid.x, pl.lds);
+      fprintf(stderr, "group member %d: conv %dx%dx%d cin %d cout %d out %dx%dx%dx%d | %s nfw %d wn %d tile %dx%dx%d rows %d halo %d wgs %u lds %zu\n", i,
+              a[i]->kt, a[i]->kh, a[i]->kw, a[i]->cin, a[i]->cout, a[i]->B, a[i]->To, a[i]->Ho, a[i]->Wo, ring ? "ring" : "direct-A", nfw, pl.wn, pl.kp.Tt,
+              pl.kp.Ht, pl.kp.Wt, pl.kp.rows, pl.kp.P, pl.grid.x, pl.lds);
   }
   FLK_REQUIRE(total < (1l << 31), "flk_conv3d_group: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  static bool attr2[FLK_MAX_DEVICES] = {}, attr4[FLK_MAX_DEVICES] = {};
-  if (nfw == 2) {
-    if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, 2>, 96 * 1024, attr2)) return rc;
-    FLK_LAUNCH_KERNEL((conv_igemm_group_kernel<bf16_t, 2>), dim3((unsigned)total), dim3(256), lds, s, g);
-  } else {
-    if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, 4>, 96 * 1024, attr4)) return rc;
-    FLK_LAUNCH_KERNEL((conv_igemm_group_kernel<bf16_t, 4>), dim3((unsigned)total), dim3(256), lds, s, g);
+  static bool attr[4][FLK_MAX_DEVICES] = {};
+#define FLK_LAUNCH_GROUP(NFWv, MODEv, idx)                                                                                           \
+  if (nfw == NFWv && (ring ? 0 : 1) == MODEv) {                                                                                       \
+    if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, NFWv, MODEv>, 96 * 1024, attr[idx])) return rc;    \
+    FLK_LAUNCH_KERNEL((conv_igemm_group_kernel<bf16_t, NFWv, MODEv>), dim3((unsigned)total), dim3(256), lds, s, g);                  \
   }
+  FLK_LAUNCH_GROUP(2, 1, 0) FLK_LAUNCH_GROUP(4, 1, 1) FLK_LAUNCH_GROUP(4, 0, 2) FLK_LAUNCH_GROUP(8, 0, 3)
+#undef FLK_LAUNCH_GROUP
   flk_last_kernel_tag = "conv_igemm_group_kernel";
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;

@@ -359,7 +359,7 @@ struct flk_net {
   // (cout2 <= 128) takes the narrowest tile of wn2 in {1, 2, 4} waves x nfw fragments that holds its channels -- with the large member
   // filling the chip it no longer has to manufacture workgroups out of 64-row tiles.  nfw = 0: no group (fp32, a geometry the group
   // kernel has no instance for, FLK_GROUP=0).
-  struct GroupLayout { int nfw = 0, nf1 = 0, nf2 = 0; };
+  struct GroupLayout { int nfw = 0, nf1 = 0, nf2 = 0, ring = 0; };
   GroupLayout plan_group(const Act& geom, int cin1, int cout1, int cout2) const {
     GroupLayout g;
     static const int on = getenv("FLK_GROUP") ? atoi(getenv("FLK_GROUP")) : 3;
@@ -372,10 +372,15 @@ struct flk_net {
     int nf1 = nf_for(cout1, 27, rows);
     if (nf1 == 6) nf1 = 4;
     int wn1 = 1, mode = 0;
-    // a large member the heuristics give the LDS weight ring (Mixed_4e / 4f forward: 560 workgroups) stays a launch of its own: as a
-    // direct-A member of a group it ran 0.120 / 0.122 ms against 0.092 + 0.019 / 0.091 + 0.022 ms for the two launches (FLK_GROUP_RING=1: group anyway)
-    static const bool ring_too = getenv("FLK_GROUP_RING") && atoi(getenv("FLK_GROUP_RING"));
-    if (!ring_too && (flk_conv_layout_query(&a, nf1, dtype, -1, &wn1, &mode) != FLK_OK || mode != 1)) return g;
+    // a large member the heuristics give the LDS weight ring (Mixed_4e / 4f forward: 560 workgroups) keeps the ring: as a direct-A member
+    // of a group it ran 0.120 / 0.122 ms against 0.092 + 0.019 / 0.091 + 0.022 ms for the two launches
+    // (FLK_GROUP_RING: 0 = such a block is not grouped: 5.889 ms; 1 = as direct-A members: 5.856 -> slower than 0 on the same box; 2 (default) = as a
+    //  RING group, both members on the ring's 256-row tiles with Branch_1's channel tile: 5.871; with Mixed_3* grouped that way too: 5.876)
+    static const int ring_too = getenv("FLK_GROUP_RING") ? atoi(getenv("FLK_GROUP_RING")) : 2;
+    if (ring_too != 1 && (flk_conv_layout_query(&a, nf1, dtype, -1, &wn1, &mode) != FLK_OK || mode != 1)) {
+      if (ring_too == 2 && mode == 0 && wn1 == 1 && (nf1 == 4 || nf1 == 8)) { g.nfw = nf1; g.nf1 = nf1; g.nf2 = nf1; g.ring = 1; }
+      return g;
+    }
     if (flk_conv_layout_query(&a, nf1, dtype, 1, &wn1, &mode) != FLK_OK || mode != 1) return g;
     int nfw = nf1 / wn1;
     if (nfw == 8) nfw = 4;                              // (nf 8 on 256-row tiles: two waves along the channels instead)
@@ -419,13 +424,13 @@ struct flk_net {
   // one operator = the two members in one launch (the large member first: its long K loops start first, the small member's
   // workgroups fill the tail)
   void emit_group(std::vector<Op>& ops, const std::string& name, const flk_conv_args& a1, const flk_conv_weights* w1, const flk_conv_args& a2,
-                  const flk_conv_weights* w2, int nfw) {
+                  const flk_conv_weights* w2, int nfw, int ring = 0) {
     auto macs = [](const flk_conv_args& a) { return (double)a.B * a.To * a.Ho * a.Wo * a.kt * a.kh * a.kw * a.cin * a.cout; };
     const int dt = dtype;
-    ops.push_back(Op{name, K_CONV, 2.0 * (macs(a1) + macs(a2)), conv_bytes(a1) + conv_bytes(a2), [a1, w1, a2, w2, nfw, dt](hipStream_t s) {
+    ops.push_back(Op{name, K_CONV, 2.0 * (macs(a1) + macs(a2)), conv_bytes(a1) + conv_bytes(a2), [a1, w1, a2, w2, nfw, ring, dt](hipStream_t s) {
                        const flk_conv_args* av[2] = {&a1, &a2};
                        const flk_conv_weights* wv[2] = {w1, w2};
-                       return flk_conv3d_group(av, wv, 2, nfw, dt, s);
+                       return flk_conv3d_group(av, wv, 2, nfw, ring, dt, s);
                      }});
   }
 
@@ -713,7 +718,7 @@ int flk_net::build_i3d() {
     if (grp_f) {
       // Branch_1 and Branch_2 in one launch on the caller's stream; only Branch_3's pool -> 1x1x1 chain runs beside it (side stream 2)
       emit_group(fwd, bn + "/Branch_1+2/Conv3d_0b_3x3", conv_fwd_args(L1b, mid, 0, out, c0), L1b->wf, conv_fwd_args(L2b, mid, c1a, out, c0 + c1b),
-                 L2b->wf, gf.nfw);
+                 L2b->wf, gf.nfw, gf.ring);
     } else {
       emit_conv_fwd(L1b, mid, 0, out, c0);
       { const size_t m0 = fwd.size(); emit_conv_fwd(L2b, mid, c1a, out, c0 + c1b); set_lane(fwd, m0, 1); }
@@ -767,7 +772,7 @@ int flk_net::build_i3d() {
       }
       if (grp_b) {
         emit_group(bwd, bn + "/Branch_1+2/Conv3d_0b_3x3/dgrad", conv_bwd_args(L1b, Gout, c0, Gmid, 0, &mid, 0), L1b->wb,
-                   conv_bwd_args(L2b, Gout, c0 + c1b, Gmid, c1a, &mid, c1a), L2b->wb, gb.nfw);
+                   conv_bwd_args(L2b, Gout, c0 + c1b, Gmid, c1a, &mid, c1a), L2b->wb, gb.nfw, gb.ring);
       } else {
         { const size_t m0 = bwd.size(); emit_conv_bwd(L2b, Gout, c0 + c1b, Gmid, c1a, nullptr, 0, 0, &mid, c1a); set_lane(bwd, m0, 1); }
         emit_conv_bwd(L1b, Gout, c0, Gmid, 0, nullptr, 0, 0, &mid, 0);

@@ -71,13 +71,14 @@ def conv3d(x, w, **kw):
     return out
 
 
-def conv3d_group(members, nfw):
-    """members: [(x, w, kwargs)] -- up to three multi-tap bf16 convolutions in ONE launch (flk_conv3d_group); returns their outputs"""
+def conv3d_group(members, nfw, ring=False):
+    """members: [(x, w, kwargs)] -- up to three multi-tap bf16 convolutions in ONE launch (flk_conv3d_group); returns their outputs.
+    ring: the members take the LDS weight ring (all packed with nf == nfw) instead of direct-A weights"""
     built = [conv3d_args(x, w, **kw) for x, w, kw in members]
     n = len(built)
     ap = (C.POINTER(ConvArgs) * n)(*[C.pointer(a) for a, _ in built])
     wp = (C.c_void_p * n)(*[w.handle for _, w, _ in members])
-    check(load().flk_conv3d_group(ap, wp, n, nfw, dtype_code(members[0][0].dtype), stream_ptr()))
+    check(load().flk_conv3d_group(ap, wp, n, nfw, int(ring), dtype_code(members[0][0].dtype), stream_ptr()))
     return [o for _, o in built]
 
 

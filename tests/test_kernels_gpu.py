@@ -539,6 +539,8 @@ GROUP_CASES = [
     ("4f_fwd", 1, 4, 14, 14, (160, 320, 4), (32, 128, 8), 4),          # wn 1 + wn 2, five channel tiles + one
     ("5b_fwd", 2, 2, 7, 7, (160, 320, 4), (32, 128, 8), 2),            # wn 2 + wn 4 (the Mixed_5 tiles: 7 x 7 planes)
     ("5c_dgrad_ragged", 1, 3, 7, 9, (384, 192, 4), (128, 48, 4), 2),   # ragged tiles, a partial channel tile in member 2
+    ("4f_fwd_ring", 1, 4, 14, 14, (160, 320, 4), (32, 128, 4), -4),     # RING members (nfw < 0 here: ring with 64-channel tiles): five tiles + two
+    ("3b_fwd_ring8", 1, 4, 12, 12, (96, 128, 8), (16, 32, 8), -8),      # ring, 128-channel tiles: member 2 fills a quarter of one
 ]
 
 
@@ -572,7 +574,9 @@ def test_conv_group(ops, case):
         singles.append((pw, dict(kw, out=out_s)))
         in_off += cin
         out_off += cout
-    ops.conv3d_group(members, nfw)
+    ring = nfw < 0
+    nfw = abs(nfw)
+    ops.conv3d_group(members, nfw, ring=ring)
     for pw, kw in singles:
         ops.conv3d(xg, pw, **kw)
     torch.cuda.synchronize()
@@ -581,7 +585,7 @@ def test_conv_group(ops, case):
         torch.testing.assert_close(out_g[..., off:off + cout].float().cpu(), ref, rtol=r, atol=a)
     assert torch.equal(out_g, out_s)                                    # bitwise the separate launches (untouched channels stay zero)
     again = torch.zeros_like(out_g)
-    ops.conv3d_group([(x_, w_, dict(k_, out=again)) for x_, w_, k_ in members], nfw)
+    ops.conv3d_group([(x_, w_, dict(k_, out=again)) for x_, w_, k_ in members], nfw, ring=ring)
     assert torch.equal(again, out_g)
 
 
