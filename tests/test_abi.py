@@ -64,3 +64,34 @@ def test_product_library_has_no_timing_ablation_switches():
     blob = open(build.build(verbose=False), "rb").read()
     for name in (b"FLK_PF_DBG", b"FLK_PG_DBG", b"FLK_SG_DBG", b"FLK_SF_ABLATE", b"FLK_SF_STAGGER", b"FLK_STEM_NI"):
         assert name not in blob, name
+
+
+def test_group_launch_validation_and_layout_query_without_gpu(lib):
+    """flk_conv3d_group / flk_conv_layout_query: host-side checks only (no device work).  The layout query reproduces the heuristics the
+    plan builder relies on when it packs the members of a grouped launch: Mixed_4b's Branch_1 forward at the benchmark batch
+    (96 -> 208 over 8 x 16 x 14 x 14) takes direct-A weights on 128-row tiles (two waves along the channels of its 128-wide tile),
+    Mixed_4f's (160 -> 320) the LDS weight ring on 256-row tiles."""
+    import ctypes as C
+    from flickering_adversarial_video_amd import _lib
+    a = _lib.ConvArgs()
+    a.B, a.Ti, a.Hi, a.Wi = 8, 16, 14, 14
+    a.To, a.Ho, a.Wo, a.OT, a.OH, a.OW = 16, 14, 14, 16, 14, 14
+    a.kt = a.kh = a.kw = 3
+    a.st = a.sh = a.sw = a.ost = a.osh = a.osw = 1
+    a.pt = a.ph = a.pw = 1
+    wn, mode = C.c_int(), C.c_int()
+    a.cin, a.cout, a.in_ld, a.out_ld = 96, 208, 96, 208
+    assert lib.flk_conv_layout_query(C.byref(a), 8, _lib.FLK_BF16, -1, C.byref(wn), C.byref(mode)) == 0
+    assert (wn.value, mode.value) == (2, 1)
+    a.cin, a.cout, a.in_ld, a.out_ld = 160, 320, 160, 320
+    assert lib.flk_conv_layout_query(C.byref(a), 4, _lib.FLK_BF16, -1, C.byref(wn), C.byref(mode)) == 0
+    assert (wn.value, mode.value) == (1, 0)
+    assert lib.flk_conv_layout_query(C.byref(a), 4, _lib.FLK_BF16, 1, C.byref(wn), C.byref(mode)) == 0 and mode.value == 1      # forced direct-A
+    assert lib.flk_conv_layout_query(None, 4, _lib.FLK_BF16, -1, C.byref(wn), C.byref(mode)) == -1
+    # group launch: argument validation
+    ap = (C.POINTER(_lib.ConvArgs) * 1)(C.pointer(a))
+    wp = (C.c_void_p * 1)(None)
+    assert lib.flk_conv3d_group(ap, wp, 0, 4, 0, _lib.FLK_BF16, None) == -1 and b"members" in lib.flk_last_error()
+    assert lib.flk_conv3d_group(ap, wp, 1, 3, 0, _lib.FLK_BF16, None) == -1 and b"fragments" in lib.flk_last_error()
+    assert lib.flk_conv3d_group(ap, wp, 1, 4, 0, _lib.FLK_F32, None) == -1
+    assert lib.flk_conv3d_group(ap, wp, 1, 4, 0, _lib.FLK_BF16, None) == -1 and b"null member" in lib.flk_last_error()
