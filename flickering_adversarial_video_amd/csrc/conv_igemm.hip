@@ -485,6 +485,79 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
       }
     }
 
+  } else if constexpr (MODE == 5) {
+    // ---- mode 0 for kw = 3 with the weights fetched a ROW of three taps ahead.  Mode 0 requests the fragments of step k + 1 during step k:
+    // one step is 16 NFW MFMAs = 256 cycles for a wave, an L2 round trip under load several times that, so every step of a workgroup ends
+    // up as long as the round trip (timing-only build without MFMAs, halo loads and stores: Conv3d_2c still takes 0.117 of its 0.258 ms:
+    // 850 cycles per step and workgroup).  Here the three taps of a (dt, dh) row live in three named registers; a register is refilled --
+    // from inline asm, hipcc drains compiler-issued queues at loop merge points -- with the same tap of the NEXT row right after the ring
+    // write that consumed it, so a fragment has three steps to arrive and ONE counted s_waitcnt vmcnt(2) per step releases exactly the
+    // register the step writes to LDS (the two younger refills stay in flight; halo loads the compiler issues in between only make the
+    // wait longer).  Ring, barriers, fragment reads and K order as in mode 0: bitwise the same outputs.
+    static_assert(WN == 1 && NF <= 4, "mode 5: one 16-byte weight chunk per thread and step");
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int wchunk = NF >= 4 ? tid : (tid & 127);
+    // step k of this channel tile: scalar base wtile + k * wstep, this thread's chunk a 32-bit offset (SADDR form: no 64-bit VGPR pointers)
+    const char* const wtile = wbase + (size_t)ntile * NF * 1024;
+    const unsigned wvoff = (unsigned)(wchunk * 16);
+    const int last_step = nsteps - 1;
+    u32x4 q0, q1, q2;
+    auto wload = [&](u32x4& dst, int k) {
+      const char* const ws = wtile + (size_t)(k < last_step ? k : last_step) * wstep;      // past the end: re-read the last step (never used)
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wvoff), "s"(ws) : "memory");
+    };
+    auto wwait = [&](u32x4& q) { asm volatile("s_waitcnt vmcnt(2) ; release %0" : "+v"(q) : : "memory"); };
+    wload(q0, 0); wload(q1, 1); wload(q2, 2);
+    int it_w = 0;
+    auto step = [&](u32x4& q, int hsel, int tapoff) {
+      char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
+      wwait(q);
+      *(u32x4*)(wcur + wchunk * 16) = q;
+      ++it_w;
+      wload(q, it_w + 2);                               // the same tap of the next row (it_w is already k + 1; clamped past the end)
+      __syncthreads();
+      if (wave_active) {
+        frag bf[4], af[NFW];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + hsel + rowpos[i] + tapoff);
+#pragma unroll
+        for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NFW; ++f)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) PR::mma(af[f], bf[i], acc[f][i]);
+      }
+    };
+    // (large halos only -- P > 256, one image staged behind a barrier per slab: the two-image pipeline's four prefetch registers on top of
+    //  the three weight registers would cost the third wave per SIMD)
+    for (int s = 0; s < nslab; ++s) {
+      __syncthreads();  // every wave has finished reading the previous slab's halo
+      {
+        const char* src; int ld;
+        const bool chvalid = slab_src(s, src, ld);
+  #pragma unroll
+        for (int n0 = 0; n0 < NPK; n0 += HB) {
+          if (n0 * 64 >= p.P) break;
+          uint4 v[HB];
+  #pragma unroll
+          for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+  #pragma unroll
+          for (int n = 0; n < HB; ++n)
+            if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
+        }
+      }
+      int tapoff_t = 0;
+      for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.Hh * p.Wh * 16) {
+        int tapoff = tapoff_t;
+        for (int dh = 0; dh < p.kh; ++dh, tapoff += p.Wh * 16) {
+          step(q0, 0, tapoff);
+          step(q1, 0, tapoff + 16);
+          step(q2, 0, tapoff + 32);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the clamped tail refills: drained before the registers may be reused
   } else if constexpr (MODE == 4) {
     // ---- folded stem (flk_conv_weights_create_s2d_stem, api.cpp): chunk c of a position holds ONE (qt,qh) parity and
     // tap index 3 of an axis exists for parity 0 only, so for dt == 3 / dh == 3 half (or three quarters) of the chunks
@@ -1439,8 +1512,16 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
 #undef FLK_LAUNCH_DMA
     }
   }
-  // two halo images for small halos; the LDS weight ring only in mode 0
-  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4) ? 2 * (size_t)nf * 1024 : 0);
+  // ring kernels of three-tap rows (kw = 3) with at most 64-channel tiles and a large halo: the weights a row ahead (mode 5).  Measured,
+  // same box, two rounds: Conv3d_2c 0.2594 -> 0.2541 ms forward, 0.2670 -> 0.2551 data-gradient; Mixed_3c Branch_1 0.2485 -> 0.2412 /
+  // 0.2607 -> 0.2509; the (1,3,3) 64 -> 144 layer 0.1413 -> 0.1370 / 0.1163 -> 0.1103; 160 -> 320 at 25 088 positions 0.0945 -> 0.0921; the
+  // step 5.82-5.89 -> 5.78 ms.  FLK_CONV_ROWAHEAD=0: mode 0
+  {
+    static const int rowahead = getenv("FLK_CONV_ROWAHEAD") ? atoi(getenv("FLK_CONV_ROWAHEAD")) : 1;
+    if (rowahead && mode == 0 && dtype == FLK_BF16 && a->kw == 3 && kp.P > 256 && (nf == 4 || nf == 2)) mode = 5;
+  }
+  // two halo images for small halos; the LDS weight ring only in mode 0 / 3 / 4 / 5
+  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4 || mode == 5) ? 2 * (size_t)nf * 1024 : 0);
   {
     static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
     if (dbg)
@@ -1478,6 +1559,8 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
     if (mode == 4 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 4>(kp, grid, lds, s);
+    if (mode == 5 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 5>(kp, grid, lds, s);
+    if (mode == 5 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 5>(kp, grid, lds, s);
     FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1); FLK_LAUNCH0(bf16_t, 6, 1);
     FLK_LAUNCHD(bf16_t, 2, 1); FLK_LAUNCHD(bf16_t, 4, 1); FLK_LAUNCHD(bf16_t, 4, 2);
     FLK_LAUNCHD(bf16_t, 8, 2); FLK_LAUNCHD(bf16_t, 8, 4);
@@ -1512,7 +1595,9 @@ extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_we
     FLK_REQUIRE(w[i]->ntaps > 1 && !w[i]->stem4 && !a[i]->pos_bias, "flk_conv3d_group: member %d is not a multi-tap convolution", i);
     ConvPlan pl{};
     if (int rc = conv3d_impl(a[i], w[i], dtype, stream, ring ? 1 : w[i]->nf / nfw, ring ? 0 : 1, 0, &pl)) return rc;
-    FLK_REQUIRE(pl.mode == (ring ? 0 : 1) && pl.wn * (ring ? nfw : nfw) == (ring ? nfw : pl.nf) && pl.kp.ksplit == 1 && pl.grid.y == 1,
+    // (ring members: a member planned for mode 5 -- the ring with the weights a row ahead -- has mode 0's arguments and LDS layout and runs the
+    //  group's mode-0 body)
+    FLK_REQUIRE((ring ? (pl.mode == 0 || pl.mode == 5) : pl.mode == 1) && pl.wn * nfw == (ring ? nfw : pl.nf) && pl.kp.ksplit == 1 && pl.grid.y == 1,
                 "flk_conv3d_group: member %d planned as mode %d, wn %d", i, pl.mode, pl.wn);
     g.m[i] = pl.kp;
     g.start[i] = (int)total;

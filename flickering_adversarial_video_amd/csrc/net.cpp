@@ -378,7 +378,7 @@ struct flk_net {
     //  RING group, both members on the ring's 256-row tiles with Branch_1's channel tile: 5.871; with Mixed_3* grouped that way too: 5.876)
     static const int ring_too = getenv("FLK_GROUP_RING") ? atoi(getenv("FLK_GROUP_RING")) : 2;
     if (ring_too != 1 && (flk_conv_layout_query(&a, nf1, dtype, -1, &wn1, &mode) != FLK_OK || mode != 1)) {
-      if (ring_too == 2 && mode == 0 && wn1 == 1 && (nf1 == 4 || nf1 == 8)) { g.nfw = nf1; g.nf1 = nf1; g.nf2 = nf1; g.ring = 1; }
+      if (ring_too == 2 && (mode == 0 || mode == 5) && wn1 == 1 && (nf1 == 4 || nf1 == 8)) { g.nfw = nf1; g.nf1 = nf1; g.nf2 = nf1; g.ring = 1; }
       return g;
     }
     if (flk_conv_layout_query(&a, nf1, dtype, 1, &wn1, &mode) != FLK_OK || mode != 1) return g;

@@ -119,7 +119,7 @@ int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_weights* w)
  * one template argument the members share; every w[i] must have been packed with nf in {nfw, 2 nfw, 4 nfw}.  ring != 0: the members
  * take the LDS weight ring instead (the large launches' path): all packed with nf == nfw (4 or 8), 256-row tiles.  Longest K loops first. */
 int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype, void* stream);
-/* the (waves along the channels, weight path: 0 LDS ring / 1 direct A / ...) flk_conv3d's heuristics choose for this geometry when the
+/* the (waves along the channels, weight path: 0 LDS ring / 5 LDS ring with the weights a row of taps ahead / 1 direct A / ...) flk_conv3d's heuristics choose for this geometry when the
  * weights are packed at `nf` (force_da: -1 heuristic, 0 ring, 1 direct A): lets a plan builder pick the packing of a grouped launch's
  * members before any weights exist.  No device work. */
 int flk_conv_layout_query(const flk_conv_args* a, int nf, int dtype, int force_da, int* wn_out, int* mode_out);

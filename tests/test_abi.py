@@ -85,7 +85,7 @@ def test_group_launch_validation_and_layout_query_without_gpu(lib):
     assert (wn.value, mode.value) == (2, 1)
     a.cin, a.cout, a.in_ld, a.out_ld = 160, 320, 160, 320
     assert lib.flk_conv_layout_query(C.byref(a), 4, _lib.FLK_BF16, -1, C.byref(wn), C.byref(mode)) == 0
-    assert (wn.value, mode.value) == (1, 0)
+    assert wn.value == 1 and mode.value in (0, 5)          # the ring (5: its form with the weights fetched a row of taps ahead)
     assert lib.flk_conv_layout_query(C.byref(a), 4, _lib.FLK_BF16, 1, C.byref(wn), C.byref(mode)) == 0 and mode.value == 1      # forced direct-A
     assert lib.flk_conv_layout_query(None, 4, _lib.FLK_BF16, -1, C.byref(wn), C.byref(mode)) == -1
     # group launch: argument validation

@@ -635,3 +635,37 @@ def test_conv_temporal_dma(ops, case):
     # (nf = 2) are outside the ring's route, so this call runs conv_igemm_kernel -- same bits
     out_h = ops.conv3d(x.to(dtype).cuda(), ops.ConvWeights(w.numpy(), dtype, 2), **kw)
     assert torch.equal(out_h, out)
+
+
+@pytest.mark.parametrize("transpose", [False, True], ids=["fwd", "dgrad"])
+def test_conv_ring_weights_a_row_ahead(ops, transpose):
+    """conv_igemm_kernel mode 5 (ring kernels of 3-tap rows with <= 64-channel tiles on grids of more than two workgroups per CU: the
+    weights fetched a row of taps ahead from inline asm) -- a shape large enough to take it (588 workgroups), forward with the BN / ReLU
+    epilogue and data-gradient with the ReLU mask against torch-CPU, and bitwise against the same layer on 128-channel tiles (mode 0:
+    the same K order per output)."""
+    dtype = torch.bfloat16
+    B, T, H, W, cin, cout = 1, 12, 56, 56, 64, 192
+    if transpose:
+        cin, cout = cout, cin
+    w = q(rnd((3, 3, 3, cin, cout), 61, (2.0 / (27 * cin)) ** 0.5), dtype)
+    torch.set_num_threads(16)
+    if not transpose:
+        x = q(rnd((B, T, H, W, cin), 62), dtype)
+        sc, bi = rnd((cout,), 63).abs() + 0.5, rnd((cout,), 64, 0.1)
+        ref = torch.relu(ref_conv(x, w, (1, 1, 1), (1, 1, 1), (T, H, W)) * sc + bi)
+        kw = dict(scale=sc.cuda(), bias=bi.cuda(), relu=True)
+        run = lambda nf: ops.conv3d(x.to(dtype).cuda(), ops.ConvWeights(w.numpy(), dtype, nf), **kw)
+    else:
+        a_scale = rnd((cout,), 65).abs() + 0.5
+        g = q(rnd((B, T, H, W, cout), 66), dtype)
+        mask = q(rnd((B, T, H, W, cin), 67), dtype)
+        xz = torch.zeros((B, T, H, W, cin), requires_grad=True)
+        (ref,) = torch.autograd.grad(ref_conv(xz, w, (1, 1, 1), (1, 1, 1), (T, H, W)) * a_scale, xz, g)
+        ref = ref * (mask > 0)
+        run = lambda nf: ops.conv3d(g.to(dtype).cuda(), ops.ConvWeights(w.numpy(), dtype, nf, row_scale=a_scale.numpy(), transpose=True),
+                                    pad=(1, 1, 1), out_grid=(T, H, W), mask=mask.to(dtype).cuda())
+    out4, out8 = run(4), run(8)
+    r, a = tol(dtype, ref)
+    torch.testing.assert_close(out4.float().cpu(), ref, rtol=r * 2, atol=a * 2)
+    assert torch.equal(out4, out8)
+    assert torch.equal(run(4), out4)
