@@ -494,27 +494,34 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     // write that consumed it, so a fragment has three steps to arrive and ONE counted s_waitcnt vmcnt(2) per step releases exactly the
     // register the step writes to LDS (the two younger refills stay in flight; halo loads the compiler issues in between only make the
     // wait longer).  Ring, barriers, fragment reads and K order as in mode 0: bitwise the same outputs.
-    static_assert(WN == 1 && NF <= 4, "mode 5: one 16-byte weight chunk per thread and step");
+    static_assert(WN == 1, "mode 5 shares the weights through LDS");
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NWAIT = 2 * WCH;                      // loads younger than the ones a step consumes: two steps' worth
     const int wchunk = NF >= 4 ? tid : (tid & 127);
     // step k of this channel tile: scalar base wtile + k * wstep, this thread's chunk a 32-bit offset (SADDR form: no 64-bit VGPR pointers)
     const char* const wtile = wbase + (size_t)ntile * NF * 1024;
     const unsigned wvoff = (unsigned)(wchunk * 16);
+    const unsigned wvoff2 = wvoff + (unsigned)w2off;    // second chunk of a step (WCH = 2; NF = 6: threads without one re-read their first)
     const int last_step = nsteps - 1;
-    u32x4 q0, q1, q2;
-    auto wload = [&](u32x4& dst, int k) {
+    u32x4 q0, q1, q2, r0, r1, r2;                      // (r*: the second chunk of a step for channel tiles of more than 64, WCH = 2)
+    auto wload = [&](u32x4& dst, u32x4& dst2, int k) {
       const char* const ws = wtile + (size_t)(k < last_step ? k : last_step) * wstep;      // past the end: re-read the last step (never used)
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wvoff), "s"(ws) : "memory");
+      if constexpr (WCH == 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst2) : "v"(wvoff2), "s"(ws) : "memory");
     };
-    auto wwait = [&](u32x4& q) { asm volatile("s_waitcnt vmcnt(2) ; release %0" : "+v"(q) : : "memory"); };
-    wload(q0, 0); wload(q1, 1); wload(q2, 2);
+    auto wwait = [&](u32x4& q, u32x4& r) {
+      if constexpr (WCH == 2) asm volatile("s_waitcnt vmcnt(%2) ; release %0 %1" : "+v"(q), "+v"(r) : "i"(NWAIT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%1) ; release %0" : "+v"(q) : "i"(NWAIT) : "memory");
+    };
+    wload(q0, r0, 0); wload(q1, r1, 1); wload(q2, r2, 2);
     int it_w = 0;
-    auto step = [&](u32x4& q, int hsel, int tapoff) {
+    auto step = [&](u32x4& q, u32x4& r, int hsel, int tapoff) {
       char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
-      wwait(q);
+      wwait(q, r);
       *(u32x4*)(wcur + wchunk * 16) = q;
+      if (WCH == 2 && w2ok) *(u32x4*)(wcur + wchunk * 16 + 4096) = r;
       ++it_w;
-      wload(q, it_w + 2);                               // the same tap of the next row (it_w is already k + 1; clamped past the end)
+      wload(q, r, it_w + 2);                            // the same tap of the next row (it_w is already k + 1; clamped past the end)
       __syncthreads();
       if (wave_active) {
         frag bf[4], af[NFW];
@@ -551,9 +558,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
       for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.Hh * p.Wh * 16) {
         int tapoff = tapoff_t;
         for (int dh = 0; dh < p.kh; ++dh, tapoff += p.Wh * 16) {
-          step(q0, 0, tapoff);
-          step(q1, 0, tapoff + 16);
-          step(q2, 0, tapoff + 32);
+          step(q0, r0, 0, tapoff);
+          step(q1, r1, 0, tapoff + 16);
+          step(q2, r2, 0, tapoff + 32);
         }
       }
     }
@@ -1512,13 +1519,16 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
 #undef FLK_LAUNCH_DMA
     }
   }
-  // ring kernels of three-tap rows (kw = 3) with at most 64-channel tiles and a large halo: the weights a row ahead (mode 5).  Measured,
+  // ring kernels of three-tap rows (kw = 3) with a large halo: the weights a row ahead (mode 5).  Measured,
   // same box, two rounds: Conv3d_2c 0.2594 -> 0.2541 ms forward, 0.2670 -> 0.2551 data-gradient; Mixed_3c Branch_1 0.2485 -> 0.2412 /
   // 0.2607 -> 0.2509; the (1,3,3) 64 -> 144 layer 0.1413 -> 0.1370 / 0.1163 -> 0.1103; 160 -> 320 at 25 088 positions 0.0945 -> 0.0921; the
-  // step 5.82-5.89 -> 5.78 ms.  FLK_CONV_ROWAHEAD=0: mode 0
+  // step 5.82-5.89 -> 5.78 ms.  128- and 96-channel tiles carry two 16-byte pieces per thread and step (six registers quads in flight,
+  // 248 / 208 VGPRs, two workgroups per CU as in mode 0): Mixed_3b Branch_1 96 -> 128 0.1498-0.1536 -> 0.1464-0.1485 ms, its data-gradient on
+  // 96-channel tiles 0.158 -> 0.160 (alone: slower), the step 5.75 -> 5.70 (128 only) -> 5.68 ms (both; four A/B pairs each, same box).
+  // FLK_CONV_ROWAHEAD=0: mode 0
   {
     static const int rowahead = getenv("FLK_CONV_ROWAHEAD") ? atoi(getenv("FLK_CONV_ROWAHEAD")) : 1;
-    if (rowahead && mode == 0 && dtype == FLK_BF16 && a->kw == 3 && kp.P > 256 && (nf == 4 || nf == 2)) mode = 5;
+    if (rowahead && mode == 0 && dtype == FLK_BF16 && a->kw == 3 && kp.P > 256 && (nf == 8 || nf == 6 || nf == 4 || nf == 2)) mode = 5;
   }
   // two halo images for small halos; the LDS weight ring only in mode 0 / 3 / 4 / 5
   const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4 || mode == 5) ? 2 * (size_t)nf * 1024 : 0);
@@ -1561,6 +1571,8 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
     if (mode == 4 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 4>(kp, grid, lds, s);
     if (mode == 5 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 5>(kp, grid, lds, s);
     if (mode == 5 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 5>(kp, grid, lds, s);
+    if (mode == 5 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 5>(kp, grid, lds, s);
+    if (mode == 5 && wn == 1 && nf == 6) return launch<bf16_t, 6, 1, 5>(kp, grid, lds, s);
     FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1); FLK_LAUNCH0(bf16_t, 6, 1);
     FLK_LAUNCHD(bf16_t, 2, 1); FLK_LAUNCHD(bf16_t, 4, 1); FLK_LAUNCHD(bf16_t, 4, 2);
     FLK_LAUNCHD(bf16_t, 8, 2); FLK_LAUNCHD(bf16_t, 8, 4);

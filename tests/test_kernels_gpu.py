@@ -639,10 +639,10 @@ def test_conv_temporal_dma(ops, case):
 
 @pytest.mark.parametrize("transpose", [False, True], ids=["fwd", "dgrad"])
 def test_conv_ring_weights_a_row_ahead(ops, transpose):
-    """conv_igemm_kernel mode 5 (ring kernels of 3-tap rows with <= 64-channel tiles on grids of more than two workgroups per CU: the
-    weights fetched a row of taps ahead from inline asm) -- a shape large enough to take it (588 workgroups), forward with the BN / ReLU
-    epilogue and data-gradient with the ReLU mask against torch-CPU, and bitwise against the same layer on 128-channel tiles (mode 0:
-    the same K order per output)."""
+    """conv_igemm_kernel mode 5 (ring kernels of 3-tap rows on large halos: the weights fetched a row of taps ahead from inline asm, one
+    16-byte piece per thread and step on 64-channel tiles, two on 128- / 96-channel tiles) -- a shape large enough to take it (588
+    workgroups), forward with the BN / ReLU epilogue and data-gradient with the ReLU mask against torch-CPU, and the three tile widths
+    bitwise against each other (the same K order per output)."""
     dtype = torch.bfloat16
     B, T, H, W, cin, cout = 1, 12, 56, 56, 64, 192
     if transpose:
@@ -664,8 +664,8 @@ def test_conv_ring_weights_a_row_ahead(ops, transpose):
         ref = ref * (mask > 0)
         run = lambda nf: ops.conv3d(g.to(dtype).cuda(), ops.ConvWeights(w.numpy(), dtype, nf, row_scale=a_scale.numpy(), transpose=True),
                                     pad=(1, 1, 1), out_grid=(T, H, W), mask=mask.to(dtype).cuda())
-    out4, out8 = run(4), run(8)
+    out4, out8, out6 = run(4), run(8), run(6)
     r, a = tol(dtype, ref)
     torch.testing.assert_close(out4.float().cpu(), ref, rtol=r * 2, atol=a * 2)
-    assert torch.equal(out4, out8)
+    assert torch.equal(out4, out8) and torch.equal(out4, out6)
     assert torch.equal(run(4), out4)
