@@ -27,6 +27,7 @@
 //     accesses for scale/bias/add/mask and stores.
 //   * bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32, parity mode).
 #include <stdlib.h>
+#include <algorithm>
 #include "flk_internal.h"
 
 struct ConvKP {
@@ -42,6 +43,8 @@ struct ConvKP {
   int add_ld, add_coff, mask_ld, mask_coff, relu;
   int Tt, Ht, Wt, nTt, nTh, nTw, rows;
   int Th, Hh, Wh, P, plane_b;
+  int FP;            // frame pitch of the halo image in 16-byte slots (>= Hh * Wh; slot of halo cell (a, b, c) = a * FP + b * Wh + c)
+  int tfast;         // tile rows enumerated w, then T, then h (1) instead of w, h, T (0): see pick_halo_layout
   int nslab, ntaps, cout_frags;
   int in2_ld, in2_coff, cin1, nslab1, out2_ld, out2_coff, cout1;
   unsigned m_HW, m_Wh, m_hw, m_Wt;   // ceil(2^20 / d): exact x / d for x * d < 2^20 (x < 1024 here)
@@ -93,6 +96,18 @@ template <> struct Prec<float> {
 
 __device__ static inline int plane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
 __device__ static inline int fdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
+
+// tile row r -> cell (rt, rh, rw) of the Tt x Ht x Wt tile.  m_hw / m_Wt are the magic numbers of the enumeration in use
+// (tfast: rows run along w, then T, then h -- the 16 rows of an MFMA fragment then differ by the halo's frame pitch, which
+// pick_halo_layout pads to a conflict-free residue; otherwise along w, then h, then T)
+__device__ static inline void row_cell(const ConvKP& p, int r, int& rt, int& rh, int& rw) {
+  const int inner = (p.tfast ? p.Tt : p.Ht) * p.Wt;
+  const int o = fdiv(r, p.m_hw), rem = r - o * inner;
+  const int i = fdiv(rem, p.m_Wt);
+  rw = rem - i * p.Wt;
+  rt = p.tfast ? i : o;
+  rh = p.tfast ? o : i;
+}
 
 // position-class bias row of an output position (flk_conv_args.pos_bias), or nullptr
 // (pos_bias_bstride != 0: one table per clip b -- per-clip perturbations)
@@ -345,12 +360,14 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
       const int hp = (tid >> 2) + 64 * n;
       int g = -2;
       if (hp < p.P) {
-        const int a = fdiv(hp, p.m_HW), rem = hp - a * HW;
-        const int bq = fdiv(rem, p.m_Wh), c = rem - bq * p.Wh;
-        const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
-        g = -1;
-        if ((unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
-          g = ((b * p.Ti + it) * p.Hi + ih) * p.Wi + iw;
+        const int a = fdiv(hp, p.m_HW), rem = hp - a * p.FP;
+        if (rem < HW) {                                   // (the slots between two frames, FP > Hh * Wh, are never read)
+          const int bq = fdiv(rem, p.m_Wh), c = rem - bq * p.Wh;
+          const int it = it0 + a, ih = ih0 + bq, iw = iw0 + c;
+          g = -1;
+          if ((unsigned)it < (unsigned)p.Ti && (unsigned)ih < (unsigned)p.Hi && (unsigned)iw < (unsigned)p.Wi)
+            g = ((b * p.Ti + it) * p.Hi + ih) * p.Wi + iw;
+        }
       }
       goff[n] = g;
     }
@@ -365,10 +382,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     const int r = wm * 64 + i * 16 + m;
     int pos = 0;
     if (r < p.rows) {
-      const int hw = p.Ht * p.Wt;
-      const int rt = fdiv(r, p.m_hw), rem = r - rt * hw;
-      const int rh = fdiv(rem, p.m_Wt), rw = rem - rh * p.Wt;
-      pos = ((rt * p.st) * p.Hh + rh * p.sh) * p.Wh + rw * p.sw;
+      int rt, rh, rw;
+      row_cell(p, r, rt, rh, rw);
+      pos = rt * p.st * p.FP + rh * p.sh * p.Wh + rw * p.sw;
     }
     rowpos[i] = pos * 16 + plane_off(q, p.plane_b);
   }
@@ -453,7 +469,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         }
       }
       int tapoff_t = 0;
-      for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.Hh * p.Wh * 16) {
+      for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.FP * 16) {
         int tapoff_h = tapoff_t;
         for (int dh = 0; dh < p.kh; ++dh, tapoff_h += p.Wh * 16) {
           int tapoff = tapoff_h;
@@ -555,7 +571,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         }
       }
       int tapoff_t = 0;
-      for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.Hh * p.Wh * 16) {
+      for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.FP * 16) {
         int tapoff = tapoff_t;
         for (int dh = 0; dh < p.kh; ++dh, tapoff += p.Wh * 16) {
           step(q0, r0, 0, tapoff);
@@ -603,7 +619,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         const int cls = (dt == 3) + 2 * (dh == 3);
         const int lo = cls == 0 ? 0 : cls == 1 ? lo1 : cls == 2 ? lo2 : lo3;
         const int wstride = cls == 0 ? 1 : cls == 3 ? 4 : 2;
-        int tapoff = (dt * p.Hh + dh) * p.Wh * 16 + lo;
+        int tapoff = (dt * p.FP + dh * p.Wh) * 16 + lo;
         for (int dw = 0; dw < 4; dw += wstride, tapoff += wstride * 16) {
           char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
           *(uint4*)(wcur + wchunk * 16) = wreg0;
@@ -833,7 +849,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
             if (++dh < p.kh) tapoff_h += p.Wh * 16;
             else {
               dh = 0;
-              if (++dt < p.kt) tapoff_t += p.Hh * p.Wh * 16;
+              if (++dt < p.kt) tapoff_t += p.FP * 16;
               else { dt = 0; tapoff_t = 0; ++s; newslab = true; }
               tapoff_h = tapoff_t;
             }
@@ -854,9 +870,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
   for (int i = 0; i < 4; ++i) {
     const int r = wm * 64 + i * 16 + m;
     if (r >= p.rows) continue;
-    const int hw = p.Ht * p.Wt;
-    const int rt = fdiv(r, p.m_hw), rem = r - rt * hw;
-    const int rh = fdiv(rem, p.m_Wt), rw = rem - rh * p.Wt;
+    int rt, rh, rw;
+    row_cell(p, r, rt, rh, rw);
     const int ot = ot0 + rt, oh = oh0 + rh, ow = ow0 + rw;
     if (ot >= p.To || oh >= p.Ho || ow >= p.Wo) continue;
     const size_t opos = ((size_t)(b * p.OT + ot * p.ost + p.oot) * p.OH + oh * p.osh + p.ooh) * p.OW + ow * p.osw + p.oow;
@@ -895,7 +910,8 @@ struct ConvGroupKP {
   int start[FLK_MAX_GROUP + 1];      // first block of member i; members past the last hold INT_MAX
 };
 // MODE 1: direct-A members of NFW fragments per wave and p.wn waves along N each.  MODE 0: ring members, all with the SAME channel tile
-// of NFW fragments (one wave row: the ring is sized by the template) -- the large launches whose weights go through LDS (Mixed_3*).
+// of NFW fragments (one wave row: the ring is sized by the template) -- the large launches whose weights go through LDS.  MODE 5: ring
+// members that ALL qualify for the weights a row of taps ahead (3-tap rows, large halos).
 template <typename T, int NFW, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_group_kernel(const ConvGroupKP g) {
   const int bx = (int)blockIdx.x;
@@ -1282,6 +1298,47 @@ static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
   return FLK_OK;
 }
 
+// Bank-conflict-free fragment reads.  A wave reads a position fragment with ds_read_b128: lane (q, m) fetches the 16-byte slot of tile
+// row 16 i + m in plane q, and the LDS serves the 16 lanes of one q together (16 x 16 bytes = all 64 banks) -- in one pass iff their
+// slots differ mod 16, in two when any two collide.  With rows enumerated along w, then h, a fragment of an 8-wide tile is two runs of 8
+// slots one halo row (Wh = 10) apart: slots 0..7 and 10..17 -> 0 / 16 and 1 / 17 collide, every such read takes twice the LDS cycles
+// (rocprofv3 on Conv3d_2c: SQ_LDS_BANK_CONFLICT = 30 % of SQ_LDS_IDX_ACTIVE, 4.7 cycles per position-fragment read).  Enumerated along w,
+// then T, the runs are one FRAME apart, and the frame pitch FP can be padded to any residue at <= 15 slots per frame: FP = Wt (mod 16)
+// makes the runs of a fragment consecutive mod 16.  Chosen per launch: the (enumeration, pad) with the fewest extra passes over the tile's
+// fragments, the unpadded w-h-T form on ties, and never at the price of a resident workgroup.  Same products, same K order per output:
+// the results do not change.
+static void pick_halo_layout(ConvKP& kp, int nf) {
+  static const int on = getenv("FLK_CONV_HALO_PAD") ? atoi(getenv("FLK_CONV_HALO_PAD")) : 1;
+  if (!on || kp.P <= 256) return;              // (the two-image path of small halos keeps its 256-slot images)
+  const int cells = kp.Hh * kp.Wh;
+  auto extra_passes = [&](int tfast, int FP) {
+    int total = 0;
+    for (int r0 = 0; r0 < kp.rows; r0 += 16) {
+      int cnt[16] = {}, mx = 0;
+      for (int r = r0; r < r0 + 16 && r < kp.rows; ++r) {
+        const int inner = (tfast ? kp.Tt : kp.Ht) * kp.Wt, o = r / inner, rem = r % inner, i = rem / kp.Wt, rw = rem % kp.Wt;
+        const int rt = tfast ? i : o, rh = tfast ? o : i;
+        const int c = ++cnt[(rt * kp.st * FP + rh * kp.sh * kp.Wh + rw * kp.sw) & 15];
+        mx = c > mx ? c : mx;
+      }
+      total += mx - 1;
+    }
+    return total;
+  };
+  auto lds_of = [&](int P) { return 4 * ((size_t)(P * 16 + 255) / 256 * 256) + 64 + 2 * (size_t)nf * 1024; };   // (with the weight ring)
+  const size_t cap = 160 * 1024;
+  const size_t res0 = std::min<size_t>(nf <= 4 ? 3 : 2, cap / lds_of(kp.P));
+  int best = extra_passes(0, cells), best_t = 0, best_fp = cells;
+  for (int pad = 0; pad < 16 && best > 0; ++pad)
+    for (int tfast = 0; tfast < 2 && best > 0; ++tfast) {
+      const int FP = cells + pad, P = (kp.Th - 1) * FP + cells;
+      if (P > FLK_MAX_HALO || std::min<size_t>(nf <= 4 ? 3 : 2, cap / lds_of(P)) < res0) continue;
+      const int c = extra_passes(tfast, FP);
+      if (c < best) { best = c; best_t = tfast; best_fp = FP; }
+    }
+  kp.tfast = best_t; kp.FP = best_fp; kp.P = (kp.Th - 1) * best_fp + cells;
+}
+
 constexpr int FLK_MAX_KSPLIT = 8;
 static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, int dtype, int nf, int wn, int mode);
 static bool dbg_on() { static const bool d = getenv("FLK_CONV_DBG") != nullptr; return d; }
@@ -1396,6 +1453,8 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   kp.Th = (t.Tt - 1) * a->st + a->kt; kp.Hh = (t.Ht - 1) * a->sh + a->kh; kp.Wh = (t.Wt - 1) * a->sw + a->kw;
   kp.P = kp.Th * kp.Hh * kp.Wh;
   FLK_REQUIRE(kp.P <= FLK_MAX_HALO && kp.rows <= FLK_ROWS / wn, "flk_conv3d: no tile fits (halo %d)", kp.P);
+  kp.FP = kp.Hh * kp.Wh; kp.tfast = 0;
+  pick_halo_layout(kp, nf);
   kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
   kp.nslab = w->nslab; kp.ntaps = w->ntaps; kp.cout_frags = w->cout_frags;
   if (a->in2) {
@@ -1418,7 +1477,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     kp.out2 = kp.out; kp.cout1 = a->cout;
   }
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
-  kp.m_HW = magic(kp.Hh * kp.Wh); kp.m_Wh = magic(kp.Wh); kp.m_hw = magic(kp.Ht * kp.Wt); kp.m_Wt = magic(kp.Wt);
+  kp.m_HW = magic(kp.FP); kp.m_Wh = magic(kp.Wh); kp.m_hw = magic((kp.tfast ? kp.Tt : kp.Ht) * kp.Wt); kp.m_Wt = magic(kp.Wt);
   kp.ntile_n = ntile_n;
   const long ptiles = (long)a->B * kp.nTt * kp.nTh * kp.nTw;
   // position tiles in contiguous chunks per XCD (halo-sharing neighbours in one L2): measured 6.82 -> 6.76 ms per step, conv kernels
@@ -1535,9 +1594,9 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   {
     static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
     if (dbg)
-      fprintf(stderr, "conv %dx%dx%d s%d%d%d cin %d cout %d out %dx%dx%dx%d | nf %d wn %d tile %dx%dx%d rows %d halo %d wgs %ld mode %d lds %zu\n",
+      fprintf(stderr, "conv %dx%dx%d s%d%d%d cin %d cout %d out %dx%dx%dx%d | nf %d wn %d tile %dx%dx%d rows %d halo %d (frame pitch %d + %d, rows %s) wgs %ld mode %d lds %zu\n",
               a->kt, a->kh, a->kw, a->st, a->sh, a->sw, a->cin, a->cout, a->B, a->To, a->Ho, a->Wo, nf, wn, kp.Tt, kp.Ht, kp.Wt,
-              kp.rows, kp.P, ptiles * ntile_n, mode, lds);
+              kp.rows, kp.P, kp.Hh * kp.Wh, kp.FP - kp.Hh * kp.Wh, kp.tfast ? "w-T-h" : "w-h-T", ptiles * ntile_n, mode, lds);
     if (dbg && kp.ksplit > 1) fprintf(stderr, "   split-K x%d (%d slabs)\n", kp.ksplit, kp.nslab);
   }
   if (plan) {
@@ -1598,6 +1657,7 @@ extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_we
   ConvGroupKP g{};
   size_t lds = 0;
   long total = 0;
+  bool all5 = ring != 0;
   for (int i = 0; i <= FLK_MAX_GROUP; ++i) g.start[i] = 0x7fffffff;
   for (int i = 0; i < n; ++i) {
     FLK_REQUIRE(a[i] && w[i] && w[i]->dev, "flk_conv3d_group: null member %d", i);
@@ -1607,8 +1667,9 @@ extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_we
     FLK_REQUIRE(w[i]->ntaps > 1 && !w[i]->stem4 && !a[i]->pos_bias, "flk_conv3d_group: member %d is not a multi-tap convolution", i);
     ConvPlan pl{};
     if (int rc = conv3d_impl(a[i], w[i], dtype, stream, ring ? 1 : w[i]->nf / nfw, ring ? 0 : 1, 0, &pl)) return rc;
-    // (ring members: a member planned for mode 5 -- the ring with the weights a row ahead -- has mode 0's arguments and LDS layout and runs the
-    //  group's mode-0 body)
+    // (ring members: a member planned for mode 5 -- the ring with the weights a row ahead -- has mode 0's arguments and LDS layout; the group
+    //  runs the mode-5 body when every member was planned so, the mode-0 body otherwise)
+    all5 = all5 && pl.mode == 5;
     FLK_REQUIRE((ring ? (pl.mode == 0 || pl.mode == 5) : pl.mode == 1) && pl.wn * nfw == (ring ? nfw : pl.nf) && pl.kp.ksplit == 1 && pl.grid.y == 1,
                 "flk_conv3d_group: member %d planned as mode %d, wn %d", i, pl.mode, pl.wn);
     g.m[i] = pl.kp;
@@ -1622,13 +1683,15 @@ extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_we
   }
   FLK_REQUIRE(total < (1l << 31), "flk_conv3d_group: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  static bool attr[4][FLK_MAX_DEVICES] = {};
+  static bool attr[6][FLK_MAX_DEVICES] = {};
+  static const bool group5 = !getenv("FLK_CONV_ROWAHEAD") || atoi(getenv("FLK_CONV_ROWAHEAD")) >= 2;    // 1: mode 5 in single launches only
+  const int gmode = ring ? (all5 && group5 ? 5 : 0) : 1;
 #define FLK_LAUNCH_GROUP(NFWv, MODEv, idx)                                                                                           \
-  if (nfw == NFWv && (ring ? 0 : 1) == MODEv) {                                                                                       \
+  if (nfw == NFWv && gmode == MODEv) {                                                                                                \
     if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, NFWv, MODEv>, 96 * 1024, attr[idx])) return rc;    \
     FLK_LAUNCH_KERNEL((conv_igemm_group_kernel<bf16_t, NFWv, MODEv>), dim3((unsigned)total), dim3(256), lds, s, g);                  \
   }
-  FLK_LAUNCH_GROUP(2, 1, 0) FLK_LAUNCH_GROUP(4, 1, 1) FLK_LAUNCH_GROUP(4, 0, 2) FLK_LAUNCH_GROUP(8, 0, 3)
+  FLK_LAUNCH_GROUP(2, 1, 0) FLK_LAUNCH_GROUP(4, 1, 1) FLK_LAUNCH_GROUP(4, 0, 2) FLK_LAUNCH_GROUP(8, 0, 3) FLK_LAUNCH_GROUP(4, 5, 4) FLK_LAUNCH_GROUP(8, 5, 5)
 #undef FLK_LAUNCH_GROUP
   flk_last_kernel_tag = "conv_igemm_group_kernel";
   FLK_CHECK_HIP(hipGetLastError());
