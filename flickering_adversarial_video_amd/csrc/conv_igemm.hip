@@ -1307,7 +1307,7 @@ static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
 // makes the runs of a fragment consecutive mod 16.  Chosen per launch: the (enumeration, pad) with the fewest extra passes over the tile's
 // fragments, the unpadded w-h-T form on ties, and never at the price of a resident workgroup.  Same products, same K order per output:
 // the results do not change.
-static void pick_halo_layout(ConvKP& kp, int nf) {
+static void pick_halo_layout(ConvKP& kp, size_t ring_bytes, int max_resident) {
   static const int on = getenv("FLK_CONV_HALO_PAD") ? atoi(getenv("FLK_CONV_HALO_PAD")) : 1;
   if (!on || kp.P <= 256) return;              // (the two-image path of small halos keeps its 256-slot images)
   const int cells = kp.Hh * kp.Wh;
@@ -1325,14 +1325,14 @@ static void pick_halo_layout(ConvKP& kp, int nf) {
     }
     return total;
   };
-  auto lds_of = [&](int P) { return 4 * ((size_t)(P * 16 + 255) / 256 * 256) + 64 + 2 * (size_t)nf * 1024; };   // (with the weight ring)
+  auto lds_of = [&](int P) { return 4 * ((size_t)(P * 16 + 255) / 256 * 256) + 64 + ring_bytes; };
   const size_t cap = 160 * 1024;
-  const size_t res0 = std::min<size_t>(nf <= 4 ? 3 : 2, cap / lds_of(kp.P));
+  const size_t res0 = std::min<size_t>(max_resident, cap / lds_of(kp.P));
   int best = extra_passes(0, cells), best_t = 0, best_fp = cells;
   for (int pad = 0; pad < 16 && best > 0; ++pad)
     for (int tfast = 0; tfast < 2 && best > 0; ++tfast) {
       const int FP = cells + pad, P = (kp.Th - 1) * FP + cells;
-      if (P > FLK_MAX_HALO || std::min<size_t>(nf <= 4 ? 3 : 2, cap / lds_of(P)) < res0) continue;
+      if (P > FLK_MAX_HALO || std::min<size_t>(max_resident, cap / lds_of(P)) < res0) continue;
       const int c = extra_passes(tfast, FP);
       if (c < best) { best = c; best_t = tfast; best_fp = FP; }
     }
@@ -1454,8 +1454,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   kp.P = kp.Th * kp.Hh * kp.Wh;
   FLK_REQUIRE(kp.P <= FLK_MAX_HALO && kp.rows <= FLK_ROWS / wn, "flk_conv3d: no tile fits (halo %d)", kp.P);
   kp.FP = kp.Hh * kp.Wh; kp.tfast = 0;
-  pick_halo_layout(kp, nf);
-  kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
+  kp.plane_b = (kp.P * 16 + 255) / 256 * 256;          // (pick_halo_layout may pad the image once the weight path is known)
   kp.nslab = w->nslab; kp.ntaps = w->ntaps; kp.cout_frags = w->cout_frags;
   if (a->in2) {
     FLK_REQUIRE(w->cin_split == a->cin1 && a->cin1 > 0 && a->cin1 < a->cin, "flk_conv3d: in2 given but weights were packed with "
@@ -1590,7 +1589,14 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     if (rowahead && mode == 0 && dtype == FLK_BF16 && a->kw == 3 && kp.P > 256 && (nf == 8 || nf == 6 || nf == 4 || nf == 2)) mode = 5;
   }
   // two halo images for small halos; the LDS weight ring only in mode 0 / 3 / 4 / 5
-  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ((mode == 0 || mode == 3 || mode == 4 || mode == 5) ? 2 * (size_t)nf * 1024 : 0);
+  const size_t ring_bytes = (mode == 0 || mode == 3 || mode == 4 || mode == 5) ? 2 * (size_t)nf * 1024 : 0;
+  if (!w->stem4) {
+    // workgroups per CU the registers allow: the ring kernels with <= 64-channel tiles hold three, everything else two
+    pick_halo_layout(kp, ring_bytes, (mode == 0 || mode == 5) && nf <= 4 ? 3 : 2);
+    kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
+    kp.m_HW = magic(kp.FP); kp.m_hw = magic((kp.tfast ? kp.Tt : kp.Ht) * kp.Wt);
+  }
+  const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ring_bytes;
   {
     static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
     if (dbg)

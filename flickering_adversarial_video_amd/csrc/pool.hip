@@ -321,6 +321,7 @@ struct PoolTP {
   PoolKP k;
   int Tt, Ht, Wt, nTt, nTh, nTw, Th, Hh, Wh, P, plane_b, rows, ntiles, nslab;
   int interleave;      // 1: tile i on XCD i % 8 (default); 0: contiguous chunks of tiles per XCD (FLK_POOL_XCD_CHUNK=1)
+  int legacy_skew;     // W-run forward: the plane skew of pplane_off (FLK_POOL_WSKEW=0; A/B timing)
   int dbg;             // timing experiments only (FLK_PF_DBG, W-run forward): 1 = no halo loads, 2 = no column maxima, 4 = no stores
 };
 
@@ -503,6 +504,12 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd_bf16(const PoolTP
 // element-taps per WT outputs instead of WT * 27 (2.1x fewer VALU operations at WT = 7; the pool is VALU-bound).  Tie rule unchanged:
 // the column stage tags a candidate with 255 - 3*(3 dt + dh), the combine stage subtracts dw, so the low byte is 255 - tap and the
 // larger one (first maximum in scan order) wins among equal keys.
+// plane of channel chunk c in the W-run kernel's halo image: 64 bytes of skew per plane.  gfx950 serves a ds_read_b128 / ds_write_b128 16
+// lanes at a time (16 x 16 bytes = the 64 banks) and in one pass iff the lanes' 16-byte units differ mod 16; the 16 lanes are 4 (t, h)
+// pairs x 4 channel chunks, the pairs' slots one halo row (WT + 2 = 9: odd) apart, so units 4 c + 9 j are all different.  The 32 bytes
+// per plane PAIR of pplane_off put chunks 0 / 1 and 2 / 3 on the same banks: rocprofv3 counted SQ_LDS_BANK_CONFLICT = 65 % of this
+// kernel's SQ_LDS_IDX_ACTIVE (four passes per read), as many LDS cycles per column as its VALU cycles.
+__device__ static inline int wplane_off(int c, int plane_b, int legacy) { return legacy ? c * plane_b + (c >> 1) * 32 : c * (plane_b + 64); }
 template <int WT>
 __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP p) {
   constexpr int EPL = 8, SLABC = 32;
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
       if (hp >= p.P) break;
       uint4 w = v[u];
       w.x = bf16x2_to_keys(w.x); w.y = bf16x2_to_keys(w.y); w.z = bf16x2_to_keys(w.z); w.w = bf16x2_to_keys(w.w);
-      *(uint4*)(smem + pplane_off(ch, p.plane_b) + hp * 16) = w;
+      *(uint4*)(smem + wplane_off(ch, p.plane_b, p.legacy_skew) + hp * 16) = w;
     }
   }
   __syncthreads();
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
     const int rt = qdiv(pr, 1.0f / (float)p.Ht), rh = pr - rt * p.Ht;
     const int ot = ot0 + rt, oh = oh0 + rh;
     if (ot >= k.To || oh >= k.Ho) continue;
-    const char* base = smem + pplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * WH) * 16;
+    const char* base = smem + wplane_off(ch, p.plane_b, p.legacy_skew) + ((rt * p.Hh + rh) * WH) * 16;
     uint32_t cm[3][8];
     auto colmax = [&](int c, uint32_t (&m)[8]) {
 #pragma unroll
@@ -640,9 +647,11 @@ static int launch_wrun_fwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t
   tp.Th = tp.Tt + 2; tp.Hh = tp.Ht + 2; tp.Wh = WT + 2;
   tp.P = tp.Th * tp.Hh * tp.Wh;
   tp.plane_b = (tp.P * 16 + 255) / 256 * 256;
-  const size_t lds = 4 * (size_t)tp.plane_b + 64;
+  const size_t lds = 4 * (size_t)tp.plane_b + 256;               // (wplane_off: 64 bytes of skew per plane)
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
   tp.interleave = pool_interleave();
+  static const bool legacy_skew = getenv("FLK_POOL_WSKEW") && atoi(getenv("FLK_POOL_WSKEW")) == 0;
+  tp.legacy_skew = legacy_skew;
 #ifdef FLK_ABLATE
   { const char* e = getenv("FLK_PF_DBG"); tp.dbg = e ? atoi(e) : 0; }
 #endif
