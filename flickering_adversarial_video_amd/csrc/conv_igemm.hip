@@ -289,6 +289,13 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // convolutions in one grid): NF then counts the channel fragments of ONE WAVE, the waves-along-N count is the member's run-time p.wn
 // and the workgroup tile is 16 * NF * p.wn channels wide -- direct-A weights (MODE 1) only, where the tile width appears in two
 // address computations and nowhere in the loop structure.
+// timing experiments on the row-ahead ring loop (-DCONV_ABLATE=bits builds only; WRONG results): 1 no wait for the weights, 2 no barrier per
+// step, 4 no ring write, 8 no MFMAs, 16 no position-fragment reads, 32 no weight-fragment reads.  The product build compiles every CAB() to true.
+#ifdef CONV_ABLATE
+#define CAB(bit) (!((CONV_ABLATE) & (bit)))
+#else
+#define CAB(bit) true
+#endif
 template <typename T, int NF, int WN, int MODE>
 __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, const int by) {
   constexpr bool K1 = MODE == 2 || MODE == 3;
@@ -501,7 +508,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
       }
     }
 
-  } else if constexpr (MODE == 5) {
+  } else if constexpr (MODE == 5 || MODE == 6) {
     // ---- mode 0 for kw = 3 with the weights fetched a ROW of three taps ahead.  Mode 0 requests the fragments of step k + 1 during step k:
     // one step is 16 NFW MFMAs = 256 cycles for a wave, an L2 round trip under load several times that, so every step of a workgroup ends
     // up as long as the round trip (timing-only build without MFMAs, halo loads and stores: Conv3d_2c still takes 0.117 of its 0.258 ms:
@@ -529,22 +536,54 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
       if constexpr (WCH == 2) asm volatile("s_waitcnt vmcnt(%2) ; release %0 %1" : "+v"(q), "+v"(r) : "i"(NWAIT) : "memory");
       else asm volatile("s_waitcnt vmcnt(%1) ; release %0" : "+v"(q) : "i"(NWAIT) : "memory");
     };
-    wload(q0, r0, 0); wload(q1, r1, 1); wload(q2, r2, 2);
+    // MODE 6: the ring write moves BEHIND the barrier.  Mode 5 (and 0) write the fragments of step k, wait for the write (lgkmcnt(0) of
+    // __syncthreads), meet at the barrier and then read them back: two LDS round trips in a row on every step's critical path, both behind
+    // the other two workgroups' reads in the LDS queue.  Here step k, once through its barrier, requests its fragments and THEN writes step
+    // k + 1's into the other slot (free: every wave passed barrier k with its reads of step k - 1 consumed); the write completes under the
+    // step's MFMAs and the lgkmcnt(0) of the next barrier finds it done.  The registers hold steps k + 1 .. k + 3.
+    constexpr bool WA = MODE == 6;
     int it_w = 0;
-    auto step = [&](u32x4& q, u32x4& r, int hsel, int tapoff) {
+    if constexpr (WA) {
+      wload(q0, r0, 0);
+      if constexpr (WCH == 2) asm volatile("s_waitcnt vmcnt(0) ; release %0 %1" : "+v"(q0), "+v"(r0) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) ; release %0" : "+v"(q0) :: "memory");
+      *(u32x4*)(wbuf + wchunk * 16) = q0;
+      if (WCH == 2 && w2ok) *(u32x4*)(wbuf + wchunk * 16 + 4096) = r0;
+      wload(q0, r0, 1); wload(q1, r1, 2); wload(q2, r2, 3);
+    } else {
+      wload(q0, r0, 0); wload(q1, r1, 1); wload(q2, r2, 2);
+    }
+    auto step = [&](u32x4& q, u32x4& r, int tapoff) {
       char* const wcur = wbuf + (it_w & 1) * (NF * 1024);
-      wwait(q, r);
-      *(u32x4*)(wcur + wchunk * 16) = q;
-      if (WCH == 2 && w2ok) *(u32x4*)(wcur + wchunk * 16 + 4096) = r;
-      ++it_w;
-      wload(q, r, it_w + 2);                            // the same tap of the next row (it_w is already k + 1; clamped past the end)
-      __syncthreads();
+      if constexpr (!WA) {
+        if (CAB(1)) wwait(q, r);
+        if (CAB(4)) {
+          *(u32x4*)(wcur + wchunk * 16) = q;
+          if (WCH == 2 && w2ok) *(u32x4*)(wcur + wchunk * 16 + 4096) = r;
+        }
+        ++it_w;
+        wload(q, r, it_w + 2);                          // the same tap of the next row (it_w is already k + 1; clamped past the end)
+      }
+      if (CAB(2)) __syncthreads();
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      frag bf[4], af[NFW];
       if (wave_active) {
-        frag bf[4], af[NFW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bf[i] = *(const frag*)(halo + hsel + rowpos[i] + tapoff);
+        for (int i = 0; i < 4; ++i) bf[i] = CAB(16) ? *(const frag*)(halo + rowpos[i] + tapoff) : __builtin_bit_cast(frag, q);
 #pragma unroll
-        for (int f = 0; f < NFW; ++f) af[f] = *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16);
+        for (int f = 0; f < NFW; ++f) af[f] = CAB(32) ? *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16) : __builtin_bit_cast(frag, q);
+      }
+      if constexpr (WA) {
+        char* const wnext = wbuf + ((it_w + 1) & 1) * (NF * 1024);
+        if (CAB(1)) wwait(q, r);
+        if (CAB(4)) {
+          *(u32x4*)(wnext + wchunk * 16) = q;
+          if (WCH == 2 && w2ok) *(u32x4*)(wnext + wchunk * 16 + 4096) = r;
+        }
+        ++it_w;
+        wload(q, r, it_w + 3);                          // (q held step k + 1 = it_w now; its next turn is step k + 4)
+      }
+      if (wave_active && CAB(8)) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < NFW; ++f)
@@ -570,13 +609,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
             if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
         }
       }
+      // every halo load has been consumed -- but behind exec-masked branches, so hipcc carries their destination registers as "maybe
+      // pending" into the tap loop and puts s_waitcnt vmcnt(0) in front of whatever reuses one (seen in the mode-6 listing: two per step,
+      // each draining the row-ahead queue).  An explicit vmcnt(0) it can see settles its scoreboard; free here: loads return in order and
+      // the halo loads are the youngest
+      __builtin_amdgcn_s_waitcnt(0x0F70);
       int tapoff_t = 0;
       for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.FP * 16) {
         int tapoff = tapoff_t;
         for (int dh = 0; dh < p.kh; ++dh, tapoff += p.Wh * 16) {
-          step(q0, r0, 0, tapoff);
-          step(q1, r1, 0, tapoff + 16);
-          step(q2, r2, 0, tapoff + 32);
+          step(q0, r0, tapoff);
+          step(q1, r1, tapoff + 16);
+          step(q2, r2, tapoff + 32);
         }
       }
     }
@@ -1634,6 +1678,16 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
     if (mode == 4 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 4>(kp, grid, lds, s);
     if (mode == 4 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 4>(kp, grid, lds, s);
+    // ring write behind the barrier (mode 6): measured on <= 64-channel tiles only (Conv3d_2c 0.2525 / 0.2467 -> 0.2478 / 0.2402 ms forward /
+    // data-gradient, Mixed_3c Branch_1 0.2348 -> 0.2308, 160 -> 320 at 25 088 positions 0.0955 -> 0.0922, the (1,3,3) 64 -> 144 layer 0.1398 ->
+    // 0.1315; 128- and 96-channel tiles the same: FLK_CONV_WRITEAHEAD=2 takes them too, 0 none)
+    static const int write_ahead = getenv("FLK_CONV_WRITEAHEAD") ? atoi(getenv("FLK_CONV_WRITEAHEAD")) : 1;
+    if (mode == 5 && write_ahead) {
+      if (wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 6>(kp, grid, lds, s);
+      if (wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 6>(kp, grid, lds, s);
+      if (wn == 1 && nf == 8 && write_ahead >= 2) return launch<bf16_t, 8, 1, 6>(kp, grid, lds, s);
+      if (wn == 1 && nf == 6 && write_ahead >= 2) return launch<bf16_t, 6, 1, 6>(kp, grid, lds, s);
+    }
     if (mode == 5 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 5>(kp, grid, lds, s);
     if (mode == 5 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 5>(kp, grid, lds, s);
     if (mode == 5 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 5>(kp, grid, lds, s);
@@ -1689,15 +1743,16 @@ extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_we
   }
   FLK_REQUIRE(total < (1l << 31), "flk_conv3d_group: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  static bool attr[6][FLK_MAX_DEVICES] = {};
+  static bool attr[7][FLK_MAX_DEVICES] = {};
   static const bool group5 = !getenv("FLK_CONV_ROWAHEAD") || atoi(getenv("FLK_CONV_ROWAHEAD")) >= 2;    // 1: mode 5 in single launches only
-  const int gmode = ring ? (all5 && group5 ? 5 : 0) : 1;
+  static const bool group6 = !getenv("FLK_CONV_WRITEAHEAD") || atoi(getenv("FLK_CONV_WRITEAHEAD")) != 0;   // ring write behind the barrier (64-channel tiles)
+  const int gmode = ring ? (all5 && group5 ? (group6 && nfw == 4 ? 6 : 5) : 0) : 1;
 #define FLK_LAUNCH_GROUP(NFWv, MODEv, idx)                                                                                           \
   if (nfw == NFWv && gmode == MODEv) {                                                                                                \
     if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, NFWv, MODEv>, 96 * 1024, attr[idx])) return rc;    \
     FLK_LAUNCH_KERNEL((conv_igemm_group_kernel<bf16_t, NFWv, MODEv>), dim3((unsigned)total), dim3(256), lds, s, g);                  \
   }
-  FLK_LAUNCH_GROUP(2, 1, 0) FLK_LAUNCH_GROUP(4, 1, 1) FLK_LAUNCH_GROUP(4, 0, 2) FLK_LAUNCH_GROUP(8, 0, 3) FLK_LAUNCH_GROUP(4, 5, 4) FLK_LAUNCH_GROUP(8, 5, 5)
+  FLK_LAUNCH_GROUP(2, 1, 0) FLK_LAUNCH_GROUP(4, 1, 1) FLK_LAUNCH_GROUP(4, 0, 2) FLK_LAUNCH_GROUP(8, 0, 3) FLK_LAUNCH_GROUP(4, 5, 4) FLK_LAUNCH_GROUP(8, 5, 5) FLK_LAUNCH_GROUP(4, 6, 6)
 #undef FLK_LAUNCH_GROUP
   flk_last_kernel_tag = "conv_igemm_group_kernel";
   FLK_CHECK_HIP(hipGetLastError());
