@@ -27,6 +27,9 @@ def test_no_compiler_access_to_in_flight_registers():
     r = _audit(SRC)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "kernels with asm loads audited, 0 with violations" in r.stdout and " 0 kernels" not in r.stdout
+    # second check of the same run: no compiler-generated vmcnt wait inside a row-ahead tap loop (modes 5 / 6, single and grouped)
+    assert "\n0 row-ahead kernels with compiler vmcnt waits in the tap loop" in r.stdout
+    assert "conv_igemm_group_kernel" in r.stdout, "the grouped ring kernels issue asm loads too"
 
 
 def test_audit_flags_a_minimal_hazard():
@@ -56,3 +59,21 @@ def test_audit_flags_the_pre_fix_k_loops(tmp_path):
     assert "touches in-flight" in r.stdout
     m = re.search(r"(\d+) kernels with asm loads audited, (\d+) with violations", r.stdout)
     assert m and int(m.group(1)) >= 30 and int(m.group(2)) >= 10, r.stdout[-500:]
+
+
+def test_audit_flags_a_drained_row_ahead_queue(tmp_path):
+    """the product source without the explicit vmcnt(0) behind the halo staging of the row-ahead kernels: hipcc then carries the halo
+    loads' destination registers as "maybe pending" into the tap loop and waits on vmcnt in front of the fragment reads that reuse them
+    -- every such wait drains the inline-asm weight queue (results correct, the layer 10 % slower: DESIGN.md, mode 6)"""
+    s = open(SRC).read()
+    line = "      __builtin_amdgcn_s_waitcnt(0x0F70);\n"
+    assert s.count(line) == 1, "conv_igemm.hip changed: update the fixture's patch"
+    p = tmp_path / "conv_igemm_noscoreboard.hip"
+    p.write_text(s.replace(line, ""))
+    r = _audit(str(p))
+    assert r.returncode == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "compiler wait inside the row-ahead tap loop" in r.stdout
+    import re
+    m = re.search(r"(\d+) row-ahead kernels with compiler vmcnt waits in the tap loop", r.stdout)
+    assert m and int(m.group(1)) >= 1, r.stdout[-500:]
+    assert re.search(r"kernels with asm loads audited, 0 with violations", r.stdout), "only the second check may fire"

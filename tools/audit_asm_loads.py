@@ -133,11 +133,38 @@ def audit_kernel(name, lines):
     return sum(1 for k, _, _ in ins if k == "gen"), violations
 
 
+ROWAHEAD = re.compile(r"Li[56]EEv(?:6ConvKP|11ConvGroupKP)$")       # conv_igemm_kernel<.., 5 | 6> and the grouped forms
+
+
+def rowahead_compiler_waits(lines):
+    """Second check, row-ahead ring kernels (modes 5 / 6) only: between the first and the last counted `s_waitcnt vmcnt(N > 0) ; release`
+    of the tap loop there must be NO compiler-generated vmcnt wait.  hipcc does not see the asm loads, so a wait it inserts for one of
+    ITS registers (a halo-load destination it still carries as "maybe pending" behind an exec-masked branch) drains the whole row-ahead
+    queue on every step -- correct results, 10 % slower (mode 6).  Returns the offending (line, instruction) pairs."""
+    sites, hits, in_asm = [], [], False
+    for i, raw in enumerate(lines):
+        st = raw.strip()
+        if st.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif st.startswith(";;#ASMEND"):
+            in_asm = False
+        elif in_asm:
+            m = re.search(r"s_waitcnt vmcnt\((\d+)\)\s*;\s*release", st)
+            if m and int(m.group(1)) > 0:
+                sites.append(i)
+        else:
+            code = st.split(";")[0].strip()
+            if code.startswith("s_waitcnt") and "vmcnt" in code:
+                hits.append((i, code))
+    return [h for h in hits if len(sites) >= 2 and sites[0] < h[0] < sites[-1]]
+
+
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_igemm.hip")
     text = compile_asm(src)
     bad = total = 0
-    for m in re.finditer(r"^(\S*(?:conv_igemm_kernel|pw_gemm_kernel)\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+    drained = 0
+    for m in re.finditer(r"^(\S*(?:conv_igemm_kernel|conv_igemm_group_kernel|pw_gemm_kernel)\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
         nloads, viol = audit_kernel(name, body)
         if nloads:
@@ -147,8 +174,14 @@ def main():
             for i, regs, l in uniq[:10]:
                 print(f"    line {i}: touches in-flight v{list(regs)}: {l}")
             bad += bool(uniq)
+            if ROWAHEAD.search(name):
+                waits = rowahead_compiler_waits(body)
+                for i, code in waits[:6]:
+                    print(f"    line {i}: compiler wait inside the row-ahead tap loop (drains the queue): {code}")
+                drained += bool(waits)
     print(f"{total} kernels with asm loads audited, {bad} with violations")
-    return 1 if bad else 0
+    print(f"{drained} row-ahead kernels with compiler vmcnt waits in the tap loop")
+    return 1 if bad or drained else 0
 
 
 if __name__ == "__main__":
