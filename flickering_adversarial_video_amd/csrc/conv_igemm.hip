@@ -1542,13 +1542,17 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   dim3 grid((unsigned)gx, (unsigned)kp.ksplit);
   hipStream_t s = (hipStream_t)stream;
   // Weight path.  Direct-A (modes 1/2) wherever a K step holds few MFMAs per wave and the waves would otherwise stall
-  // on the per-step barrier: all WN >= 2 layouts, and narrow channel tiles (nf <= 4) on grids of at most two
-  // workgroups per CU.  Everything else shares the weights through the LDS ring (mode 0).
+  // on the per-step barrier: all WN >= 2 layouts.  Everything else shares the weights through the LDS ring (mode 0 / 5 / 6).
+  // Until round 4 narrow channel tiles (nf <= 4) on grids of at most two workgroups per CU (<= 512) took direct-A as well; with the
+  // row-ahead ring kernels and the conflict-free halo images the ring wins there too (bs 8, four interleaved rounds on one box, threshold 512 /
+  // 448 / 336 / 256 / 0 workgroups: 5.694 / 5.685 / 5.674 / 5.658 / 5.644 ms per step; the other configurations neutral to -0.5 %:
+  // gpurun_out/da_ab.log, da_ab2.log).  FLK_CONV_DA_MAXWG=512: the old rule.
   int mode = 0;
   {
     static const bool no_k1 = getenv("FLK_CONV_NO_K1") != nullptr;
     static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
-    const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= 512);      // (nf = 6 is never narrow)
+    static const long da_maxwg = getenv("FLK_CONV_DA_MAXWG") ? atol(getenv("FLK_CONV_DA_MAXWG")) : 0;
+    const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= da_maxwg);      // (nf = 6 is never narrow)
     const bool k1 = kp.ntaps == 1 && kp.P <= 256;
     // direct A needs <= 4 fragments per wave (and >= 2 in bf16); the ring kernels are instantiated for wn == 1 only
     const int nfw = nf / wn;
