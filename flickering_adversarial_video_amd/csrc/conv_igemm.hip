@@ -1486,6 +1486,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
     const int force = force_wn > 0 ? force_wn : force_env ? atoi(force_env) : 0;
     while (true) {
       const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * ntile_n;
+      // (threshold re-measured at the round-4 kernels: 64 / 128 / 256 / 384 / 512 workgroups -> 5.715 / 5.628 / 5.586 / 5.619 / 5.607 ms per step)
       const bool more = w->stem4 ? false : force ? wn < force : (wgs < 256 && ksplit == 1);   // fewer workgroups than CUs (mode 4 is written for wn = 1)
       if (!more || wn * 2 > 4 || wn * 2 > wn_max) break;
       wn *= 2;

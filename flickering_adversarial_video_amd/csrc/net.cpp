@@ -240,6 +240,11 @@ struct flk_net {
     // SIMD), not by bytes: same total time alone, the step -0.035 ms (they overlap their neighbours better).  FLK_SMALL_NF=0: off
     if (dtype == FLK_BF16 && taps == 1 && small_nf() && rows >= 2048 && rows < 256L * 256 && cout > 64) return small_nf();
     // (the same for the 3x3x3 layers of those blocks: 6.122-6.124 vs 6.132-6.135 ms, within the noise; 96-wide: 6.32 ms -- not done)
+    // multi-tap layers on >= 256 position tiles (Mixed_3*): 64- instead of 128-channel tiles -- since the ring write moved behind the
+    // barrier on 64-channel tiles (conv_igemm.hip, mode 6) they are the faster kernels at equal padding (tools/nf_sweep.py, round 4:
+    // 96 -> 128 at 8x32x28x28 0.134 vs 0.148 ms, 192 -> 128 0.245 vs 0.263).  FLK_BIG_NF4=0: off
+    static const bool big_nf4 = !(getenv("FLK_BIG_NF4") && atoi(getenv("FLK_BIG_NF4")) == 0);
+    if (dtype == FLK_BF16 && taps > 1 && nf == 8 && rows >= 256L * 256 && big_nf4) return 4;
     return (dtype == FLK_BF16 && taps == 1 && nf == 2) ? 4 : nf;
   }
   static int small_nf() { static const int v = getenv("FLK_SMALL_NF") ? atoi(getenv("FLK_SMALL_NF")) : 4; return v == 4 || v == 8 ? (v == 8 ? 0 : 4) : 0; }
