@@ -21,6 +21,10 @@ int flk_head_backward(const void* y, int ld, int coff, void* gy, int gld, int gc
                       const float* wt, const float* W, int N, const float* dlogits, float* dfeat, int use_mask, int dtype,
                       hipStream_t s);
 
+// stem_grad.hip: the fused delta-gradient on a slice of the batch / its stage 2 (flk_stem_delta_grad = mask + one slice + stage 2)
+int flk_stem_delta_grad_part(const flk_apply_args* a, int b0, int nb, const void* G, int g_ld, const float* wf_dev, float* scratch, hipStream_t s);
+int flk_stem_delta_grad_finish(const flk_apply_args* a, int nb, float* scratch, float* gdelta, hipStream_t s);
+
 namespace {
 
 enum OpKind { K_CONV = 0, K_POOL = 1, K_HEAD = 2, K_OTHER = 3, K_FORK = 4, K_JOIN = 5 };
@@ -109,6 +113,10 @@ struct flk_net {
   float* d_stem_wf = nullptr;
   int stem_dgrad_op = -1;
   Act stem_G;
+  // set by flk_net_backward_delta for the duration of its run: the delta-gradient GEMM of clips [b0, b0 + nb), launched by the half-batch
+  // operators "Conv3d_1a_7x7/dgrad/half" of the split stem segment on their own streams (nullptr: those operators launch nothing)
+  std::function<int(int, int, hipStream_t)> delta_part;
+  int stem_halves = 1;         // parts the backward stem segment was emitted in
   // exact perturbation path of the stem's forward in bf16 (flk_net_forward_flicker): class sums of the weights, per-call table
   float* d_stem_sums = nullptr;
   float* d_stem_tab = nullptr;
@@ -596,10 +604,18 @@ int flk_net::build_i3d() {
         emit_conv_bwd(c2c, G2c, 0, G2b, 0, nullptr, 0, 0, &a2b, 0);
         emit_conv_bwd(c2b, G2b, 0, Gp2a, 0, nullptr, 0, 0, nullptr, 0);
         emit_pool_bwd("MaxPool3d_2a_3x3", h ? r2a1 : r2a0, Gp2a, G1, nullptr);
+        if (split) {
+          // the half's share of the fused stem delta-gradient, right behind the gradient it consumes: the MFMA-bound GEMM of one half
+          // runs beside the HBM-bound tail (1x1x1 data-gradient, pool backward) of the other instead of after both
+          // (flk_net_backward_delta; a no-op in every other run of this list)
+          const int b0 = bs_b0, nb = bs_nb;
+          bwd.push_back(Op{"Conv3d_1a_7x7/dgrad/half", K_CONV, 0.0, 0.0, [this, b0, nb](hipStream_t st) { return delta_part ? delta_part(b0, nb, st) : FLK_OK; }});
+        }
         set_lane(bwd, m0, h);
       }
       bs_b0 = bs_nb = 0;
       if (split) push_sync(bwd, K_JOIN, 1);
+      stem_halves = nhalf;
     });
   }
 
@@ -1455,11 +1471,24 @@ extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const fl
     if (rc) return rc;
     FLK_CHECK_HIP(hipEventRecord(n->ev_mask_done, n->mask_stream));
   }
-  const std::function<int(hipStream_t)> fused = [n, ac, gdelta, partials, beside](hipStream_t st) {
+  // the GEMM per half of the batch on the halves' own streams (multi-stream runs with the mask on its side stream only; measured
+  // FLK_STEM_DGRAD_SPLIT=0: one launch behind the join)
+  static const bool split_off = getenv("FLK_STEM_DGRAD_SPLIT") && atoi(getenv("FLK_STEM_DGRAD_SPLIT")) == 0;
+  const bool halves = beside && n->stem_halves == 2 && !split_off;
+  const int nb_half = n->B / 2;
+  if (halves)
+    n->delta_part = [n, ac, partials](int b0, int nb, hipStream_t st) {
+      FLK_CHECK_HIP(hipStreamWaitEvent(st, n->ev_mask_done, 0));
+      return flk_stem_delta_grad_part(&ac, b0, nb, n->stem_G.p, n->stem_G.ld, n->d_stem_wf, partials, st);
+    };
+  const std::function<int(hipStream_t)> fused = [n, ac, gdelta, partials, beside, halves, nb_half](hipStream_t st) {
+    if (halves) return flk_stem_delta_grad_finish(&ac, nb_half, partials, gdelta, st);
     if (beside) FLK_CHECK_HIP(hipStreamWaitEvent(st, n->ev_mask_done, 0));
     return flk_stem_delta_grad(&ac, n->stem_G.p, n->stem_G.ld, n->d_stem_wf, gdelta, partials, beside ? 1 : 0, st);
   };
-  return run_ops(n, n->bwd, n->ev_bwd, n->ev_bwd_valid, s, n->stem_dgrad_op, &fused);
+  const int rc = run_ops(n, n->bwd, n->ev_bwd, n->ev_bwd_valid, s, n->stem_dgrad_op, &fused);
+  n->delta_part = nullptr;
+  return rc;
 }
 
 // Optional: start the clip-mask pre-pass of the coming flk_net_backward_delta(a, scratch) NOW, on the net's own side stream -- called
@@ -1515,6 +1544,7 @@ extern "C" int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap) {
     const std::vector<const char*>& tags = &ops == &n->fwd ? n->tag_fwd : n->tag_bwd;
     for (size_t i = 0; i < ops.size(); ++i) {
       if (ops[i].kind == K_FORK || ops[i].kind == K_JOIN) continue;
+      if (ops[i].nlaunch == 0) continue;                  // (operators that had nothing to do in this run: the half-batch delta-gradient slots)
       FLK_CHECK_HIP(hipEventSynchronize(ev[i].second));
       float ms = 0.f;
       FLK_CHECK_HIP(hipEventElapsedTime(&ms, ev[i].first, ev[i].second));

@@ -495,6 +495,54 @@ extern "C" int flk_stem_delta_grad_mask(const flk_apply_args* a, float* scratch,
   return FLK_OK;
 }
 
+// chunks per frame pair for launches of nb clips each (per-clip perturbations: the chunking of a batch-1 call)
+static void sg_chunks(const flk_apply_args* a, int nb, int Ho, int& nchunk, int& rows_per_chunk) {
+  nchunk = sg_nchunk(a->delta_per_clip ? 1 : nb, a->T, Ho);
+  { static const char* e = getenv("FLK_SG_NCHUNK"); if (e && atoi(e) > 0) nchunk = atoi(e) < 16 ? atoi(e) : 16; }
+  rows_per_chunk = (Ho + nchunk - 1) / nchunk;
+  nchunk = (Ho + rows_per_chunk - 1) / rows_per_chunk;       // no empty chunks
+}
+
+// the GEMM for clips [b0, b0 + nb) of the batch (mask in the scratch already; stage-1 partials of those clips into their slots of the scratch).
+// A batch may be covered by several such launches of EQUAL nb (on different streams), followed by ONE flk_stem_delta_grad_finish with the same nb.
+int flk_stem_delta_grad_part(const flk_apply_args* a, int b0, int nb, const void* G, int g_ld, const float* wf_dev, float* scratch, hipStream_t s) {
+  int rc = sg_check(a);
+  if (rc) return rc;
+  FLK_REQUIRE(G && wf_dev && scratch, "flk_stem_delta_grad: null argument");
+  FLK_REQUIRE(g_ld >= SG_CO && g_ld % 8 == 0, "flk_stem_delta_grad: bad channel stride %d", g_ld);
+  FLK_REQUIRE(b0 >= 0 && nb > 0 && b0 + nb <= a->B, "flk_stem_delta_grad: clips [%d, %d) of %d", b0, b0 + nb, a->B);
+  StemGradKP kp{};
+  kp.B = nb; kp.T = a->T; kp.H = a->H;
+  kp.To = a->T / 2; kp.Ho = a->H / 2; kp.Wo = a->W / 2;
+  FLK_REQUIRE((size_t)a->B * kp.To * kp.Ho * kp.Wo * g_ld < (1ull << 31), "flk_stem_delta_grad: tensor too large");
+  sg_chunks(a, nb, kp.Ho, kp.nchunk, kp.rows_per_chunk);
+  // every use of the clip index in the kernel is linear in it: a slice is the same kernel on shifted bases
+  kp.G = (const char*)G + (size_t)b0 * kp.To * kp.Ho * kp.Wo * g_ld * 2; kp.g_ld = g_ld; kp.Wf = wf_dev;
+  kp.partials = scratch + (size_t)b0 * (a->T / 2) * kp.nchunk * 6;
+  kp.mask = (const char*)scratch + sg_partial_bytes(a->B, a->T, a->H) + (size_t)b0 * a->T * a->H * SG_ROWSET;
+#ifdef FLK_ABLATE
+  { static const char* e = getenv("FLK_SG_DBG"); kp.dbg = e ? atoi(e) : 0; }
+#endif
+  static bool attr_set[FLK_MAX_DEVICES] = {};
+  if ((rc = flk_raise_lds_limit((const void*)stem_delta_grad_kernel, SG_LDS, attr_set))) return rc;
+  FLK_LAUNCH_KERNEL(stem_delta_grad_kernel, dim3((unsigned)(nb * kp.To * kp.nchunk)), dim3(SG_THREADS), SG_LDS, s, kp);
+  FLK_CHECK_HIP(hipGetLastError());
+  flk_last_kernel_tag = "stem_delta_grad_kernel";
+  return FLK_OK;
+}
+
+// stage 2 over the whole batch, behind launches of nb clips each
+int flk_stem_delta_grad_finish(const flk_apply_args* a, int nb, float* scratch, float* gdelta, hipStream_t s) {
+  int rc = sg_check(a);
+  if (rc) return rc;
+  FLK_REQUIRE(scratch && gdelta && nb > 0 && a->B % nb == 0, "flk_stem_delta_grad_finish: bad argument");
+  int nchunk, rows;
+  sg_chunks(a, nb, a->H / 2, nchunk, rows);
+  flk_apply_args a2 = *a;
+  a2.fold_t = 2;                                       // stage 2 reads the partials as (frame pair, parity)
+  return flk_grad_reduce_stage2_launch(&a2, nchunk, scratch, gdelta, s);
+}
+
 // G: bf16 [B][T/2][H/2][W/2][g_ld] = d(loss)/d(pre-ReLU stem output) (64 channels); gdelta: [T,3] fp32.  mask_done != 0: the scratch
 // already holds the mask of these arguments (flk_stem_delta_grad_mask, ordered before this call by the caller).
 extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g_ld, const float* wf_dev, float* gdelta,
@@ -502,30 +550,9 @@ extern "C" int flk_stem_delta_grad(const flk_apply_args* a, const void* G, int g
   int rc = sg_check(a);
   if (rc) return rc;
   FLK_REQUIRE(G && wf_dev && gdelta && scratch, "flk_stem_delta_grad: null argument");
-  FLK_REQUIRE(g_ld >= SG_CO && g_ld % 8 == 0, "flk_stem_delta_grad: bad channel stride %d", g_ld);
-  StemGradKP kp{};
-  kp.G = (const char*)G; kp.g_ld = g_ld; kp.Wf = wf_dev; kp.partials = scratch;
-  kp.B = a->B; kp.T = a->T; kp.H = a->H;
-  kp.To = a->T / 2; kp.Ho = a->H / 2; kp.Wo = a->W / 2;
-  kp.mask = (const char*)scratch + sg_partial_bytes(a->B, a->T, a->H);
-  FLK_REQUIRE((size_t)a->B * kp.To * kp.Ho * kp.Wo * g_ld < (1ull << 31), "flk_stem_delta_grad: tensor too large");
-#ifdef FLK_ABLATE
-  { static const char* e = getenv("FLK_SG_DBG"); kp.dbg = e ? atoi(e) : 0; }
-#endif
-  kp.nchunk = sg_nchunk(a->delta_per_clip ? 1 : a->B, a->T, kp.Ho);      // per-clip perturbations: the chunking of a batch-1 call
-  { static const char* e = getenv("FLK_SG_NCHUNK"); if (e && atoi(e) > 0) kp.nchunk = atoi(e) < 16 ? atoi(e) : 16; }
-  kp.rows_per_chunk = (kp.Ho + kp.nchunk - 1) / kp.nchunk;
-  kp.nchunk = (kp.Ho + kp.rows_per_chunk - 1) / kp.rows_per_chunk;       // no empty chunks
-  static bool attr_set[FLK_MAX_DEVICES] = {};
-  if ((rc = flk_raise_lds_limit((const void*)stem_delta_grad_kernel, SG_LDS, attr_set))) return rc;
-  hipStream_t s = (hipStream_t)stream;
   if (!mask_done && (rc = flk_stem_delta_grad_mask(a, scratch, stream))) return rc;
-  FLK_LAUNCH_KERNEL(stem_delta_grad_kernel, dim3((unsigned)(a->B * kp.To * kp.nchunk)), dim3(SG_THREADS), SG_LDS, s, kp);
-  FLK_CHECK_HIP(hipGetLastError());
-  flk_last_kernel_tag = "stem_delta_grad_kernel";
-  flk_apply_args a2 = *a;
-  a2.fold_t = 2;                                       // stage 2 reads the partials as (frame pair, parity)
-  return flk_grad_reduce_stage2_launch(&a2, kp.nchunk, scratch, gdelta, s);
+  if ((rc = flk_stem_delta_grad_part(a, 0, a->B, G, g_ld, wf_dev, scratch, (hipStream_t)stream))) return rc;
+  return flk_stem_delta_grad_finish(a, a->B, scratch, gdelta, (hipStream_t)stream);
 }
 
 // ---- exact perturbation path of the stem's FORWARD in bf16 mode (flk_apply_args.center, flk_conv_args.pos_bias) -------------------
