@@ -658,8 +658,11 @@ int flk_net::build_i3d() {
     const long rows_blk = (long)B * cur.T * cur.H * cur.W;
     // Branch_1 + Branch_2 3x3x3 units as ONE launch per pass (Mixed_4* / Mixed_5* at the benchmark batch: launches of < 256 x 256 positions,
     // where Branch_2 alone runs at 40-250 TFLOP/s on a 27-step K loop): group layouts of the forward pass and of the data-gradients.
-    // FLK_GROUP_ROWS: largest position count that is grouped (default: below the Mixed_3* size)
-    static const long group_rows = getenv("FLK_GROUP_ROWS") ? atol(getenv("FLK_GROUP_ROWS")) : 256L * 256 - 1;
+    // FLK_GROUP_ROWS: largest position count that is grouped.  Until the row-ahead ring kernels (conv_igemm.hip modes 5 / 6) the Mixed_3*
+    // blocks (>= 256 x 256 positions at bs 8) were faster as two launches on two streams (65535: that rule); as RING groups they save a
+    // fork / join pair per block and pass and Branch_2's 27-step workgroups fill Branch_1's tail: 5.547 -> 5.502 ms per step (four
+    // interleaved pairs, gpurun_out/grows_ab.log)
+    static const long group_rows = getenv("FLK_GROUP_ROWS") ? atol(getenv("FLK_GROUP_ROWS")) : (1L << 40);
     GroupLayout gf, gb;
     static const long group_min_rows = getenv("FLK_GROUP_MIN_ROWS") ? atol(getenv("FLK_GROUP_MIN_ROWS")) : 8192;      // (below: Mixed_5*, 3136 positions at T = 64 and 4704 at T = 90 -- split-K launches)
     static const int group_dirs = getenv("FLK_GROUP") ? atoi(getenv("FLK_GROUP")) : 3;      // bit 0: forward, bit 1: data-gradients
