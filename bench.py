@@ -462,7 +462,14 @@ def main():
         # the dominant kernel alone: conv_igemm_kernel (every 3x3x3 / strided / small convolution, forward and data-gradient).  The stem's
         # forward (stem_fwd_u8_kernel), the 1x1x1 GEMMs (conv1x1_dma_kernel) and the stem's data-gradient (stem_delta_grad_kernel) are
         # kernels of their own and get their own entries below.
-        ig = by_kernel.get("conv_igemm_kernel") or {k: cv[k] - fused[k] for k in ("ms", "flops", "launches")}
+        # Its grouped form (conv_igemm_group_kernel: the SAME device function, conv_igemm_body, run over two convolutions in one grid --
+        # Branch_1 + Branch_2 of an Inception block) is counted with it: since the Mixed_3* blocks are grouped too, most of the body's
+        # time is spent in grouped launches.  A grouped launch is ONE launch.
+        IG = ("conv_igemm_kernel", "conv_igemm_group_kernel")
+        if any(k in by_kernel for k in IG):
+            ig = {f: sum(by_kernel[k][f] for k in IG if k in by_kernel) for f in ("ms", "flops", "bytes", "launches")}
+        else:
+            ig = {k: cv[k] - fused[k] for k in ("ms", "flops", "launches")}
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12
         # HBM traffic per launch comes from the committed rocprofv3 --pmc passes of this same command (bench.py cannot
         # profile itself): profiles/*_pmc_hbm_traffic.json, produced by tools/pmc_summary.py -- the file and the library
@@ -472,9 +479,11 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))[-1:]:
                 tj = json.load(open(f))
-                traffic = tj["kernels"]["conv_igemm_kernel"]["bytes_per_launch"]
+                tk = [tj["kernels"][k] for k in IG if k in tj["kernels"]]
+                traffic = sum(t["read_bytes"] + t["write_bytes"] for t in tk) / sum(t["launches"] for t in tk)
                 traffic_src = {"file": os.path.relpath(f, ROOT), "state": tj.get("state", "unknown")}
-        out["roofline"] = {"kernel": "conv_igemm_kernel (implicit-GEMM conv3d fwd + dgrad with LDS halo tiles: every 3x3x3 / strided layer)", "bound": "mfma",
+        out["roofline"] = {"kernel": "conv_igemm_kernel + conv_igemm_group_kernel = conv_igemm_body (implicit-GEMM conv3d fwd + dgrad with LDS halo tiles: every 3x3x3 / strided "
+                                     "layer, as single launches and as grouped launches of an Inception block's Branch_1 + Branch_2)", "bound": "mfma",
                            "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.dtype],
                            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, gfx950-corrected)", "traffic_source": traffic_src,
                            "compulsory_bytes_per_launch": ig["bytes"] / ig["launches"] if ig.get("bytes") else None,
@@ -484,8 +493,8 @@ def main():
                            "all_conv_achieved": cv["flops"] / (cv["ms"] * 1e-3) / 1e12}
         oth = {}
         for kn, kv in by_kernel.items():
-            if kn == "conv_igemm_kernel" or not kv["ms"]:
-                continue
+            if not kv["ms"]:
+                continue                                # (the two forms of conv_igemm_body are listed here as well, one entry each)
             tf, gb = kv["flops"] / (kv["ms"] * 1e-3) / 1e12, kv["bytes"] / (kv["ms"] * 1e-3) / 1e9
             mf = kv["flops"] / (PEAK_TFLOPS[a.dtype] * 1e12) >= kv["bytes"] / 8e12
             oth[kn] = {"bound": "mfma" if mf else "hbm", "launches_per_step": kv["launches"] // reps, "ms_per_step": kv["ms"] / reps,
