@@ -869,3 +869,40 @@ def test_operator_launch_count_may_change_between_runs():
     ref = run(["fwd"])[0]
     for got in run(["fwd", "apply", "fwd", "apply", "apply", "fwd"]):
         assert torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_stem_delta_gradient_per_half_batch_equals_one_launch():
+    """bf16 plans with an even batch >= 4 run the fused stem delta-gradient once per HALF of the batch, on the halves' own streams, and
+    stage 2 behind the join (net.cpp: "Conv3d_1a_7x7/dgrad/half", flk_stem_delta_grad_part / _finish).  With the per-launch profile on the
+    plan runs serially and takes the one-launch path: same mask, same products, the stage-1 partials summed in another chunking -- the two
+    gradients agree to fp32 summation order (stated 2e-5 of the largest entry; measured 1e-7).  Alternating the two modes leaves every
+    run of a mode bitwise equal to the first one (the half-batch operators launch nothing in the serial runs; the stop events armed on them
+    follow the launch count of the previous run)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from flickering_adversarial_video_amd import i3d_spec
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
+    B = 4
+    eng = FlickerI3D(i3d_spec.synthetic_i3d_weights(42), batch_size=B, frames=T, dtype="bf16")
+    assert eng.fused_delta_grad
+    xu = torch.from_numpy(i3d_spec.synthetic_clip_u8(B, T, seed=21)).cuda()
+    eng.perturbation.copy_(torch.from_numpy(np.random.default_rng(5).uniform(-0.1, 0.1, (T, 1, 1, 3)).astype(np.float32)))
+    labels = eng.logits(xu, adv_flag=0.0).argmax(-1).clone()
+
+    def grad(serial):
+        eng.net.profile(serial)
+        eng.step(xu, labels, update=False)
+        g = eng.delta_gradient().clone()
+        torch.cuda.synchronize()
+        eng.net.profile(False)
+        return g
+
+    halves, whole = grad(False), grad(True)
+    scale = float(whole.abs().max())
+    assert scale > 0
+    err = float((halves - whole).abs().max()) / scale
+    print(f"stem delta-gradient, two half-batch launches vs one: max |diff| / max |g| = {err:.2e}")
+    assert err <= 2e-5
+    for serial, ref in ((False, halves), (True, whole), (False, halves), (False, halves), (True, whole)):
+        assert torch.equal(grad(serial), ref)
