@@ -291,6 +291,8 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // address computations and nowhere in the loop structure.
 // timing experiments on the row-ahead ring loop (-DCONV_ABLATE=bits builds only; WRONG results): 1 no wait for the weights, 2 no barrier per
 // step, 4 no ring write, 8 no MFMAs, 16 no position-fragment reads, 32 no weight-fragment reads.  The product build compiles every CAB() to true.
+// (The substitutes for skipped reads are ZERO fragments: a substitute taken from a weight-queue register faulted -- DESIGN.md, round-4 fault.
+//  Put every variant build through tools/audit_asm_loads.py <this file> -DCONV_ABLATE=... before it goes to the GPU.)
 #ifdef CONV_ABLATE
 #define CAB(bit) (!((CONV_ABLATE) & (bit)))
 #else
@@ -569,9 +571,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
       frag bf[4], af[NFW];
       if (wave_active) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bf[i] = CAB(16) ? *(const frag*)(halo + rowpos[i] + tapoff) : __builtin_bit_cast(frag, q);
+        for (int i = 0; i < 4; ++i) bf[i] = CAB(16) ? *(const frag*)(halo + rowpos[i] + tapoff) : frag{};
 #pragma unroll
-        for (int f = 0; f < NFW; ++f) af[f] = CAB(32) ? *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16) : __builtin_bit_cast(frag, q);
+        for (int f = 0; f < NFW; ++f) af[f] = CAB(32) ? *(const frag*)(wcur + ((wn * NFW + f) * 64 + lane) * 16) : frag{};
       }
       if constexpr (WA) {
         char* const wnext = wbuf + ((it_w + 1) & 1) * (NF * 1024);

@@ -8,7 +8,7 @@ while the data is still in flight -- which shows up as garbage operands or a mem
 to assembly and checks, for every kernel, that on no path between an asm load and the wait statement that releases its
 destination a compiler-generated instruction reads or writes that register (forward dataflow over the kernel's CFG).
 
-Usage: audit_asm_loads.py [path/to/conv_igemm.hip]   (exit code 1 on a violation).  Needs hipcc; no GPU."""
+Usage: audit_asm_loads.py [path/to/conv_igemm.hip] [-DFLAG=...]   (exit code 1 on a violation).  Needs hipcc; no GPU."""
 import os
 import re
 import subprocess
@@ -29,11 +29,11 @@ def regs_of(text):
     return out
 
 
-def compile_asm(src):
+def compile_asm(src, extra=()):
     hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc") if c and (os.path.exists(c) or c == "hipcc")), "hipcc")
     out = os.path.join(tempfile.mkdtemp(prefix="flk_audit_"), "k.s")
     inc = [os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc"), os.path.join(ROOT, "include")]
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *(f"-I{d}" for d in inc), "-o", out, src],
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", *(f"-I{d}" for d in inc), *extra, "-o", out, src],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return open(out).read()
 
@@ -160,8 +160,10 @@ def rowahead_compiler_waits(lines):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_igemm.hip")
-    text = compile_asm(src)
+    args = [a for a in sys.argv[1:] if not a.startswith("-")]
+    extra = [a for a in sys.argv[1:] if a.startswith("-")]       # e.g. -DCONV_ABLATE=48: audit a timing-only variant BEFORE it runs on a GPU
+    src = args[0] if args else os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_igemm.hip")
+    text = compile_asm(src, extra)
     bad = total = 0
     drained = 0
     for m in re.finditer(r"^(\S*(?:conv_igemm_kernel|conv_igemm_group_kernel|pw_gemm_kernel)\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
