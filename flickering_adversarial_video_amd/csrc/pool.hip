@@ -214,8 +214,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const PoolKP p) {
   }
 }
 
-// Backward of the STRIDED pools (MaxPool3d_2a/3a/4a/5a, i3d.py:174,189,252,398; pad-before 0, window <= 2 * stride):
-// one thread = one output window x one 16-byte channel group, and it OWNS the stride^3 input cells o*s + a, a in [0,s).
+// Backward of the STRIDED pools (MaxPool3d_2a/3a/4a/5a, i3d.py:174,189,252,398; window <= 2 * stride; SAME pad-before p < stride per
+// dimension: 0 on even sizes, 1 on the odd ones the reference's 90-frame clips produce -- T/2 = 45, 23):
+// one thread = one output window x one 16-byte channel group, and it OWNS the stride^3 input cells o*s - p + a, a in [0,s).
 // A cell is covered by its own window (tap a) and, where a + s < k, by the previous window of that dimension (tap
 // a + s): every thread loads the index bytes and gradients of its <= 8 candidate windows up front (independent loads,
 // shared with its neighbours through L1/L2), then resolves its cells in registers in a fixed order -- no atomics,
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void maxpool_strided_bwd(const PoolKP p) {
       for (int ah = 0; ah < SH; ++ah)
 #pragma unroll
         for (int aw = 0; aw < SW; ++aw) {
-          const int it = min(ot * ST + at, p.Ti - 1), ih = min(oh * SH + ah, p.Hi - 1), iw = min(ow * SW + aw, p.Wi - 1);
+          const int it = min(max(ot * ST - p.pt + at, 0), p.Ti - 1), ih = min(max(oh * SH - p.ph + ah, 0), p.Hi - 1), iw = min(max(ow * SW - p.pw + aw, 0), p.Wi - 1);
           const size_t ipos = (((size_t)(b * p.Ti + it) * p.Hi + ih) * p.Wi + iw);
           PV<T>::ld(p.mask + (ipos * p.mask_ld + p.mask_coff + cg * EPL) * sizeof(T), mk[(at * SH + ah) * SW + aw]);
         }
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(256) void maxpool_strided_bwd(const PoolKP p) {
     for (int ah = 0; ah < SH; ++ah)
 #pragma unroll
       for (int aw = 0; aw < SW; ++aw) {
-        const int it = ot * ST + at, ih = oh * SH + ah, iw = ow * SW + aw;
-        if (it >= p.Ti || ih >= p.Hi || iw >= p.Wi) continue;
+        const int it = ot * ST - p.pt + at, ih = oh * SH - p.ph + ah, iw = ow * SW - p.pw + aw;
+        if ((unsigned)it >= (unsigned)p.Ti || (unsigned)ih >= (unsigned)p.Hi || (unsigned)iw >= (unsigned)p.Wi) continue;
         float g[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e) g[e] = 0.f;
@@ -306,10 +307,10 @@ static int launch_strided_bwd(const PoolKP& kp, const flk_pool_args* a, hipStrea
   return FLK_OK;
 }
 
-// the owner form needs pad-before 0 and every input cell inside some window's stride box
+// the owner form needs a pad-before below the stride and every input cell inside some window's stride box [o*s - p, o*s - p + s)
 static bool strided_owner_ok(const flk_pool_args* a, int kt, int kh, int kw, int st, int sh, int sw) {
-  return a->kt == kt && a->kh == kh && a->kw == kw && a->st == st && a->sh == sh && a->sw == sw && a->pt == 0 && a->ph == 0 &&
-         a->pw == 0 && a->Ti <= a->To * st && a->Hi <= a->Ho * sh && a->Wi <= a->Wo * sw;
+  return a->kt == kt && a->kh == kh && a->kw == kw && a->st == st && a->sh == sh && a->sw == sw && a->pt >= 0 && a->pt < st && a->ph >= 0 &&
+         a->ph < sh && a->pw >= 0 && a->pw < sw && a->Ti <= a->To * st - a->pt && a->Hi <= a->Ho * sh - a->ph && a->Wi <= a->Wo * sw - a->pw;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1156,7 +1157,10 @@ __global__ __launch_bounds__(256, KS >= 3 ? 2 : 3) void maxpool_scatter_gemm_bwd
 
 // input-cell tile for the scatter backward: minimise bytes moved per useful cell (tile writes + the windows read,
 // which overlap between neighbouring tiles) plus a fixed per-workgroup cost
-static flk_tile choose_scatter_tile(const flk_pool_args* a) {
+// max_reach > 0: only tiles reached by at most that many windows (the register-resident fused Branch_3 backward holds 64 x 8 of them; the
+// reference's 90-frame clips -- T/2 = 45 frames in Mixed_3* -- otherwise get 5-frame tiles reached by 567 windows and the slower loop form:
+// Mixed_3c 0.249 ms against 0.19 for 1.41 x the positions of the 64-frame clips)
+static flk_tile choose_scatter_tile(const flk_pool_args* a, long max_reach = 0) {
   flk_tile best{1, 1, 1};
   double best_cost = 1e300;
   for (int Tt = 1; Tt <= a->Ti && Tt <= 8; ++Tt)
@@ -1165,6 +1169,7 @@ static flk_tile choose_scatter_tile(const flk_pool_args* a) {
       for (int Wt = 1; Wt <= wmax; ++Wt) {
         const double tiles = (double)((a->Ti + Tt - 1) / Tt) * ((a->Hi + Ht - 1) / Ht) * ((a->Wi + Wt - 1) / Wt);
         const double outs = (double)((Tt + a->kt - 2) / a->st + 1) * ((Ht + a->kh - 2) / a->sh + 1) * ((Wt + a->kw - 2) / a->sw + 1);
+        if (max_reach > 0 && outs > (double)max_reach) continue;
         const double passes = (double)(((long)outs + 255) / 256);           // 64 position threads x 4-deep unroll
         const double cost = tiles * (Tt * Ht * Wt * 16.0 + outs * 24.0 + passes * 2048.0 + 2048.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = flk_tile{Tt, Ht, Wt}; }
@@ -1380,7 +1385,10 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
 #ifdef FLK_ABLATE
   { const char* e = getenv("FLK_PG_DBG"); pg.dbg = e ? atoi(e) : 0; }
 #endif
-  const flk_tile t = choose_scatter_tile(a);
+  const char* const reg_env = getenv("FLK_POOL_GEMM_REG");     // (read per call: the tests compare the two forms)
+  const bool reg_form = !(reg_env && atoi(reg_env) == 0);
+  const bool reg_able = reg_form && a->kt == 3 && a->kh == 3 && a->kw == 3;
+  const flk_tile t = choose_scatter_tile(a, reg_able ? 512 : 0);
   PoolTP& tp = pg.t;
   tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
   tp.nTt = (a->Ti + t.Tt - 1) / t.Tt; tp.nTh = (a->Hi + t.Ht - 1) / t.Ht; tp.nTw = (a->Wi + t.Wt - 1) / t.Wt;
@@ -1399,9 +1407,7 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   const unsigned m1 = magic(a->kh * a->kw), m2 = magic(a->kw);
   // windows that can reach a tile: at most 64 * 8 -> the register-resident form
   const long reach = (long)((t.Tt + a->kt - 2) / a->st + 1) * ((t.Ht + a->kh - 2) / a->sh + 1) * ((t.Wt + a->kw - 2) / a->sw + 1);
-  const char* const reg_env = getenv("FLK_POOL_GEMM_REG");     // (read per call: the tests compare the two forms)
-  const bool reg_form = !(reg_env && atoi(reg_env) == 0);
-  if (reg_form && reach <= 512 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
+  if (reg_able && reach <= 512) {
     const size_t lds_reg = lds + (size_t)(64 + 256 + 256) * sizeof(unsigned);      // + the tap table + one dummy word per thread
     switch (pg.KS) {
       case 1: FLK_LAUNCH_KERNEL((maxpool_scatter_gemm_bwd_reg<1, 8, 4>), grid, dim3(256), lds_reg, s, pg, m1, m2); break;

@@ -224,8 +224,8 @@ def test_conv_data_gradient(ops, dtype, k, cin, cout, nf):
 @pytest.mark.parametrize("k,s,dims", [((1, 3, 3), (1, 2, 2), (4, 28, 28)), ((3, 3, 3), (2, 2, 2), (8, 14, 14)),
                                       ((2, 2, 2), (2, 2, 2), (4, 14, 14)), ((3, 3, 3), (1, 1, 1), (3, 7, 7)),
                                       ((3, 3, 3), (2, 2, 2), (5, 7, 9)), ((3, 3, 3), (1, 1, 1), (5, 13, 30)),
-                                      ((1, 3, 3), (1, 1, 1), (3, 9, 9))],
-                         ids=["2a", "4a", "5a", "branch3", "odd", "branch3_ragged_tiles", "1x3x3_s1"])
+                                      ((1, 3, 3), (1, 1, 1), (3, 9, 9)), ((3, 3, 3), (2, 2, 2), (23, 14, 14)), ((1, 3, 3), (1, 2, 2), (3, 15, 13))],
+                         ids=["2a", "4a", "5a", "branch3", "odd", "branch3_ragged_tiles", "1x3x3_s1", "4a_T90_odd_frames", "1x3x3_s2_odd"])
 def test_maxpool_fwd_bwd(ops, dtype, k, s, dims):
     B, C_ = 2, 24
     T, H, W = dims
