@@ -946,6 +946,15 @@ void flk_net::emit_gen_fwd(ConvLayer* L, const Act& in, const Act& out, bool rel
 }
 
 void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const void* add, int add_ld, const Act* mask) {
+  // The parity classes of a strided layer's data-gradient write disjoint output cells and are small launches on their latency floor.  The
+  // EIGHT classes of a 3x3x3 / 2 layer (r3d_18 layer2-4.0) run side by side on the caller's stream and the two side streams: r3d_18 bs 8 2.91 ->
+  // 2.81 ms per iteration.  With two or four classes ((3,1,1) / (2,1,1), (1,3,3) / (1,2,2): r2plus1d_18, mc3_18) the fork / join pair costs
+  // more than the overlap gives (r2plus1d_18 bs 8 4.24 -> 4.37, bs 1 2.20 -> 2.36; mc3_18 the same; gpurun_out/lanes_ab.log): those stay in
+  // line.  FLK_VRN_CLASS_LANES=0: always in line; =2: from two classes on.
+  static const int lanes_mode = getenv("FLK_VRN_CLASS_LANES") ? atoi(getenv("FLK_VRN_CLASS_LANES")) : 1;
+  const bool par = lanes_mode != 0 && L->bcls.size() >= (lanes_mode == 2 ? 2u : 8u);
+  if (par) push_sync(bwd, K_FORK, ~0);
+  int ci = 0;
   for (const auto& bc : L->bcls) {
     flk_conv_args a{};
     a.in = G.p; a.in_ld = G.ld; a.cin = L->cout; a.B = B; a.Ti = G.T; a.Hi = G.H; a.Wi = G.W;
@@ -960,8 +969,11 @@ void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const voi
     flk_conv_weights* wb = bc.w;
     const int dt = dtype;
     attach_splitk(a, wb);
+    const size_t m0 = bwd.size();
     bwd.push_back(Op{L->name + "/dgrad", K_CONV, 2.0 * macs, conv_bytes(a), [a, wb, dt](hipStream_t s) { return flk_conv3d(&a, wb, dt, s); }});
+    if (par) set_lane(bwd, m0, ci++ % (kSideStreams + 1));
   }
+  if (par) push_sync(bwd, K_JOIN, ~0);
 }
 
 int flk_net::build_videoresnet() {
