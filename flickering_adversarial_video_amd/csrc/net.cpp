@@ -952,7 +952,7 @@ void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const voi
   // more than the overlap gives (r2plus1d_18 bs 8 4.24 -> 4.37, bs 1 2.20 -> 2.36; mc3_18 the same; gpurun_out/lanes_ab.log): those stay in
   // line.  FLK_VRN_CLASS_LANES=0: always in line; =2: from two classes on.
   static const int lanes_mode = getenv("FLK_VRN_CLASS_LANES") ? atoi(getenv("FLK_VRN_CLASS_LANES")) : 1;
-  const bool par = lanes_mode != 0 && L->bcls.size() >= (lanes_mode == 2 ? 2u : 8u);
+  const bool par = lanes_mode != 0 && L->bcls.size() >= (lanes_mode == 2 ? 2u : lanes_mode == 4 ? 4u : 8u);
   if (par) push_sync(bwd, K_FORK, ~0);
   int ci = 0;
   for (const auto& bc : L->bcls) {
