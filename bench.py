@@ -465,7 +465,7 @@ def main():
         # Its grouped form (conv_igemm_group_kernel: the SAME device function, conv_igemm_body, run over two convolutions in one grid --
         # Branch_1 + Branch_2 of an Inception block) is counted with it: since the Mixed_3* blocks are grouped too, most of the body's
         # time is spent in grouped launches.  A grouped launch is ONE launch.
-        IG = ("conv_igemm_kernel", "conv_igemm_group_kernel")
+        IG = ("conv_igemm_kernel", "conv_igemm_group_kernel", "conv_pc_kernel")      # (conv_pc_kernel: the persistent producer / consumer form the large 3x3x3 launches take, round 5)
         if any(k in by_kernel for k in IG):
             ig = {f: sum(by_kernel[k][f] for k in IG if k in by_kernel) for f in ("ms", "flops", "bytes", "launches")}
         else:
@@ -482,8 +482,9 @@ def main():
                 tk = [tj["kernels"][k] for k in IG if k in tj["kernels"]]
                 traffic = sum(t["read_bytes"] + t["write_bytes"] for t in tk) / sum(t["launches"] for t in tk)
                 traffic_src = {"file": os.path.relpath(f, ROOT), "state": tj.get("state", "unknown")}
-        out["roofline"] = {"kernel": "conv_igemm_kernel + conv_igemm_group_kernel = conv_igemm_body (implicit-GEMM conv3d fwd + dgrad with LDS halo tiles: every 3x3x3 / strided "
-                                     "layer, as single launches and as grouped launches of an Inception block's Branch_1 + Branch_2)", "bound": "mfma",
+        out["roofline"] = {"kernel": "conv_igemm_kernel + conv_igemm_group_kernel (conv_igemm_body) + conv_pc_kernel: implicit-GEMM conv3d fwd + dgrad with LDS halo tiles -- every "
+                                     "3x3x3 / strided layer, as single launches, as grouped launches of an Inception block's Branch_1 + Branch_2, and (the large layers at the benchmark "
+                                     "batch) as persistent launches with wave-specialised producers", "bound": "mfma",
                            "achieved": ach, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[a.dtype],
                            "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC, gfx950-corrected)", "traffic_source": traffic_src,
                            "compulsory_bytes_per_launch": ig["bytes"] / ig["launches"] if ig.get("bytes") else None,

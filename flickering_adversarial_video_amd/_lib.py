@@ -111,6 +111,10 @@ _SIGS = {
     "flk_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "flk_conv_splitk_bytes": (C.c_int64, [C.POINTER(ConvArgs), C.c_void_p]),
     "flk_conv3d_group": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "flk_conv3d_pc": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    "flk_conv3d_pc_worthwhile": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "flk_conv3d_pc_why_not": (C.c_char_p, [C.POINTER(ConvArgs), C.c_void_p, C.c_int]),
+    "flk_conv3d_group_check": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "flk_conv_layout_query": (C.c_int, [C.POINTER(ConvArgs), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "flk_comm_unique_id": (C.c_int, [C.c_void_p]),
     "flk_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -136,6 +140,8 @@ _SIGS = {
     "flk_conv_set_autotune": (C.c_int, [C.c_int]),
     "flk_net_profile_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "flk_net_input_numel": (C.c_int64, [C.c_void_p]),
+    "flk_net_input_channels": (C.c_int, [C.c_void_p]),
+    "flk_net_input_fold": (C.c_int, [C.c_void_p]),
     "flk_net_num_classes": (C.c_int, [C.c_void_p]),
     "flk_net_get_activation": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
 }

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libflicker_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "pool.hip", "head.hip", "attack.hip", "stem_grad.hip", "stem_fwd.hip", "net.cpp", "comm.cpp"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv_pc.hip", "pool.hip", "head.hip", "attack.hip", "stem_grad.hip", "stem_fwd.hip", "net.cpp", "comm.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-x", "hip"]
 
@@ -26,8 +26,29 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# sources that issue asynchronous loads from inline asm (hand-counted s_waitcnt vmcnt): hipcc does not know those loads are in flight
+ASM_LOAD_SOURCES = ["conv_igemm.hip", "conv_pc.hip"]
+
+
+def audit_asm_sources(sources, extra_flags):
+    """tools/audit_asm_loads.py on each of `sources` (names under csrc/) that issues inline-asm loads, compiled WITH extra_flags: raises
+    when a compiler-generated instruction can touch a register whose asm load is still in flight.  Every non-default build of such a file
+    (FLK_HIPCC_EXTRA, tools/build_variant.py) goes through this before anything is linked: the timing-only variants that faulted GPU boxes
+    in rounds 1 and 4 were builds the audit would have refused."""
+    audit = os.path.join(HERE, "..", "tools", "audit_asm_loads.py")
+    for src in sources:
+        if src not in ASM_LOAD_SOURCES:
+            continue
+        r = subprocess.run([sys.executable, audit, os.path.join(CSRC, src)] + list(extra_flags), capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"asm-load audit of {src} with flags {list(extra_flags)} FAILED -- not building:\n" + r.stdout[-3000:] + r.stderr[-2000:])
+
+
 def build(force=False, verbose=True):
     hipcc = _hipcc()
+    extra = os.environ.get("FLK_HIPCC_EXTRA", "").split()
+    if extra:
+        audit_asm_sources(SOURCES, extra)       # a flagged variant never reaches the linker (and so never a GPU)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "flicker_hip.h"))
     objs, jobs = [], []
@@ -36,7 +57,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + os.environ.get("FLK_HIPCC_EXTRA", "").split() + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + extra + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -240,8 +240,7 @@ extern "C" int flk_perturb_apply_s2d(const flk_apply_args* a, void* out, int dty
     return FLK_OK;
   }
   const bool bf = dtype == FLK_BF16;
-  static const bool apply_generic = getenv("FLK_APPLY_GENERIC") != nullptr;
-  if (ft == 2 && a->x_is_u8 && !a->delta_dense && a->W % 8 == 0 && a->T / 2 < 65536 && a->B < 65536 && !apply_generic) {
+  if (ft == 2 && a->x_is_u8 && !a->delta_dense && a->W % 8 == 0 && a->T / 2 < 65536 && a->B < 65536) {
     const dim3 g3((unsigned)(((a->H / 2) * (a->W / 8) + 255) / 256), (unsigned)(a->T / 2), (unsigned)a->B);
     if (bf && ftl == 2) FLK_LAUNCH_KERNEL((apply_s2d_u8_flicker_kernel<bf16_t, 2>), g3, dim3(256), 0, st, *a, (char*)out);
     else if (bf) FLK_LAUNCH_KERNEL((apply_s2d_u8_flicker_kernel<bf16_t, 3>), g3, dim3(256), 0, st, *a, (char*)out);

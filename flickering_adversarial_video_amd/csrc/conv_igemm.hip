@@ -29,252 +29,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "flk_internal.h"
-
-struct ConvKP {
-  const char* in; const char* in2; const char* w; char* out; char* out2;
-  const float* scale; const float* bias; const char* add; const char* mask;
-  const float* pos_bias; long pos_bias_bstride;
-  int in_ld, in_coff, cin;
-  int B, Ti, Hi, Wi;
-  int kt, kh, kw, st, sh, sw, pt, ph, pw;
-  int To, Ho, Wo;
-  int out_ld, out_coff, cout;
-  int OT, OH, OW, ost, osh, osw, oot, ooh, oow;
-  int add_ld, add_coff, mask_ld, mask_coff, relu;
-  int Tt, Ht, Wt, nTt, nTh, nTw, rows;
-  int Th, Hh, Wh, P, plane_b;
-  int FP;            // frame pitch of the halo image in 16-byte slots (>= Hh * Wh; slot of halo cell (a, b, c) = a * FP + b * Wh + c)
-  int tfast;         // tile rows enumerated w, then T, then h (1) instead of w, h, T (0): see pick_halo_layout
-  int nslab, ntaps, cout_frags;
-  int in2_ld, in2_coff, cin1, nslab1, out2_ld, out2_coff, cout1;
-  unsigned m_HW, m_Wh, m_hw, m_Wt;   // ceil(2^20 / d): exact x / d for x * d < 2^20 (x < 1024 here)
-  int ntile_n;
-  int xcd_chunk;     // > 0: position tiles are dealt to the XCDs in contiguous chunks of this many (see the kernel's index decode)
-  // deterministic split-K (blockIdx.y = slice of the input-channel slabs): raw fp32 partial sums [ksplit][positions][part_ld],
-  // summed in slice order and finished by conv_splitk_finish_kernel
-  float* part; int ksplit, part_ld; unsigned npos;
-  int wn;            // grouped launches (conv_igemm_group_kernel): waves along N of THIS member (1 / 2 / 4), a run-time value there
-};
-
-template <typename T> struct Prec;
-template <> struct Prec<bf16_t> {
-  static constexpr int EPL = 8;
-  typedef bf16x8 frag;
-  __device__ static inline void mma(const frag& a, const frag& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-  __device__ static inline void to_f32(const uint4& u, float* f) {
-    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f[2 * i] = __uint_as_float(w[i] << 16);
-      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
-    }
-  }
-  __device__ static inline uint4 from_f32(const float* f) {
-    bf16x8 v;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (bf16_t)f[i];
-    return __builtin_bit_cast(uint4, v);
-  }
-};
-template <> struct Prec<float> {
-  static constexpr int EPL = 4;
-  typedef f32x4 frag;
-  __device__ static inline void mma(const frag& a, const frag& b, f32x4& c) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
-  }
-  __device__ static inline void to_f32(const uint4& u, float* f) {
-    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
-    f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
-  }
-  __device__ static inline uint4 from_f32(const float* f) {
-    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
-  }
-};
-
-__device__ static inline int plane_off(int c, int plane_b) { return c * plane_b + (c >> 1) * 32; }
-__device__ static inline int fdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
-
-// tile row r -> cell (rt, rh, rw) of the Tt x Ht x Wt tile.  m_hw / m_Wt are the magic numbers of the enumeration in use
-// (tfast: rows run along w, then T, then h -- the 16 rows of an MFMA fragment then differ by the halo's frame pitch, which
-// pick_halo_layout pads to a conflict-free residue; otherwise along w, then h, then T)
-__device__ static inline void row_cell(const ConvKP& p, int r, int& rt, int& rh, int& rw) {
-  const int inner = (p.tfast ? p.Tt : p.Ht) * p.Wt;
-  const int o = fdiv(r, p.m_hw), rem = r - o * inner;
-  const int i = fdiv(rem, p.m_Wt);
-  rw = rem - i * p.Wt;
-  rt = p.tfast ? i : o;
-  rh = p.tfast ? o : i;
-}
-
-// position-class bias row of an output position (flk_conv_args.pos_bias), or nullptr
-// (pos_bias_bstride != 0: one table per clip b -- per-clip perturbations)
-__device__ static inline const float* pos_bias_row(const ConvKP& p, int b, int ot, int oh, int ow) {
-  if (!p.pos_bias) return nullptr;
-  const int hc = oh == 0 ? 0 : oh == p.Ho - 1 ? 3 : oh == p.Ho - 2 ? 2 : 1;
-  const int wc = ow == 0 ? 0 : ow == p.Wo - 1 ? 3 : ow == p.Wo - 2 ? 2 : 1;
-  return p.pos_bias + (size_t)b * p.pos_bias_bstride + (size_t)((ot * 4 + hc) * 4 + wc) * p.cout;
-}
-
-// acc * scale, rounded, + bias, rounded -- NEVER one fused multiply-add, in every epilogue variant (finish_store, finish_store_row,
-// finish_store_row_pre): left to fp-contract, whether hipcc fuses the two steps depends on the shape of the surrounding code, and the same
-// layer run through two kernels (128- against 64-channel tiles, a batch-1 against a batch-8 plan) would differ in the last bit.  (Two
-// roundings are also what the oracle's separate multiply and add do.)
-__device__ static inline float epi_scale_bias(float v, float sc, float bi, bool has_scale, bool has_bias) {
-#pragma clang fp contract(off)
-  float t = v;
-  if (has_scale) t = t * sc;
-  if (has_bias) t = t + bi;
-  return t;
-}
-
-// the epilogue of EPL consecutive output channels [c0, c0 + EPL) of physical output position opos: v = acc*scale + bias (+ position
-// bias) (+ add); relu; mask; 16-byte store into the first or second output segment
-template <typename T>
-__device__ static inline void finish_store(const ConvKP& p, size_t opos, const float* pb, int c0, float* v) {
-  typedef Prec<T> PR;
-  constexpr int EPL = PR::EPL;
-  const bool hs = p.scale != nullptr, hb = p.bias != nullptr;
-#pragma unroll
-  for (int e = 0; e < EPL; e += 4) {
-    const float4 sc = hs ? *(const float4*)(p.scale + c0 + e) : make_float4(1.f, 1.f, 1.f, 1.f);
-    const float4 bi = hb ? *(const float4*)(p.bias + c0 + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[e] = epi_scale_bias(v[e], sc.x, bi.x, hs, hb); v[e + 1] = epi_scale_bias(v[e + 1], sc.y, bi.y, hs, hb);
-    v[e + 2] = epi_scale_bias(v[e + 2], sc.z, bi.z, hs, hb); v[e + 3] = epi_scale_bias(v[e + 3], sc.w, bi.w, hs, hb);
-  }
-  if (pb) {
-#pragma unroll
-    for (int e = 0; e < EPL; e += 4) {
-      const float4 t4 = *(const float4*)(pb + c0 + e);
-      v[e] += t4.x; v[e + 1] += t4.y; v[e + 2] += t4.z; v[e + 3] += t4.w;
-    }
-  }
-  if (p.add) {
-    float a[EPL];
-    PR::to_f32(*(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + c0) * sizeof(T)), a);
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] += a[e];
-  }
-  if (p.relu) {
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
-  }
-  if (p.mask) {
-    float a[EPL];
-    PR::to_f32(*(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + c0) * sizeof(T)), a);
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f;
-  }
-  if (c0 < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c0) * sizeof(T)) = PR::from_f32(v);
-  else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c0 - p.cout1)) * sizeof(T)) = PR::from_f32(v);
-}
-
-// finish_store for the NG store groups (channels c0 + g * 4 * EPL) of ONE output position at once: every add / mask operand of the
-// position is requested before the first store.  Called group by group (finish_store), the loads of group g + 1 sit behind the
-// store of group g -- the compiler must assume they alias -- and each pays a full memory round trip.
-template <typename T, int NG>
-__device__ static inline void finish_store_row(const ConvKP& p, size_t opos, const float* pb, int c0, float (&v)[NG][Prec<T>::EPL]) {
-  typedef Prec<T> PR;
-  constexpr int EPL = PR::EPL;
-  uint4 av[NG], mv[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int c = c0 + g * 4 * EPL;
-    const bool in = c < p.cout;
-    if (p.add) av[g] = *(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + (in ? c : 0)) * sizeof(T));
-    if (p.mask) mv[g] = *(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + (in ? c : 0)) * sizeof(T));
-  }
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int c = c0 + g * 4 * EPL;
-    if (c >= p.cout) continue;
-    float* w = v[g];
-    const bool hs = p.scale != nullptr, hb = p.bias != nullptr;
-#pragma unroll
-    for (int e = 0; e < EPL; e += 4) {
-      const float4 sc = hs ? *(const float4*)(p.scale + c + e) : make_float4(1.f, 1.f, 1.f, 1.f);
-      const float4 bi = hb ? *(const float4*)(p.bias + c + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-      w[e] = epi_scale_bias(w[e], sc.x, bi.x, hs, hb); w[e + 1] = epi_scale_bias(w[e + 1], sc.y, bi.y, hs, hb);
-      w[e + 2] = epi_scale_bias(w[e + 2], sc.z, bi.z, hs, hb); w[e + 3] = epi_scale_bias(w[e + 3], sc.w, bi.w, hs, hb);
-    }
-    if (pb) {
-#pragma unroll
-      for (int e = 0; e < EPL; e += 4) {
-        const float4 t4 = *(const float4*)(pb + c + e);
-        w[e] += t4.x; w[e + 1] += t4.y; w[e + 2] += t4.z; w[e + 3] += t4.w;
-      }
-    }
-    if (p.add) {
-      float a[EPL];
-      PR::to_f32(av[g], a);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) w[e] += a[e];
-    }
-    if (p.relu) {
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) w[e] = fmaxf(w[e], 0.f);
-    }
-    if (p.mask) {
-      float a[EPL];
-      PR::to_f32(mv[g], a);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) w[e] = a[e] > 0.f ? w[e] : 0.f;
-    }
-    if (c < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c) * sizeof(T)) = PR::from_f32(w);
-    else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c - p.cout1)) * sizeof(T)) = PR::from_f32(w);
-  }
-}
-
-// finish_store_row with the batch-norm scale / bias of the lane's NG store groups already in registers (loaded once per lane: inside the
-// row loop hipcc re-requests them behind every store -- it must assume they alias the output -- and waits for each)
-template <typename T, int NG>
-__device__ static inline void finish_store_row_pre(const ConvKP& p, size_t opos, int c0, float (&v)[NG][Prec<T>::EPL],
-                                                   const float4 (&sc)[NG][2], const float4 (&bi)[NG][2]) {
-  typedef Prec<T> PR;
-  constexpr int EPL = PR::EPL;
-  static_assert(EPL == 8, "bf16 only");
-  uint4 av[NG], mv[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int c = c0 + g * 4 * EPL;
-    const bool in = c < p.cout;
-    if (p.add) av[g] = *(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + (in ? c : 0)) * sizeof(T));
-    if (p.mask) mv[g] = *(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + (in ? c : 0)) * sizeof(T));
-  }
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int c = c0 + g * 4 * EPL;
-    if (c >= p.cout) continue;
-    float* w = v[g];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int e = 4 * h;
-      const bool hs = p.scale != nullptr, hb = p.bias != nullptr;
-      w[e] = epi_scale_bias(w[e], sc[g][h].x, bi[g][h].x, hs, hb); w[e + 1] = epi_scale_bias(w[e + 1], sc[g][h].y, bi[g][h].y, hs, hb);
-      w[e + 2] = epi_scale_bias(w[e + 2], sc[g][h].z, bi[g][h].z, hs, hb); w[e + 3] = epi_scale_bias(w[e + 3], sc[g][h].w, bi[g][h].w, hs, hb);
-    }
-    if (p.add) {
-      float a[EPL];
-      PR::to_f32(av[g], a);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) w[e] += a[e];
-    }
-    if (p.relu) {
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) w[e] = fmaxf(w[e], 0.f);
-    }
-    if (p.mask) {
-      float a[EPL];
-      PR::to_f32(mv[g], a);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) w[e] = a[e] > 0.f ? w[e] : 0.f;
-    }
-    if (c < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c) * sizeof(T)) = PR::from_f32(w);
-    else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c - p.cout1)) * sizeof(T)) = PR::from_f32(w);
-  }
-}
+#include "conv_common.h"
 
 constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pairs staged per thread (16)
 
@@ -289,10 +44,13 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // convolutions in one grid): NF then counts the channel fragments of ONE WAVE, the waves-along-N count is the member's run-time p.wn
 // and the workgroup tile is 16 * NF * p.wn channels wide -- direct-A weights (MODE 1) only, where the tile width appears in two
 // address computations and nowhere in the loop structure.
-// timing experiments on the row-ahead ring loop (-DCONV_ABLATE=bits builds only; WRONG results): 1 no wait for the weights, 2 no barrier per
-// step, 4 no ring write, 8 no MFMAs, 16 no position-fragment reads, 32 no weight-fragment reads.  The product build compiles every CAB() to true.
-// (The substitutes for skipped reads are ZERO fragments: a substitute taken from a weight-queue register faulted -- DESIGN.md, round-4 fault.
-//  Put every variant build through tools/audit_asm_loads.py <this file> -DCONV_ABLATE=... before it goes to the GPU.)
+// timing experiments on the row-ahead ring loop (-DCONV_ABLATE=bits builds only; WRONG results): 1 no weight stream (neither the row-ahead
+// loads nor their waits: the ring is written from registers that hold zeros), 2 no barrier per step, 4 no ring write, 8 no MFMAs, 16 no
+// position-fragment reads, 32 no weight-fragment reads.  The product build compiles every CAB() to true.
+// (The substitutes for skipped reads are ZERO fragments, and bit 1 drops the LOADS with the waits: a substitute taken from a weight-queue
+//  register, and a ring write of a register whose load nothing had waited for, are what faulted in round 4 -- DESIGN.md.  Variants are built
+//  with tools/build_variant.py, which puts them through tools/audit_asm_loads.py with the same flags and refuses to link a flagged one;
+//  tests/test_asm_audit_cpu.py audits bits 16, 32, 48 and 63.)
 #ifdef CONV_ABLATE
 #define CAB(bit) (!((CONV_ABLATE) & (bit)))
 #else
@@ -528,8 +286,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     const unsigned wvoff = (unsigned)(wchunk * 16);
     const unsigned wvoff2 = wvoff + (unsigned)w2off;    // second chunk of a step (WCH = 2; NF = 6: threads without one re-read their first)
     const int last_step = nsteps - 1;
-    u32x4 q0, q1, q2, r0, r1, r2;                      // (r*: the second chunk of a step for channel tiles of more than 64, WCH = 2)
+    u32x4 q0 = {}, q1 = {}, q2 = {}, r0 = {}, r1 = {}, r2 = {};   // (r*: the second chunk of a step for channel tiles of more than 64, WCH = 2;
+                                                                  //  every one is defined by its first wload before any use: the zeros are dead code)
     auto wload = [&](u32x4& dst, u32x4& dst2, int k) {
+      if (!CAB(1)) return;
       const char* const ws = wtile + (size_t)(k < last_step ? k : last_step) * wstep;      // past the end: re-read the last step (never used)
       asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(wvoff), "s"(ws) : "memory");
       if constexpr (WCH == 2) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst2) : "v"(wvoff2), "s"(ws) : "memory");
@@ -547,7 +307,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     int it_w = 0;
     if constexpr (WA) {
       wload(q0, r0, 0);
-      if constexpr (WCH == 2) asm volatile("s_waitcnt vmcnt(0) ; release %0 %1" : "+v"(q0), "+v"(r0) :: "memory");
+      if (!CAB(1)) {}
+      else if constexpr (WCH == 2) asm volatile("s_waitcnt vmcnt(0) ; release %0 %1" : "+v"(q0), "+v"(r0) :: "memory");
       else asm volatile("s_waitcnt vmcnt(0) ; release %0" : "+v"(q0) :: "memory");
       *(u32x4*)(wbuf + wchunk * 16) = q0;
       if (WCH == 2 && w2ok) *(u32x4*)(wbuf + wchunk * 16 + 4096) = r0;
@@ -1021,13 +782,6 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvKP p)
 //     next issue overwrites; the last step waits for everything (nothing newer is in flight);
 //   * invalid channel chunks (cin % 32 != 0) fetch chunk 0 of the same position instead -- finite values against zero weights.
 // Epilogue: finish_store, as everywhere.
-__device__ static inline unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
-__device__ static inline void glds16(unsigned voff, const char* sbase, unsigned lds_base) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_base) : "memory");
-}
-
 template <int NF, int R>
 __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
   typedef Prec<bf16_t> PR;
@@ -1308,8 +1062,8 @@ __global__ __launch_bounds__(256, 1) void conv_t3_dma_kernel(const ConvKP p) {
 
 // ------------------------------------------------------------------------------------------------
 flk_tile flk_choose_tile(int To, int Ho, int Wo, int kt, int kh, int kw, int st, int sh, int sw, int max_rows, int max_halo) {
-  if (max_halo <= 0 || max_halo > FLK_MAX_HALO) max_halo = FLK_MAX_HALO;
-  if (max_rows <= 0 || max_rows > FLK_ROWS) max_rows = FLK_ROWS;
+  if (max_halo <= 0) max_halo = FLK_MAX_HALO;      // (conv_pc.hip asks for 512-row tiles; conv_igemm_kernel's callers for <= FLK_ROWS / FLK_MAX_HALO)
+  if (max_rows <= 0) max_rows = FLK_ROWS;
   flk_tile best{1, 1, 1};
   double best_eff = -1.0;
   long best_halo = 0;
@@ -1354,23 +1108,9 @@ static int launch(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s) {
 // fragments, the unpadded w-h-T form on ties, and never at the price of a resident workgroup.  Same products, same K order per output:
 // the results do not change.
 static void pick_halo_layout(ConvKP& kp, size_t ring_bytes, int max_resident) {
-  static const int on = getenv("FLK_CONV_HALO_PAD") ? atoi(getenv("FLK_CONV_HALO_PAD")) : 1;
-  if (!on || kp.P <= 256) return;              // (the two-image path of small halos keeps its 256-slot images)
+  if (kp.P <= 256) return;                     // (the two-image path of small halos keeps its 256-slot images)
   const int cells = kp.Hh * kp.Wh;
-  auto extra_passes = [&](int tfast, int FP) {
-    int total = 0;
-    for (int r0 = 0; r0 < kp.rows; r0 += 16) {
-      int cnt[16] = {}, mx = 0;
-      for (int r = r0; r < r0 + 16 && r < kp.rows; ++r) {
-        const int inner = (tfast ? kp.Tt : kp.Ht) * kp.Wt, o = r / inner, rem = r % inner, i = rem / kp.Wt, rw = rem % kp.Wt;
-        const int rt = tfast ? i : o, rh = tfast ? o : i;
-        const int c = ++cnt[(rt * kp.st * FP + rh * kp.sh * kp.Wh + rw * kp.sw) & 15];
-        mx = c > mx ? c : mx;
-      }
-      total += mx - 1;
-    }
-    return total;
-  };
+  auto extra_passes = [&](int tfast, int FP) { return conv_halo_extra_passes(kp, tfast, FP); };
   auto lds_of = [&](int P) { return 4 * ((size_t)(P * 16 + 255) / 256 * 256) + 64 + ring_bytes; };
   const size_t cap = 160 * 1024;
   const size_t res0 = std::min<size_t>(max_resident, cap / lds_of(kp.P));
@@ -1386,8 +1126,13 @@ static void pick_halo_layout(ConvKP& kp, size_t ring_bytes, int max_resident) {
 }
 
 constexpr int FLK_MAX_KSPLIT = 8;
+// FLK_CONV_PC=0: the large 3x3x3 layers stay on conv_igemm_kernel (A/B of the producer / consumer kernel, conv_pc.hip; read once)
+static bool pc_route_on() { static const bool on = !(getenv("FLK_CONV_PC") && atoi(getenv("FLK_CONV_PC")) == 0); return on; }
+
 static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, int dtype, int nf, int wn, int mode);
-static bool dbg_on() { static const bool d = getenv("FLK_CONV_DBG") != nullptr; return d; }
+static bool dbg_on() { static const bool d = getenv("FLK_CONV_DBG") != nullptr; return d; }      // print every launch's layout
+// FLK_CONV_KSPLIT=k: every split-K-eligible launch in k slices (tests: the split path on small shapes); 0 = the heuristic
+static int ksplit_forced() { static const int k = getenv("FLK_CONV_KSPLIT") ? atoi(getenv("FLK_CONV_KSPLIT")) : 0; return k; }
 
 static bool splitk_eligible(const flk_conv_args* a, const flk_conv_weights* w) {
   return !w->stem4 && w->nslab >= 2 && !a->pos_bias && a->ost == 1 && a->osh == 1 && a->osw == 1 && a->oot == 0 && a->ooh == 0 && a->oow == 0 &&
@@ -1408,9 +1153,7 @@ static int plan_ksplit(const flk_conv_args* a, const flk_conv_weights* w) {
   // clips' 48 workgroups), as do Mixed_5*'s forward Branch_1 at 65 and r2plus1d_18's layer3 / layer4 halves at bs 8.  Measured, three
   // rounds on one box (gpurun_out/sk_ab.log, sk_ab3.log): I3D T = 90 bs 8 7.75 -> 7.64 ms, r2plus1d_18 bs 8 4.33 -> 4.29, I3D T = 64 bs 8
   // 5.596 -> 5.584, the batch-1 plans unchanged (without the step bound they lose 0.01-0.02 ms to the extra finish kernels).
-  // FLK_SPLITK_MAXWG=64: the old rule.
-  static const long maxwg = getenv("FLK_SPLITK_MAXWG") ? atol(getenv("FLK_SPLITK_MAXWG")) : 128;
-  static const long minsteps = getenv("FLK_SPLITK_MINSTEPS") ? atol(getenv("FLK_SPLITK_MINSTEPS")) : 100;
+  constexpr long maxwg = 128, minsteps = 100;
   if (wgs > maxwg || (wgs > 64 && (long)w->nslab * w->ntaps < minsteps)) return 1;
   int ks = (int)(256 / wgs);
   if (ks < 2) ks = 2;
@@ -1420,8 +1163,7 @@ static int plan_ksplit(const flk_conv_args* a, const flk_conv_weights* w) {
 
 extern "C" int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_weights* w) {
   if (!a || !w || !splitk_eligible(a, w)) return 0;
-  static const char* force = getenv("FLK_CONV_KSPLIT");
-  const int ks = force ? FLK_MAX_KSPLIT : plan_ksplit(a, w);
+  const int ks = ksplit_forced() ? FLK_MAX_KSPLIT : plan_ksplit(a, w);
   return ks > 1 ? (int64_t)ks * a->B * a->OT * a->OH * a->OW * a->cout * (int64_t)sizeof(float) : 0;
 }
 
@@ -1479,8 +1221,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   // split-K decision first: a split launch keeps 256-row tiles (wn = 1) and gets its parallelism from the K slices
   int ksplit = 1;
   if (a->splitk_ws && splitk_eligible(a, w) && !plan) {
-    static const char* force = getenv("FLK_CONV_KSPLIT");
-    ksplit = force ? atoi(force) : force_ks > 0 ? force_ks : plan_ksplit(a, w);
+    ksplit = ksplit_forced() ? ksplit_forced() : force_ks > 0 ? force_ks : plan_ksplit(a, w);
     ksplit = ksplit > w->nslab ? w->nslab : ksplit > FLK_MAX_KSPLIT ? FLK_MAX_KSPLIT : ksplit < 1 ? 1 : ksplit;
   }
   // narrow channel tiles (nf = 2) are latency-bound: keep their halo <= 768 so that 3 workgroups fit a CU's LDS
@@ -1493,8 +1234,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, a->kh, a->kw, a->st, a->sh, a->sw, max_rows, max_halo);
   {
     const int wn_max = nf == 6 ? 1 : dtype == FLK_BF16 ? nf / 2 : nf;      // NFW >= 2 (bf16) / 1 (fp32); 96-channel tiles: ring kernels, wn = 1 only
-    static const char* force_env = getenv("FLK_CONV_WN");
-    const int force = force_wn > 0 ? force_wn : force_env ? atoi(force_env) : 0;
+    const int force = force_wn > 0 ? force_wn : 0;
     while (true) {
       const long wgs = (long)a->B * ((a->To + t.Tt - 1) / t.Tt) * ((a->Ho + t.Ht - 1) / t.Ht) * ((a->Wo + t.Wt - 1) / t.Wt) * ntile_n;
       // (threshold re-measured at the round-4 kernels: 64 / 128 / 256 / 384 / 512 workgroups -> 5.715 / 5.628 / 5.586 / 5.619 / 5.607 ms per step)
@@ -1536,9 +1276,8 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   kp.ntile_n = ntile_n;
   const long ptiles = (long)a->B * kp.nTt * kp.nTh * kp.nTw;
   // position tiles in contiguous chunks per XCD (halo-sharing neighbours in one L2): measured 6.82 -> 6.76 ms per step, conv kernels
-  // 6.32 -> 6.23 ms serial.  FLK_XCD_CHUNK=0: the interleaved order (tile i on XCD i % 8).  1x1x1 launches have no halo to share.
-  static const int xcd_chunked = getenv("FLK_XCD_CHUNK") ? atoi(getenv("FLK_XCD_CHUNK")) : 1;
-  kp.xcd_chunk = (xcd_chunked && kp.ntaps > 1) ? (int)((ptiles + 7) / 8) : 0;
+  // 6.32 -> 6.23 ms serial.  1x1x1 launches have no halo to share: the interleaved order (tile i on XCD i % 8).
+  kp.xcd_chunk = kp.ntaps > 1 ? (int)((ptiles + 7) / 8) : 0;
   const long gx = (ptiles + 7) / 8 * 8 * ntile_n;
   FLK_REQUIRE(gx < (1l << 31), "flk_conv3d: grid too large");
   // Deterministic split-K for launches that cannot fill the chip with output tiles (Mixed_5*: 3136 positions): the input-channel
@@ -1557,43 +1296,39 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   // on the per-step barrier: all WN >= 2 layouts.  Everything else shares the weights through the LDS ring (mode 0 / 5 / 6).
   // Until round 4 narrow channel tiles (nf <= 4) on grids of at most two workgroups per CU (<= 512) took direct-A as well; with the
   // row-ahead ring kernels and the conflict-free halo images the ring wins there too (bs 8, four interleaved rounds on one box, threshold 512 /
-  // 448 / 336 / 256 / 0 workgroups: 5.694 / 5.685 / 5.674 / 5.658 / 5.644 ms per step; the other configurations neutral to -0.5 %:
-  // gpurun_out/da_ab.log, da_ab2.log).  FLK_CONV_DA_MAXWG=512: the old rule.
+  // 448 / 336 / 256 / 0 workgroups: 5.694 / 5.685 / 5.674 / 5.658 / 5.644 ms per step; the other configurations neutral to -0.5 %).
   int mode = 0;
   {
-    static const bool no_k1 = getenv("FLK_CONV_NO_K1") != nullptr;
-    static const char* force = getenv("FLK_CONV_DA");      // "0": never for wn == 1, "1": whenever nf <= 4
-    static const long da_maxwg = getenv("FLK_CONV_DA_MAXWG") ? atol(getenv("FLK_CONV_DA_MAXWG")) : 0;
-    const bool narrow_small = nf <= 4 && (force ? atoi(force) != 0 : ptiles * ntile_n <= da_maxwg);      // (nf = 6 is never narrow)
     const bool k1 = kp.ntaps == 1 && kp.P <= 256;
     // direct A needs <= 4 fragments per wave (and >= 2 in bf16); the ring kernels are instantiated for wn == 1 only
     const int nfw = nf / wn;
     const bool da_ok = nf != 6 && nfw <= 4 && (dtype != FLK_BF16 || nfw >= 2), ring_ok = wn == 1;
-    bool da = wn >= 2 || narrow_small;
+    bool da = wn >= 2;
     if (force_da == 0 && ring_ok) da = false;
     if (force_da == 1 && da_ok) da = true;
     if (w->stem4) mode = 4;
     else if (da) mode = k1 ? 2 : 1;
-    else if (k1 && kp.nslab >= 4 && !no_k1) mode = 3;   // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
+    else if (k1 && kp.nslab >= 4) mode = 3;             // (2-3 slabs: the clamped tail loads would outweigh the prefetch)
   }
   // (3,1,1) convolutions, stride 1, pad 1 (the temporal half of a (2+1)D unit) whose frames split into 16-position chunks: the LDS-DMA
-  // ring over whole-T tiles (conv_t3_dma_kernel).  FLK_CONV_T3DMA=0: the halo kernels; =R: ring slots.  Measured (r2plus1d_18, bs 8, same
-  // box): halo kernels 4.72 ms per step; R = 2 (60 KB of LDS at nf 4: two workgroups per CU) 4.42; R = 3 / 4 (one per CU, two / three
-  // slabs in flight) 4.82 / 4.89 -- once more the second resident workgroup is worth more than the deeper pipeline
+  // ring over whole-T tiles (conv_t3_dma_kernel).  Measured (r2plus1d_18, bs 8, same box): halo kernels 4.72 ms per step; R = 2 ring slots
+  // (60 KB of LDS at nf 4: two workgroups per CU) 4.42; R = 3 / 4 (one per CU, two / three slabs in flight) 4.82 / 4.89 -- once more the
+  // second resident workgroup is worth more than the deeper pipeline
   {
-    static const int t3_on = getenv("FLK_CONV_T3DMA") ? atoi(getenv("FLK_CONV_T3DMA")) : 2;
     const bool flat3 = a->kt == 3 && a->kh == 1 && a->kw == 1 && a->st == 1 && a->sh == 1 && a->sw == 1 && a->pt == 1 && a->ph == 0 && a->pw == 0 &&
                        a->ost == 1 && a->osh == 1 && a->osw == 1 && a->oot == 0 && a->ooh == 0 && a->oow == 0 && a->To == a->Ti && a->Ho == a->Hi &&
                        a->Wo == a->Wi && a->OT == a->To && a->OH == a->Ho && a->OW == a->Wo;
     const long npos = (long)a->B * a->To * a->Ho * a->Wo;
     const int Tn = a->Ti, hw = a->Hi * a->Wi;
-    if (!plan && t3_on && dtype == FLK_BF16 && flat3 && !a->in2 && !a->out2 && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
+    // (the kernel builds its global byte offsets in 32 bits: position * in_ld * 2 + channel offset must stay below 2^32)
+    const bool off32 = ((unsigned long long)npos * (unsigned)a->in_ld + (unsigned)a->in_coff + 32ull) * 2ull < (1ull << 32);
+    if (!plan && off32 && dtype == FLK_BF16 && flat3 && !a->in2 && !a->out2 && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
         (nf == 8 || nf == 4) && npos >= 2048 && npos < (1l << 23) && (Tn == 2 || Tn == 4 || Tn == 8 || Tn == 16) && hw % 16 == 0) {
       const int Gn = 16 / Tn;
       const long pt = (long)a->B * ((hw / 16 + Gn - 1) / Gn);
       dim3 g((unsigned)((pt + 7) / 8 * 8 * ntile_n));
-      static bool attr_t3[6][FLK_MAX_DEVICES] = {};
-      const int Rr = t3_on == 3 ? 3 : t3_on == 4 ? 4 : 2;
+      static bool attr_t3[2][FLK_MAX_DEVICES] = {};
+      constexpr int Rr = 2;
       const size_t l5 = (size_t)Rr * ((16 + 2 * Gn) * 1024 + 3 * nf * 1024);
       if (dbg_on()) fprintf(stderr, "conv 3x1x1 cin %d cout %d positions %ld | nf %d LDS-DMA ring over whole-T tiles, R %d, lds %zu, wgs %ld\n", a->cin, a->cout, npos, nf, Rr, l5, pt * ntile_n);
 #define FLK_LAUNCH_T3(NFv, Rv, idx)                                                                                                \
@@ -1604,19 +1339,21 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
         FLK_CHECK_HIP(hipGetLastError());                                                                                           \
         return FLK_OK;                                                                                                              \
       }
-      FLK_LAUNCH_T3(4, 2, 0) FLK_LAUNCH_T3(4, 3, 1) FLK_LAUNCH_T3(4, 4, 2) FLK_LAUNCH_T3(8, 2, 3) FLK_LAUNCH_T3(8, 3, 4)
+      FLK_LAUNCH_T3(4, 2, 0) FLK_LAUNCH_T3(8, 2, 1)
 #undef FLK_LAUNCH_T3
     }
   }
-  // 1x1x1 GEMMs over a flat position grid: both operands through the LDS-DMA ring (conv1x1_dma_kernel).  FLK_CONV_DMA=0: modes 2 / 3.
+  // 1x1x1 GEMMs over a flat position grid: both operands through the LDS-DMA ring (conv1x1_dma_kernel); what it cannot take goes to modes 2 / 3.
   {
-    static const int dma_on = getenv("FLK_CONV_DMA") ? atoi(getenv("FLK_CONV_DMA")) : 1;
     const bool flat = a->st == 1 && a->sh == 1 && a->sw == 1 && a->pt == 0 && a->ph == 0 && a->pw == 0 && a->ost == 1 && a->osh == 1 && a->osw == 1 &&
                       a->oot == 0 && a->ooh == 0 && a->oow == 0 && a->To == a->Ti && a->Ho == a->Hi && a->Wo == a->Wi && a->OT == a->To &&
                       a->OH == a->Ho && a->OW == a->Wo;
     const long npos = (long)a->B * a->To * a->Ho * a->Wo;
-    if (!plan && dma_on && dtype == FLK_BF16 && kp.ntaps == 1 && flat && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
-        (nf == 8 || nf == 6 || nf == 4) && kp.nslab >= 2 && npos >= (dma_on >= 2 ? 1 : 2048) && npos < (1l << 23)) {
+    // (32-bit global byte offsets in the kernel, over both input segments)
+    const unsigned ld_max = (unsigned)(a->in2 && a->in2_ld > a->in_ld ? a->in2_ld : a->in_ld), co_max = (unsigned)(a->in2 && a->in2_coff > a->in_coff ? a->in2_coff : a->in_coff);
+    const bool off32 = ((unsigned long long)npos * ld_max + co_max + 32ull) * 2ull < (1ull << 32);
+    if (!plan && off32 && dtype == FLK_BF16 && kp.ntaps == 1 && flat && !a->pos_bias && kp.ksplit == 1 && force_wn == 0 && force_da < 0 &&
+        (nf == 8 || nf == 6 || nf == 4) && kp.nslab >= 2 && npos >= 2048 && npos < (1l << 23)) {
       kp.npos = (unsigned)npos;
       const long pt = (npos + 255) / 256;
       dim3 g((unsigned)((pt + 7) / 8 * 8 * ntile_n));
@@ -1643,11 +1380,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   // step 5.82-5.89 -> 5.78 ms.  128- and 96-channel tiles carry two 16-byte pieces per thread and step (six registers quads in flight,
   // 248 / 208 VGPRs, two workgroups per CU as in mode 0): Mixed_3b Branch_1 96 -> 128 0.1498-0.1536 -> 0.1464-0.1485 ms, its data-gradient on
   // 96-channel tiles 0.158 -> 0.160 (alone: slower), the step 5.75 -> 5.70 (128 only) -> 5.68 ms (both; four A/B pairs each, same box).
-  // FLK_CONV_ROWAHEAD=0: mode 0
-  {
-    static const int rowahead = getenv("FLK_CONV_ROWAHEAD") ? atoi(getenv("FLK_CONV_ROWAHEAD")) : 1;
-    if (rowahead && mode == 0 && dtype == FLK_BF16 && a->kw == 3 && kp.P > 256 && (nf == 8 || nf == 6 || nf == 4 || nf == 2)) mode = 5;
-  }
+  if (mode == 0 && dtype == FLK_BF16 && a->kw == 3 && kp.P > 256 && (nf == 8 || nf == 6 || nf == 4 || nf == 2)) mode = 5;
   // two halo images for small halos; the LDS weight ring only in mode 0 / 3 / 4 / 5
   const size_t ring_bytes = (mode == 0 || mode == 3 || mode == 4 || mode == 5) ? 2 * (size_t)nf * 1024 : 0;
   if (!w->stem4) {
@@ -1658,7 +1391,7 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   }
   const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ring_bytes;
   {
-    static const bool dbg = getenv("FLK_CONV_DBG") != nullptr;
+    const bool dbg = dbg_on();
     if (dbg)
       fprintf(stderr, "conv %dx%dx%d s%d%d%d cin %d cout %d out %dx%dx%dx%d | nf %d wn %d tile %dx%dx%d rows %d halo %d (frame pitch %d + %d, rows %s) wgs %ld mode %d lds %zu\n",
               a->kt, a->kh, a->kw, a->st, a->sh, a->sw, a->cin, a->cout, a->B, a->To, a->Ho, a->Wo, nf, wn, kp.Tt, kp.Ht, kp.Wt,
@@ -1696,16 +1429,9 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
     if (mode == 4 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 4>(kp, grid, lds, s);
     // ring write behind the barrier (mode 6): measured on <= 64-channel tiles only (Conv3d_2c 0.2525 / 0.2467 -> 0.2478 / 0.2402 ms forward /
     // data-gradient, Mixed_3c Branch_1 0.2348 -> 0.2308, 160 -> 320 at 25 088 positions 0.0955 -> 0.0922, the (1,3,3) 64 -> 144 layer 0.1398 ->
-    // 0.1315; 128- and 96-channel tiles the same: FLK_CONV_WRITEAHEAD=2 takes them too, 0 none)
-    static const int write_ahead = getenv("FLK_CONV_WRITEAHEAD") ? atoi(getenv("FLK_CONV_WRITEAHEAD")) : 1;
-    if (mode == 5 && write_ahead) {
-      if (wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 6>(kp, grid, lds, s);
-      if (wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 6>(kp, grid, lds, s);
-      if (wn == 1 && nf == 8 && write_ahead >= 2) return launch<bf16_t, 8, 1, 6>(kp, grid, lds, s);
-      if (wn == 1 && nf == 6 && write_ahead >= 2) return launch<bf16_t, 6, 1, 6>(kp, grid, lds, s);
-    }
-    if (mode == 5 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 5>(kp, grid, lds, s);
-    if (mode == 5 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 5>(kp, grid, lds, s);
+    // 0.1315; 128- and 96-channel tiles the same: they stay mode 5)
+    if (mode == 5 && wn == 1 && nf == 2) return launch<bf16_t, 2, 1, 6>(kp, grid, lds, s);
+    if (mode == 5 && wn == 1 && nf == 4) return launch<bf16_t, 4, 1, 6>(kp, grid, lds, s);
     if (mode == 5 && wn == 1 && nf == 8) return launch<bf16_t, 8, 1, 5>(kp, grid, lds, s);
     if (mode == 5 && wn == 1 && nf == 6) return launch<bf16_t, 6, 1, 5>(kp, grid, lds, s);
     FLK_LAUNCH0(bf16_t, 2, 1); FLK_LAUNCH0(bf16_t, 4, 1); FLK_LAUNCH0(bf16_t, 8, 1); FLK_LAUNCH0(bf16_t, 6, 1);
@@ -1726,13 +1452,15 @@ static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, in
 // Grouped launch: n <= 3 convolutions (bf16, more than one tap, no split-K) in one grid of conv_igemm_group_kernel<NFW>.  Every member
 // is planned as a launch of its own would be, with direct-A weights and wn = (its weights' nf) / nfw waves along N, so member i's blocks
 // compute exactly what flk_conv3d would have with that layout.  Members in the order given: put the longest K loops first.
-extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype, void* stream) {
+// plan of a grouped launch: member table, LDS size, grid, body mode (1 direct-A, 0 / 5 / 6 ring forms)
+static int group_plan(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype, ConvGroupKP& g, size_t& lds,
+                      long& total, int& gmode) {
   FLK_REQUIRE(a && w && n >= 1 && n <= FLK_MAX_GROUP, "flk_conv3d_group: 1..%d members", FLK_MAX_GROUP);
   FLK_REQUIRE(dtype == FLK_BF16 && (ring ? (nfw == 4 || nfw == 8) : (nfw == 2 || nfw == 4)),
               "flk_conv3d_group: bf16; 2 or 4 channel fragments per wave (direct-A members) or channel tiles of 4 or 8 fragments (ring members)");
-  ConvGroupKP g{};
-  size_t lds = 0;
-  long total = 0;
+  g = ConvGroupKP{};
+  lds = 0;
+  total = 0;
   bool all5 = ring != 0;
   for (int i = 0; i <= FLK_MAX_GROUP; ++i) g.start[i] = 0x7fffffff;
   for (int i = 0; i < n; ++i) {
@@ -1742,7 +1470,7 @@ extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_we
                      "flk_conv3d_group: member %d packed with nf %d, not 1 / 2 / 4 waves of %d fragments", i, w[i]->nf, nfw);
     FLK_REQUIRE(w[i]->ntaps > 1 && !w[i]->stem4 && !a[i]->pos_bias, "flk_conv3d_group: member %d is not a multi-tap convolution", i);
     ConvPlan pl{};
-    if (int rc = conv3d_impl(a[i], w[i], dtype, stream, ring ? 1 : w[i]->nf / nfw, ring ? 0 : 1, 0, &pl)) return rc;
+    if (int rc = conv3d_impl(a[i], w[i], dtype, nullptr, ring ? 1 : w[i]->nf / nfw, ring ? 0 : 1, 0, &pl)) return rc;
     // (ring members: a member planned for mode 5 -- the ring with the weights a row ahead -- has mode 0's arguments and LDS layout; the group
     //  runs the mode-5 body when every member was planned so, the mode-0 body otherwise)
     all5 = all5 && pl.mode == 5;
@@ -1758,11 +1486,25 @@ extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_we
               pl.kp.Ht, pl.kp.Wt, pl.kp.rows, pl.kp.P, pl.grid.x, pl.lds);
   }
   FLK_REQUIRE(total < (1l << 31), "flk_conv3d_group: grid too large");
+  gmode = ring ? (all5 ? (nfw == 4 ? 6 : 5) : 0) : 1;      // (ring write behind the barrier: the 64-channel tiles)
+  return FLK_OK;
+}
+
+// validation + planning of flk_conv3d_group without a launch: a plan builder calls it once per group it emits, so that a layout the group
+// kernel cannot run fails when the plan is BUILT, not as FLK_EINVAL on every step
+extern "C" int flk_conv3d_group_check(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype) {
+  ConvGroupKP g; size_t lds; long total; int gmode;
+  return group_plan(a, w, n, nfw, ring, dtype, g, lds, total, gmode);
+}
+
+extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype, void* stream) {
+  // ring groups of 64-channel tiles on large grids (Branch_1 + Branch_2 of Mixed_3b / 3c at the benchmark batch): the persistent producer / consumer
+  // kernel takes all members in one launch -- bitwise the same outputs
+  if (pc_route_on() && ring && nfw == 4 && dtype == FLK_BF16 && a && w && n >= 1 && flk_conv3d_pc_worthwhile(a, w, n, dtype)) return flk_conv3d_pc(a, w, n, dtype, stream);
+  ConvGroupKP g; size_t lds; long total; int gmode;
+  if (int rc = group_plan(a, w, n, nfw, ring, dtype, g, lds, total, gmode)) return rc;
   hipStream_t s = (hipStream_t)stream;
   static bool attr[7][FLK_MAX_DEVICES] = {};
-  static const bool group5 = !getenv("FLK_CONV_ROWAHEAD") || atoi(getenv("FLK_CONV_ROWAHEAD")) >= 2;    // 1: mode 5 in single launches only
-  static const bool group6 = !getenv("FLK_CONV_WRITEAHEAD") || atoi(getenv("FLK_CONV_WRITEAHEAD")) != 0;   // ring write behind the barrier (64-channel tiles)
-  const int gmode = ring ? (all5 && group5 ? (group6 && nfw == 4 ? 6 : 5) : 0) : 1;
 #define FLK_LAUNCH_GROUP(NFWv, MODEv, idx)                                                                                           \
   if (nfw == NFWv && gmode == MODEv) {                                                                                                \
     if (int rc = flk_raise_lds_limit((const void*)conv_igemm_group_kernel<bf16_t, NFWv, MODEv>, 96 * 1024, attr[idx])) return rc;    \
@@ -1802,6 +1544,9 @@ extern "C" int flk_conv_set_autotune(int on) { g_tuning = on != 0; return FLK_OK
 
 extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream) {
   if (!a || !w) return conv3d_impl(a, w, dtype, stream, 0, -1);
+  // the large 3x3x3 stride-1 layers (Conv3d_2c_3x3 at the benchmark batch): the persistent producer / consumer kernel -- bitwise the same outputs
+  if (pc_route_on() && !g_tuning && dtype == FLK_BF16 && w->ntaps == 27 && w->nf == 4 && !a->splitk_ws && flk_conv3d_pc_worthwhile(&a, &w, 1, dtype))
+    return flk_conv3d_pc(&a, &w, 1, dtype, stream);
   for (const flk_conv_weights::Tuned& tn : w->tuned)
     if (tn.B == a->B && tn.To == a->To && tn.Ho == a->Ho && tn.Wo == a->Wo) return conv3d_impl(a, w, dtype, stream, tn.wn, tn.da);
   if (!g_tuning || w->stem4) return conv3d_impl(a, w, dtype, stream, 0, -1);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -53,6 +54,10 @@ extern thread_local unsigned flk_launch_count;      // kernel launches of this t
 extern thread_local const char* flk_last_kernel_tag;
 
 static inline int flk_esize(int dtype) { return dtype == FLK_BF16 ? 2 : 4; }
+
+// experiment knobs of the timing-only builds (-DFLK_ABLATE / -DSF_ABLATE: kernels with phases switched off, WRONG results; the shipped
+// library contains none of them -- tests/test_abi.py): read here and nowhere else
+static inline int flk_ablate_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel and one process may drive several GPUs:
 // `done` is the call site's `static bool done[FLK_MAX_DEVICES]`, indexed by the current device (set once per device, always

@@ -237,7 +237,7 @@ struct flk_net {
   // pack forward + data-gradient operators and upload the epilogue vectors
   // 96-channel tiles are candidates for launches of `rows` output positions that keep 256-row workgroups (>= 256 position tiles), bf16
   bool nf6_ok(long rows) const {
-    return dtype == FLK_BF16 && rows >= 256L * 256 && !(getenv("FLK_NF6") && atoi(getenv("FLK_NF6")) == 0);
+    return dtype == FLK_BF16 && rows >= 256L * 256;
   }
   // (bf16 1x1x1 layers: at least 64-channel tiles, so that a 32-channel Branch_3 convolution goes through the LDS-DMA ring kernel too --
   // it is memory-bound, the padded MFMAs are free: 25 -> 22 us for 192 -> 32 at 200 704 positions)
@@ -245,17 +245,15 @@ struct flk_net {
     const int nf = choose_nf(cout, taps, nf6_ok(rows));
     // 1x1x1 GEMMs on 8 .. 255 position tiles (Mixed_4* / Mixed_5* at bs 8): 64-channel tiles, twice the workgroups of the 128-wide
     // choice -- these launches are paced by the step chain of ONE workgroup per CU (DMA issue -> LDS reads -> MFMAs, one wave per
-    // SIMD), not by bytes: same total time alone, the step -0.035 ms (they overlap their neighbours better).  FLK_SMALL_NF=0: off
-    if (dtype == FLK_BF16 && taps == 1 && small_nf() && rows >= 2048 && rows < 256L * 256 && cout > 64) return small_nf();
+    // SIMD), not by bytes: same total time alone, the step -0.035 ms (they overlap their neighbours better)
+    if (dtype == FLK_BF16 && taps == 1 && rows >= 2048 && rows < 256L * 256 && cout > 64) return 4;
     // (the same for the 3x3x3 layers of those blocks: 6.122-6.124 vs 6.132-6.135 ms, within the noise; 96-wide: 6.32 ms -- not done)
     // multi-tap layers on >= 256 position tiles (Mixed_3*): 64- instead of 128-channel tiles -- since the ring write moved behind the
     // barrier on 64-channel tiles (conv_igemm.hip, mode 6) they are the faster kernels at equal padding (tools/nf_sweep.py, round 4:
-    // 96 -> 128 at 8x32x28x28 0.134 vs 0.148 ms, 192 -> 128 0.245 vs 0.263).  FLK_BIG_NF4=0: off
-    static const bool big_nf4 = !(getenv("FLK_BIG_NF4") && atoi(getenv("FLK_BIG_NF4")) == 0);
-    if (dtype == FLK_BF16 && taps > 1 && nf == 8 && rows >= 256L * 256 && big_nf4) return 4;
+    // 96 -> 128 at 8x32x28x28 0.134 vs 0.148 ms, 192 -> 128 0.245 vs 0.263)
+    if (dtype == FLK_BF16 && taps > 1 && nf == 8 && rows >= 256L * 256) return 4;
     return (dtype == FLK_BF16 && taps == 1 && nf == 2) ? 4 : nf;
   }
-  static int small_nf() { static const int v = getenv("FLK_SMALL_NF") ? atoi(getenv("FLK_SMALL_NF")) : 4; return v == 4 || v == 8 ? (v == 8 ? 0 : 4) : 0; }
   // (nf_f / nf_b > 0: the channel-tile width of the forward / data-gradient operator is given -- members of a grouped launch)
   int pack(ConvLayer* L, long rows = 0, int nf_f = 0, int nf_b = 0) {
     const int taps = L->kt * L->kh * L->kw;
@@ -371,12 +369,11 @@ struct flk_net {
   // direct-A weights (nf1 channels x wn1 waves); that fixes the fragments per wave nfw = nf1 / wn1 every member shares.  The small member
   // (cout2 <= 128) takes the narrowest tile of wn2 in {1, 2, 4} waves x nfw fragments that holds its channels -- with the large member
   // filling the chip it no longer has to manufacture workgroups out of 64-row tiles.  nfw = 0: no group (fp32, a geometry the group
-  // kernel has no instance for, FLK_GROUP=0).
+  // kernel has no instance for).
   struct GroupLayout { int nfw = 0, nf1 = 0, nf2 = 0, ring = 0; };
   GroupLayout plan_group(const Act& geom, int cin1, int cout1, int cout2) const {
     GroupLayout g;
-    static const int on = getenv("FLK_GROUP") ? atoi(getenv("FLK_GROUP")) : 3;
-    if (!on || dtype != FLK_BF16) return g;
+    if (dtype != FLK_BF16) return g;
     flk_conv_args a{};
     a.B = B; a.Ti = a.To = a.OT = geom.T; a.Hi = a.Ho = a.OH = geom.H; a.Wi = a.Wo = a.OW = geom.W;
     a.kt = a.kh = a.kw = 3; a.st = a.sh = a.sw = 1; a.pt = a.ph = a.pw = 1; a.ost = a.osh = a.osw = 1;
@@ -387,22 +384,18 @@ struct flk_net {
     int wn1 = 1, mode = 0;
     // a large member the heuristics give the LDS weight ring (Mixed_4e / 4f forward: 560 workgroups) keeps the ring: as a direct-A member
     // of a group it ran 0.120 / 0.122 ms against 0.092 + 0.019 / 0.091 + 0.022 ms for the two launches
-    // (FLK_GROUP_RING: 0 = such a block is not grouped: 5.889 ms; 1 = as direct-A members: 5.856 -> slower than 0 on the same box; 2 (default) = as a
-    //  RING group, both members on the ring's 256-row tiles with Branch_1's channel tile: 5.871; with Mixed_3* grouped that way too: 5.876)
-    static const int ring_too = getenv("FLK_GROUP_RING") ? atoi(getenv("FLK_GROUP_RING")) : 2;
-    if (ring_too != 1 && (flk_conv_layout_query(&a, nf1, dtype, -1, &wn1, &mode) != FLK_OK || mode != 1)) {
-      if (ring_too == 2 && (mode == 0 || mode == 5) && wn1 == 1 && (nf1 == 4 || nf1 == 8)) { g.nfw = nf1; g.nf1 = nf1; g.nf2 = nf1; g.ring = 1; }
+    // (such a block not grouped: 5.889 ms per step; as direct-A members: slower on the same box; as a RING group, both members on the ring's
+    //  256-row tiles with Branch_1's channel tile -- what happens here: 5.871)
+    if (flk_conv_layout_query(&a, nf1, dtype, -1, &wn1, &mode) != FLK_OK || mode != 1) {
+      if ((mode == 0 || mode == 5) && wn1 == 1 && (nf1 == 4 || nf1 == 8)) { g.nfw = nf1; g.nf1 = nf1; g.nf2 = nf1; g.ring = 1; }
       return g;
     }
     if (flk_conv_layout_query(&a, nf1, dtype, 1, &wn1, &mode) != FLK_OK || mode != 1) return g;
-    int nfw = nf1 / wn1;
-    if (nfw == 8) nfw = 4;                              // (nf 8 on 256-row tiles: two waves along the channels instead)
     // measured (bs 8, same box, interleaved runs): no groups 5.94-5.96 ms per step; Mixed_4* grouped with the heuristic's fragments per
-    // wave 5.89-5.92; with four fragments per wave everywhere (the data-gradients of Mixed_4b-d on 128- instead of 64-row tiles) 5.88;
-    // Mixed_5* grouped as well 5.98-6.04 (their split-K launches are faster than any one-slice layout); Mixed_3* too 5.97
-    static const int force_nfw = getenv("FLK_GROUP_NFW") ? atoi(getenv("FLK_GROUP_NFW")) : 4;
-    if (force_nfw == 2 || force_nfw == 4) { if (nf1 < force_nfw) nf1 = force_nfw; nfw = force_nfw; }
-    if (nfw != 2 && nfw != 4) return g;
+    // wave 5.89-5.92; with FOUR fragments per wave everywhere (the data-gradients of Mixed_4b-d on 128- instead of 64-row tiles) 5.88;
+    // Mixed_5* grouped as well 5.98-6.04 (their split-K launches are faster than any one-slice layout)
+    constexpr int nfw = 4;
+    if (nf1 < nfw) nf1 = nfw;
     if (nf1 / nfw > 4) nf1 = 4 * nfw;
     int wn2 = 1;
     while (wn2 < 4 && 16 * nfw * wn2 < cout2) wn2 *= 2;
@@ -440,6 +433,19 @@ struct flk_net {
                   const flk_conv_weights* w2, int nfw, int ring = 0) {
     auto macs = [](const flk_conv_args& a) { return (double)a.B * a.To * a.Ho * a.Wo * a.kt * a.kh * a.kw * a.cin * a.cout; };
     const int dt = dtype;
+    {
+      // plan_group decided layout and packing through flk_conv_layout_query; flk_conv3d_group re-plans every member at launch.  Checked
+      // once, here: a disagreement fails (falls back) when the plan is built, not as FLK_EINVAL on every step.  The fallback -- the two
+      // members as launches of their own, in line -- computes the same values from the weights as packed.
+      const flk_conv_args* av[2] = {&a1, &a2};
+      const flk_conv_weights* wv[2] = {w1, w2};
+      if (flk_conv3d_group_check(av, wv, 2, nfw, ring, dt) != FLK_OK) {
+        fprintf(stderr, "[flicker_hip] %s: grouped launch refused (%s); running its members as two launches\n", name.c_str(), flk_last_error());
+        ops.push_back(Op{name + "/member0", K_CONV, 2.0 * macs(a1), conv_bytes(a1), [a1, w1, dt](hipStream_t s) { return flk_conv3d(&a1, w1, dt, s); }});
+        ops.push_back(Op{name + "/member1", K_CONV, 2.0 * macs(a2), conv_bytes(a2), [a2, w2, dt](hipStream_t s) { return flk_conv3d(&a2, w2, dt, s); }});
+        return;
+      }
+    }
     ops.push_back(Op{name, K_CONV, 2.0 * (macs(a1) + macs(a2)), conv_bytes(a1) + conv_bytes(a2), [a1, w1, a2, w2, nfw, ring, dt](hipStream_t s) {
                        const flk_conv_args* av[2] = {&a1, &a2};
                        const flk_conv_weights* wv[2] = {w1, w2};
@@ -518,8 +524,8 @@ int flk_net::build_i3d() {
   Act p2a, Gp2a, a2b, G2b, a2c, G2c, p3a, Gp3a;
   // The segment up to Mixed_3b alternates MFMA-bound convolutions (Conv3d_1a, Conv3d_2c) with HBM-bound pools and a 1x1x1, one
   // kernel at a time.  With an even batch >= 4 it is emitted once per HALF of the batch, the halves on two streams: the pools of one
-  // half run beside the convolutions of the other.  FLK_STEM_SPLIT=0: one pass over the whole batch (round-1 order).
-  const bool split = B >= 4 && B % 2 == 0 && !(getenv("FLK_STEM_SPLIT") && atoi(getenv("FLK_STEM_SPLIT")) == 0);
+  // half run beside the convolutions of the other.
+  const bool split = B >= 4 && B % 2 == 0;
   const int nhalf = split ? 2 : 1;
   PoolRec r2a[2], r3a[2];
   const double stem_macs = (double)(B / nhalf) * T1 * H1 * W1 * 343.0 * 3 * 64;   // algorithmic (7x7x7x3), not the padded 4x4x4x32
@@ -658,17 +664,14 @@ int flk_net::build_i3d() {
     const long rows_blk = (long)B * cur.T * cur.H * cur.W;
     // Branch_1 + Branch_2 3x3x3 units as ONE launch per pass (Mixed_4* / Mixed_5* at the benchmark batch: launches of < 256 x 256 positions,
     // where Branch_2 alone runs at 40-250 TFLOP/s on a 27-step K loop): group layouts of the forward pass and of the data-gradients.
-    // FLK_GROUP_ROWS: largest position count that is grouped.  Until the row-ahead ring kernels (conv_igemm.hip modes 5 / 6) the Mixed_3*
-    // blocks (>= 256 x 256 positions at bs 8) were faster as two launches on two streams (65535: that rule); as RING groups they save a
-    // fork / join pair per block and pass and Branch_2's 27-step workgroups fill Branch_1's tail: 5.547 -> 5.502 ms per step (four
-    // interleaved pairs, gpurun_out/grows_ab.log)
-    static const long group_rows = getenv("FLK_GROUP_ROWS") ? atol(getenv("FLK_GROUP_ROWS")) : (1L << 40);
+    // Until the row-ahead ring kernels (conv_igemm.hip modes 5 / 6) the Mixed_3* blocks (>= 256 x 256 positions at bs 8) were faster as two
+    // launches on two streams; as RING groups they save a fork / join pair per block and pass and Branch_2's 27-step workgroups fill
+    // Branch_1's tail: 5.547 -> 5.502 ms per step.
     GroupLayout gf, gb;
-    static const long group_min_rows = getenv("FLK_GROUP_MIN_ROWS") ? atol(getenv("FLK_GROUP_MIN_ROWS")) : 8192;      // (below: Mixed_5*, 3136 positions at T = 64 and 4704 at T = 90 -- split-K launches)
-    static const int group_dirs = getenv("FLK_GROUP") ? atoi(getenv("FLK_GROUP")) : 3;      // bit 0: forward, bit 1: data-gradients
-    if (rows_blk <= group_rows && rows_blk >= group_min_rows) {
-      if (group_dirs & 1) gf = plan_group(cur, c1a, c1b, bk.c[4]);
-      if (group_dirs & 2) gb = plan_group(cur, c1b, c1a, bk.c[3]);
+    constexpr long group_min_rows = 8192;      // (below: Mixed_5*, 3136 positions at T = 64 and 4704 at T = 90 -- split-K launches)
+    if (rows_blk >= group_min_rows) {
+      gf = plan_group(cur, c1a, c1b, bk.c[4]);
+      gb = plan_group(cur, c1b, c1a, bk.c[3]);
     }
     if ((rc = make_unit3d(bn + "/Branch_1/Conv3d_0b_3x3", 3, 3, 3, c1a, c1b, &L1b)) || (rc = pack(L1b, rows_blk, gf.nf1, gb.nf1))) return rc;
     if ((rc = make_unit3d(bn + "/Branch_2/Conv3d_0a_1x1", 1, 1, 1, cur_c, c2a, &L2a))) return rc;
@@ -723,22 +726,18 @@ int flk_net::build_i3d() {
     }
     // The Branch_3 pool reads the block input only: it starts beside the fused 1x1x1 GEMM (98-392 workgroups, which leave CUs
     // idle) on side stream 2 and Branch_3's 1x1x1 follows it there.  The two 3x3x3 branches fork after the GEMM (disjoint
-    // channel slices of `out`).  FLK_POOL_LATE=1 restores the old order (pool after the GEMM).
-    static const bool pool_late = getenv("FLK_POOL_LATE") && atoi(getenv("FLK_POOL_LATE"));
+    // channel slices of `out`).
     Op fused = std::move(fwd.back());
     fwd.pop_back();
-    if (pool_late) fwd.push_back(std::move(fused));
-    push_sync(fwd, K_FORK, pool_late ? ~0 : 2);
+    push_sync(fwd, K_FORK, 2);
     {
       const size_t m0 = fwd.size();
       if ((rc = emit_pool_fwd(bn + "/Branch_3/MaxPool3d_0a_3x3", cur, cur_c, 3, 3, 3, 1, 1, 1, pl, pr3))) return rc;
       set_lane(fwd, m0, 2);
     }
-    const bool grp_f = gf.nfw > 0 && !pool_late, grp_b = gb.nfw > 0;
-    if (!pool_late) {
-      fwd.push_back(std::move(fused));
-      if (!grp_f) push_sync(fwd, K_FORK, 1);
-    }
+    const bool grp_f = gf.nfw > 0, grp_b = gb.nfw > 0;
+    fwd.push_back(std::move(fused));
+    if (!grp_f) push_sync(fwd, K_FORK, 1);
     if (grp_f) {
       // Branch_1 and Branch_2 in one launch on the caller's stream; only Branch_3's pool -> 1x1x1 chain runs beside it (side stream 2)
       emit_group(fwd, bn + "/Branch_1+2/Conv3d_0b_3x3", conv_fwd_args(L1b, mid, 0, out, c0), L1b->wf, conv_fwd_args(L2b, mid, c1a, out, c0 + c1b),
@@ -759,11 +758,9 @@ int flk_net::build_i3d() {
     const std::string pname = bn + "/Branch_3/MaxPool3d_0a_3x3";
     // Branch_3's backward is a CHAIN of two kernels (1x1x1 data-gradient -> pool scatter) beside the two single 3x3x3 data-gradients:
     // started together, its first link is starved by the big launches (19 -> 88 us in Mixed_4c) and the scatter then runs alone on
-    // the device before the join.  FLK_B3_EARLY=1: the 1x1x1 link runs BEFORE the fork, alone (it is short), and the scatter
-    // overlaps the 3x3x3 data-gradients.
-    static const bool b3_early = getenv("FLK_B3_EARLY") && atoi(getenv("FLK_B3_EARLY"));
-    // bf16: Branch_3's backward (1x1x1 data-gradient -> pool scatter) as ONE kernel (FLK_B3_FUSED=0: the two-launch chain)
-    const bool b3_fused = dtype == FLK_BF16 && c3 % 32 == 0 && c3 <= 128 && !(getenv("FLK_B3_FUSED") && atoi(getenv("FLK_B3_FUSED")) == 0);
+    // the device before the join (the 1x1x1 link ahead of the fork instead, alone: measured slower, DESIGN_LOG.md).
+    // bf16: Branch_3's backward (1x1x1 data-gradient -> pool scatter) as ONE kernel; fp32, the parity mode: the two-launch chain
+    const bool b3_fused = dtype == FLK_BF16 && c3 % 32 == 0 && c3 <= 128;
     void* wpg = nullptr;
     if (b3_fused) {
       std::vector<float> wt((size_t)c3 * cur_c);                     // Wt[k][c] = w[c][k] * bn_scale[k]
@@ -774,7 +771,6 @@ int flk_net::build_i3d() {
     }
     const int cur_c_blk = cur_c;
     bwd_emit.push_back([=]() {
-      if (b3_early && !b3_fused) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
       push_sync(bwd, K_FORK, grp_b ? 2 : ~0);
       {
         const size_t m0 = bwd.size();
@@ -789,7 +785,7 @@ int flk_net::build_i3d() {
                              return flk_maxpool3d_bwd_gemm(&pa, gp, gld, gco, K, wpg, gip, gild, 0, FLK_BF16, s);
                            }});
         } else {
-          if (!b3_early) emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
+          emit_conv_bwd(L3, Gout, c0 + c1b + c2b_, Gpl, 0, nullptr, 0, 0, nullptr, 0);
           emit_pool_bwd(pname, pr3, Gpl, gxa, nullptr);
         }
         set_lane(bwd, m0, 2);
@@ -949,10 +945,8 @@ void flk_net::emit_gen_bwd(ConvLayer* L, const Act& G, const Act& gin, const voi
   // The parity classes of a strided layer's data-gradient write disjoint output cells and are small launches on their latency floor.  The
   // EIGHT classes of a 3x3x3 / 2 layer (r3d_18 layer2-4.0) run side by side on the caller's stream and the two side streams: r3d_18 bs 8 2.91 ->
   // 2.81 ms per iteration.  With two or four classes ((3,1,1) / (2,1,1), (1,3,3) / (1,2,2): r2plus1d_18, mc3_18) the fork / join pair costs
-  // more than the overlap gives (r2plus1d_18 bs 8 4.24 -> 4.37, bs 1 2.20 -> 2.36; mc3_18 the same; gpurun_out/lanes_ab.log): those stay in
-  // line.  FLK_VRN_CLASS_LANES=0: always in line; =2: from two classes on.
-  static const int lanes_mode = getenv("FLK_VRN_CLASS_LANES") ? atoi(getenv("FLK_VRN_CLASS_LANES")) : 1;
-  const bool par = lanes_mode != 0 && L->bcls.size() >= (lanes_mode == 2 ? 2u : lanes_mode == 4 ? 4u : 8u);
+  // more than the overlap gives (r2plus1d_18 bs 8 4.24 -> 4.37, bs 1 2.20 -> 2.36; mc3_18 the same): those stay in line.
+  const bool par = L->bcls.size() >= 8u;
   if (par) push_sync(bwd, K_FORK, ~0);
   int ci = 0;
   for (const auto& bc : L->bcls) {
@@ -1013,8 +1007,7 @@ int flk_net::build_videoresnet() {
   // bf16: the clip arrives as TWO bf16 numbers per value (flk_apply_args.fold_t = 4: channels [0,16) = bf16(x_adv), [16,32) = the
   // remainder), both halves against the same weights -- the stem's K step had 32 channels anyway (16 padded): same MFMA work, the
   // perturbed clip to ~16 bits.  The data-gradient keeps the 16-channel operator (its output is the gradient of x_adv).
-  static const bool hilo_off = getenv("FLK_VRN_HILO") && atoi(getenv("FLK_VRN_HILO")) == 0;      // (A/B: one bf16 number per value, the round-3 input)
-  const bool hilo = dtype == FLK_BF16 && !hilo_off;
+  const bool hilo = dtype == FLK_BF16;
   flk_conv_weights* stem_wf = stem->wf;
   if (hilo) {
     std::vector<float> w2((size_t)skt * 16 * 32 * stem->cout);
@@ -1250,12 +1243,8 @@ extern "C" int flk_net_finalize(flk_net* n) {
   // which is what the waiting queue needs.  Measured: the idle gap at each fork and join shrinks, 7.14 -> 6.88 ms per step.
   const unsigned evf = getenv("FLK_EVENT_FLAGS") ? (unsigned)strtoul(getenv("FLK_EVENT_FLAGS"), nullptr, 0)
                                                  : (hipEventDisableTiming | hipEventDisableSystemFence);
-  const int prio_mode = getenv("FLK_SIDE_PRIO") ? atoi(getenv("FLK_SIDE_PRIO")) : 0;
-  int prio_lo = 0, prio_hi = 0;
-  FLK_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
   for (int l = 0; l < kSideStreams; ++l) {
-    const bool high = prio_mode == 1 || (prio_mode == 2 && l == kSideStreams - 1) || (prio_mode == 3 && l == 0);
-    FLK_CHECK_HIP(hipStreamCreateWithPriority(&n->side[l], hipStreamNonBlocking, high ? prio_hi : 0));
+    FLK_CHECK_HIP(hipStreamCreateWithFlags(&n->side[l], hipStreamNonBlocking));      // (stream priorities for the side lanes: measured, no gain)
     FLK_CHECK_HIP(hipEventCreateWithFlags(&n->ev_join[l], evf));
   }
   FLK_CHECK_HIP(hipStreamCreateWithFlags(&n->mask_stream, hipStreamNonBlocking));
@@ -1277,6 +1266,8 @@ extern "C" int64_t flk_net_input_numel(const flk_net* n) {
                                 : (int64_t)n->B * n->T * (n->H / 2) * (n->W / 2) * n->in_ch;
 }
 extern "C" int flk_net_num_classes(const flk_net* n) { return n ? n->num_classes : 0; }
+extern "C" int flk_net_input_channels(const flk_net* n) { return !n ? 0 : n->arch == FLK_NET_I3D ? 32 : n->in_ch; }
+extern "C" int flk_net_input_fold(const flk_net* n) { return !n ? 0 : n->arch == FLK_NET_I3D ? 3 : n->in_ch == 32 ? 4 : 1; }
 
 static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEvent_t, hipEvent_t>>& ev, bool& ev_valid, hipStream_t s,
                    int replace_op = -1, const std::function<int(hipStream_t)>* replacement = nullptr) {
@@ -1287,8 +1278,8 @@ static int run_ops(flk_net* n, std::vector<Op>& ops, std::vector<std::pair<hipEv
       // timing-only events (hipEventDisableSystemFence, the flag's documented use): a default event's system-scope fence writes the
       // caches back / invalidates them for the host at every record and that cost lands inside the measured interval of an
       // 8-70 us kernel (measured: 73.5 -> 71.7 us per conv launch; rocprofv3's kernel time is 69.8).  hipEventReleaseToDevice
-      // alone changes nothing.  FLK_PROFILE_EVENT_FLAGS overrides (0 = default events).
-      const unsigned pf = getenv("FLK_PROFILE_EVENT_FLAGS") ? (unsigned)strtoul(getenv("FLK_PROFILE_EVENT_FLAGS"), nullptr, 0) : hipEventDisableSystemFence;
+      // alone changes nothing.
+      const unsigned pf = hipEventDisableSystemFence;
       hipEvent_t a, b;
       FLK_CHECK_HIP(hipEventCreateWithFlags(&a, pf));
       FLK_CHECK_HIP(hipEventCreateWithFlags(&b, pf));
@@ -1486,10 +1477,9 @@ extern "C" int flk_net_backward_delta(flk_net* n, const float* dlogits, const fl
     if (rc) return rc;
     FLK_CHECK_HIP(hipEventRecord(n->ev_mask_done, n->mask_stream));
   }
-  // the GEMM per half of the batch on the halves' own streams (multi-stream runs with the mask on its side stream only; measured
-  // FLK_STEM_DGRAD_SPLIT=0: one launch behind the join)
-  static const bool split_off = getenv("FLK_STEM_DGRAD_SPLIT") && atoi(getenv("FLK_STEM_DGRAD_SPLIT")) == 0;
-  const bool halves = beside && n->stem_halves == 2 && !split_off;
+  // the GEMM per half of the batch on the halves' own streams (multi-stream runs with the mask on its side stream only; as one launch
+  // behind the join: 5.567 against 5.536 ms per step)
+  const bool halves = beside && n->stem_halves == 2;
   const int nb_half = n->B / 2;
   if (halves)
     n->delta_part = [n, ac, partials](int b0, int nb, hipStream_t st) {
@@ -1516,8 +1506,7 @@ extern "C" int flk_net_prepare_backward_delta(flk_net* n, const flk_apply_args* 
   FLK_REQUIRE(a->B == n->B && a->T == n->T && a->H == n->H && a->W == n->W, "flk_net_prepare_backward_delta: apply args (%d,%d,%d,%d) do not match "
               "the net (%d,%d,%d,%d)", a->B, a->T, a->H, a->W, n->B, n->T, n->H, n->W);
   n->premask = false;
-  static const bool off = getenv("FLK_PREMASK") && atoi(getenv("FLK_PREMASK")) == 0;
-  if (off || !(n->multi_stream && n->mask_stream && !n->profile)) return FLK_OK;
+  if (!(n->multi_stream && n->mask_stream && !n->profile)) return FLK_OK;
   hipStream_t s = (hipStream_t)stream;
   FLK_CHECK_HIP(hipEventRecord(n->ev_mask_fork, s));          // behind everything queued so far: the previous update of delta, the previous GEMM's reads
   FLK_CHECK_HIP(hipStreamWaitEvent(n->mask_stream, n->ev_mask_fork, 0));

@@ -321,8 +321,6 @@ static bool strided_owner_ok(const flk_pool_args* a, int kt, int kh, int kw, int
 struct PoolTP {
   PoolKP k;
   int Tt, Ht, Wt, nTt, nTh, nTw, Th, Hh, Wh, P, plane_b, rows, ntiles, nslab;
-  int interleave;      // 1: tile i on XCD i % 8 (default); 0: contiguous chunks of tiles per XCD (FLK_POOL_XCD_CHUNK=1)
-  int legacy_skew;     // W-run forward: the plane skew of pplane_off (FLK_POOL_WSKEW=0; A/B timing)
   int dbg;             // timing experiments only (FLK_PF_DBG, W-run forward): 1 = no halo loads, 2 = no column maxima, 4 = no stores
 };
 
@@ -331,13 +329,12 @@ __device__ static inline int pplane_off(int c, int plane_b) { return c * plane_b
 // 1-D grid -> (tile, channel slab).  Workgroups are dealt to the 8 XCDs round-robin, so the slabs of ONE tile are put
 // on consecutive slots of the SAME XCD: together they touch whole cache lines of every position while those lines
 // are still in that XCD's L2 (a slab is only 64 B of a position's row).
-// PoolTP.interleave = 0 deals the tiles themselves to the XCDs in contiguous chunks (XCD x works through tiles [x * chunk, (x + 1) * chunk)
-// in order; FLK_POOL_XCD_CHUNK=1), 1 (default) puts tile i on XCD i % 8.
+// Tile i sits on XCD i % 8 (dealing the tiles to the XCDs in contiguous chunks, as the convolutions do, measured 6.81 against 6.77-6.79 ms
+// per step: DESIGN_LOG.md).
 __device__ static inline bool tile_slab_of_block(const PoolTP& p, int nslab, int& tile, int& slab) {
   const int bid = blockIdx.x, xcd = bid & 7, r = bid >> 3;
   slab = r % nslab;
-  const int chunk = (int)gridDim.x / (8 * nslab);            // = ceil(ntiles / 8): the host sizes the grid as 8 * chunk * nslab
-  tile = p.interleave ? (r / nslab) * 8 + xcd : xcd * chunk + r / nslab;
+  tile = (r / nslab) * 8 + xcd;                              // (the host sizes the grid as 8 * ceil(ntiles / 8) * nslab)
   return tile < p.ntiles;
 }
 __device__ static inline bool tile_slab_of_block(const PoolTP& p, int& tile, int& slab) { return tile_slab_of_block(p, p.nslab, tile, slab); }
@@ -348,13 +345,6 @@ __device__ static inline bool tile_slab_of_block(const PoolTP& p, int& tile, int
 __device__ static inline int qdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 __device__ static inline void split3(int x, int d1, float inv1, int d2, float inv2, int& a, int& b, int& c) {   // x = (a * d1) + b * d2 + c, d1 = (rows of b) * d2
   a = qdiv(x, inv1); const int rem = x - a * d1; b = qdiv(rem, inv2); c = rem - b * d2;
-}
-
-// (measured: chunked pool tiles 6.81 vs interleaved 6.77-6.79 ms per step with the convolutions chunked -- the pools keep the
-// interleaved order; FLK_POOL_XCD_CHUNK=1 selects the chunked one)
-static int pool_interleave() {
-  static const int v = !(getenv("FLK_POOL_XCD_CHUNK") && atoi(getenv("FLK_POOL_XCD_CHUNK")) == 1);
-  return v;
 }
 
 template <typename T>
@@ -510,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_tiled_fwd_bf16(const PoolTP
 // pairs x 4 channel chunks, the pairs' slots one halo row (WT + 2 = 9: odd) apart, so units 4 c + 9 j are all different.  The 32 bytes
 // per plane PAIR of pplane_off put chunks 0 / 1 and 2 / 3 on the same banks: rocprofv3 counted SQ_LDS_BANK_CONFLICT = 65 % of this
 // kernel's SQ_LDS_IDX_ACTIVE (four passes per read), as many LDS cycles per column as its VALU cycles.
-__device__ static inline int wplane_off(int c, int plane_b, int legacy) { return legacy ? c * plane_b + (c >> 1) * 32 : c * (plane_b + 64); }
+__device__ static inline int wplane_off(int c, int plane_b) { return c * (plane_b + 64); }
 template <int WT>
 __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP p) {
   constexpr int EPL = 8, SLABC = 32;
@@ -550,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
       if (hp >= p.P) break;
       uint4 w = v[u];
       w.x = bf16x2_to_keys(w.x); w.y = bf16x2_to_keys(w.y); w.z = bf16x2_to_keys(w.z); w.w = bf16x2_to_keys(w.w);
-      *(uint4*)(smem + wplane_off(ch, p.plane_b, p.legacy_skew) + hp * 16) = w;
+      *(uint4*)(smem + wplane_off(ch, p.plane_b) + hp * 16) = w;
     }
   }
   __syncthreads();
@@ -560,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void maxpool_s1_wrun_fwd_bf16(const PoolTP 
     const int rt = qdiv(pr, 1.0f / (float)p.Ht), rh = pr - rt * p.Ht;
     const int ot = ot0 + rt, oh = oh0 + rh;
     if (ot >= k.To || oh >= k.Ho) continue;
-    const char* base = smem + wplane_off(ch, p.plane_b, p.legacy_skew) + ((rt * p.Hh + rh) * WH) * 16;
+    const char* base = smem + wplane_off(ch, p.plane_b) + ((rt * p.Hh + rh) * WH) * 16;
     uint32_t cm[3][8];
     auto colmax = [&](int c, uint32_t (&m)[8]) {
 #pragma unroll
@@ -650,11 +640,8 @@ static int launch_wrun_fwd(const PoolKP& kp, const flk_pool_args* a, hipStream_t
   tp.plane_b = (tp.P * 16 + 255) / 256 * 256;
   const size_t lds = 4 * (size_t)tp.plane_b + 256;               // (wplane_off: 64 bytes of skew per plane)
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
-  tp.interleave = pool_interleave();
-  static const bool legacy_skew = getenv("FLK_POOL_WSKEW") && atoi(getenv("FLK_POOL_WSKEW")) == 0;
-  tp.legacy_skew = legacy_skew;
 #ifdef FLK_ABLATE
-  { const char* e = getenv("FLK_PF_DBG"); tp.dbg = e ? atoi(e) : 0; }
+  tp.dbg = flk_ablate_env("FLK_PF_DBG");
 #endif
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   static bool attr_set[FLK_MAX_DEVICES] = {};
@@ -1187,7 +1174,6 @@ static int launch_scatter_bwd(const PoolKP& kp, const flk_pool_args* a, hipStrea
   tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
   tp.nTt = (a->Ti + t.Tt - 1) / t.Tt; tp.nTh = (a->Hi + t.Ht - 1) / t.Ht; tp.nTw = (a->Wi + t.Wt - 1) / t.Wt;
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 4 * EPL - 1) / (4 * EPL);
-  tp.interleave = pool_interleave();
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
   tp.plane_b = (tp.rows + 47) / 64 * 64 + 16;                         // accumulator plane stride in floats, = 16 (mod 64)
@@ -1217,14 +1203,12 @@ static int launch_tiled(const PoolKP& kp, const flk_pool_args* a, bool bwd, hipS
   constexpr int EPL = PV<T>::EPL;
   const size_t lds = 4 * (size_t)tp.plane_b + 64 + (bwd ? (size_t)4 * tp.P * EPL + 16 : 0);
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 4 * EPL - 1) / (4 * EPL);
-  tp.interleave = pool_interleave();
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   static bool attr_fwd[FLK_MAX_DEVICES] = {}, attr_bwd[FLK_MAX_DEVICES] = {};
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_fwd<T>, 96 * 1024, attr_fwd)) return rc;
   if (int rc = flk_raise_lds_limit((const void*)maxpool_s1_tiled_bwd<T>, 96 * 1024, attr_bwd)) return rc;
-  static const bool no_wrun = getenv("FLK_POOL_NO_WRUN") != nullptr;
   if (bwd) FLK_LAUNCH_KERNEL(maxpool_s1_tiled_bwd<T>, grid, dim3(256), lds, s, tp);
-  else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3 && a->pt == 1 && a->ph == 1 && a->pw == 1 && !no_wrun) {
+  else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3 && a->pt == 1 && a->ph == 1 && a->pw == 1) {
     return a->Wo % 7 == 0 ? launch_wrun_fwd<7>(kp, a, s) : launch_wrun_fwd<8>(kp, a, s);
   } else if (sizeof(T) == 2 && a->kt == 3 && a->kh == 3 && a->kw == 3) {
     static bool attr2[FLK_MAX_DEVICES] = {};
@@ -1273,8 +1257,7 @@ extern "C" int flk_maxpool3d_fwd(const flk_pool_args* a, int dtype, void* stream
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   FLK_REQUIRE(a->Ho < 65536 && (long)a->B * a->To < 65536, "flk_maxpool3d_fwd: grid too large");
   const dim3 grid((unsigned)((a->Wo * (a->C / epl) + 255) / 256), (unsigned)a->Ho, (unsigned)(a->B * a->To));
-  static const bool fixed_k = !(getenv("FLK_POOL_FWD_FIXED") && atoi(getenv("FLK_POOL_FWD_FIXED")) == 0);
-  const int kcode = fixed_k ? a->kt * 100 + a->kh * 10 + a->kw : 0;
+  const int kcode = a->kt * 100 + a->kh * 10 + a->kw;
   if (dtype == FLK_BF16) {
     if (kcode == 133) FLK_LAUNCH_KERNEL((maxpool_fwd_kernel_k<bf16_t, 1, 3, 3>), grid, dim3(256), 0, (hipStream_t)stream, kp);
     else if (kcode == 333) FLK_LAUNCH_KERNEL((maxpool_fwd_kernel_k<bf16_t, 3, 3, 3>), grid, dim3(256), 0, (hipStream_t)stream, kp);
@@ -1304,9 +1287,7 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
   kp.mask = (const char*)mask; kp.mask_ld = mask_ld; kp.mask_coff = mask_coff;
   kp.add = nullptr;
   FLK_REQUIRE(dtype == FLK_BF16 || dtype == FLK_F32, "flk_maxpool3d_bwd: bad dtype");
-  static const bool use_gather = getenv("FLK_POOL_GATHER") != nullptr;     // bitwise-reproducible gather forms on request
-  static const bool no_owner = getenv("FLK_POOL_NO_OWNER") != nullptr;
-  if (!no_owner) {
+  {
     hipStream_t s = (hipStream_t)stream;
 #define FLK_OWNER(KT, KH, KW, ST, SH, SW)                                                                   \
     if (strided_owner_ok(a, KT, KH, KW, ST, SH, SW))                                                          \
@@ -1316,17 +1297,14 @@ extern "C" int flk_maxpool3d_bwd(const flk_pool_args* a, const void* gout, int g
 #undef FLK_OWNER
   }
   // fp32 is the parity mode: it takes the gather form (fixed summation order) so that two fp32 runs are bitwise equal; the scatter
-  // form's float LDS atomics are order-dependent in the last ulp, which Adam turns into 1e-4 relative on tiny components
-  // (FLK_POOL_SCATTER_F32=1 restores the scatter form for fp32)
-  static const bool scatter_f32 = getenv("FLK_POOL_SCATTER_F32") != nullptr;
-  if (!use_gather && (dtype == FLK_BF16 || scatter_f32))
-    return dtype == FLK_BF16 ? launch_scatter_bwd<bf16_t>(kp, a, (hipStream_t)stream) : launch_scatter_bwd<float>(kp, a, (hipStream_t)stream);
-  if (use_tiled(a)) return dtype == FLK_BF16 ? launch_tiled<bf16_t>(kp, a, true, (hipStream_t)stream) : launch_tiled<float>(kp, a, true, (hipStream_t)stream);
+  // form's float LDS atomics are order-dependent in the last ulp, which Adam turns into 1e-4 relative on tiny components.  bf16 takes the
+  // scatter form (32-bit fixed-point integer LDS atomics: order-independent, bitwise reproducible as well)
+  if (dtype == FLK_BF16) return launch_scatter_bwd<bf16_t>(kp, a, (hipStream_t)stream);
+  if (use_tiled(a)) return launch_tiled<float>(kp, a, true, (hipStream_t)stream);
   const int epl = dtype == FLK_BF16 ? 8 : 4;
   FLK_REQUIRE(a->Hi < 65536 && (long)a->B * a->Ti < 65536, "flk_maxpool3d_bwd: grid too large");
   const dim3 grid((unsigned)((a->Wi * (a->C / epl) + 255) / 256), (unsigned)a->Hi, (unsigned)(a->B * a->Ti));
-  if (dtype == FLK_BF16) FLK_LAUNCH_KERNEL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, kp);
-  else FLK_LAUNCH_KERNEL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
+  FLK_LAUNCH_KERNEL(maxpool_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, kp);
   FLK_CHECK_HIP(hipGetLastError());
   return FLK_OK;
 }
@@ -1383,7 +1361,7 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   pg.t.k.gin = (char*)gin; pg.t.k.gin_ld = gin_ld; pg.t.k.gin_coff = gin_coff;
   pg.g = (const char*)g; pg.g_ld = g_ld; pg.g_coff = g_coff; pg.KS = K / 32; pg.wpack = (const char*)wpack;
 #ifdef FLK_ABLATE
-  { const char* e = getenv("FLK_PG_DBG"); pg.dbg = e ? atoi(e) : 0; }
+  pg.dbg = flk_ablate_env("FLK_PG_DBG");
 #endif
   const char* const reg_env = getenv("FLK_POOL_GEMM_REG");     // (read per call: the tests compare the two forms)
   const bool reg_form = !(reg_env && atoi(reg_env) == 0);
@@ -1393,13 +1371,11 @@ extern "C" int flk_maxpool3d_bwd_gemm(const flk_pool_args* a, const void* g, int
   tp.Tt = t.Tt; tp.Ht = t.Ht; tp.Wt = t.Wt; tp.rows = t.Tt * t.Ht * t.Wt;
   tp.nTt = (a->Ti + t.Tt - 1) / t.Tt; tp.nTh = (a->Hi + t.Ht - 1) / t.Ht; tp.nTw = (a->Wi + t.Wt - 1) / t.Wt;
   tp.ntiles = a->B * tp.nTt * tp.nTh * tp.nTw; tp.nslab = (a->C + 31) / 32;
-  tp.interleave = pool_interleave();
   const dim3 grid((unsigned)((tp.ntiles + 7) / 8 * 8 * tp.nslab));
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
   { // accumulator plane stride in words: 4 (mod 64) -- the four lane groups q of an atomic (planes 4 q + j) start 16 banks apart
-    // (16 (mod 64), the stride of maxpool_scatter_bwd, puts all four on the same banks); FLK_POOL_PLANE_MOD overrides the residue
-    static const char* const e = getenv("FLK_POOL_PLANE_MOD");
-    static const int res = e ? atoi(e) & 63 : 4;
+    // (16 (mod 64), the stride of maxpool_scatter_bwd, puts all four on the same banks)
+    constexpr int res = 4;
     tp.plane_b = (tp.rows - res + 63) / 64 * 64 + res;
   }
   const size_t lds = (size_t)(32 * tp.plane_b + 64) * sizeof(float);

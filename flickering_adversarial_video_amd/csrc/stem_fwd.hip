@@ -393,8 +393,8 @@ extern "C" int flk_stem_fwd_u8(const flk_apply_args* a, const flk_conv_weights* 
   kp.out = (char*)out; kp.out_ld = out_ld;
   kp.To = a->T / 2; kp.nTt = (kp.To + SF_TT - 1) / SF_TT;
 #ifdef SF_ABLATE
-  kp.ablate = getenv("FLK_SF_ABLATE") ? atoi(getenv("FLK_SF_ABLATE")) : 0;
-  kp.stagger = getenv("FLK_SF_STAGGER") ? atoi(getenv("FLK_SF_STAGGER")) : 0;
+  kp.ablate = flk_ablate_env("FLK_SF_ABLATE");
+  kp.stagger = flk_ablate_env("FLK_SF_STAGGER");
 #endif
   hipStream_t st = (hipStream_t)stream;
   // (NI = 8 -- 128 positions per wave, 32 MFMAs per 12 fragment reads, two workgroups per CU -- measured 0.273 vs 0.258 ms: only in

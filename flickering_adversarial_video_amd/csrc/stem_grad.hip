@@ -498,7 +498,9 @@ extern "C" int flk_stem_delta_grad_mask(const flk_apply_args* a, float* scratch,
 // chunks per frame pair for launches of nb clips each (per-clip perturbations: the chunking of a batch-1 call)
 static void sg_chunks(const flk_apply_args* a, int nb, int Ho, int& nchunk, int& rows_per_chunk) {
   nchunk = sg_nchunk(a->delta_per_clip ? 1 : nb, a->T, Ho);
-  { static const char* e = getenv("FLK_SG_NCHUNK"); if (e && atoi(e) > 0) nchunk = atoi(e) < 16 ? atoi(e) : 16; }
+#ifdef FLK_ABLATE
+  if (const int e = flk_ablate_env("FLK_SG_NCHUNK")) nchunk = e < 16 ? e : 16;
+#endif
   rows_per_chunk = (Ho + nchunk - 1) / nchunk;
   nchunk = (Ho + rows_per_chunk - 1) / rows_per_chunk;       // no empty chunks
 }
@@ -521,7 +523,7 @@ int flk_stem_delta_grad_part(const flk_apply_args* a, int b0, int nb, const void
   kp.partials = scratch + (size_t)b0 * (a->T / 2) * kp.nchunk * 6;
   kp.mask = (const char*)scratch + sg_partial_bytes(a->B, a->T, a->H) + (size_t)b0 * a->T * a->H * SG_ROWSET;
 #ifdef FLK_ABLATE
-  { static const char* e = getenv("FLK_SG_DBG"); kp.dbg = e ? atoi(e) : 0; }
+  kp.dbg = flk_ablate_env("FLK_SG_DBG");
 #endif
   static bool attr_set[FLK_MAX_DEVICES] = {};
   if ((rc = flk_raise_lds_limit((const void*)stem_delta_grad_kernel, SG_LDS, attr_set))) return rc;

@@ -82,6 +82,17 @@ def conv3d_group(members, nfw, ring=False):
     return [o for _, o in built]
 
 
+def conv3d_pc(members):
+    """members: [(x, w, kwargs)] -- up to three 3x3x3 stride-1 bf16 convolutions (weights packed with nf = 4) in ONE persistent launch of
+    the producer / consumer kernel (flk_conv3d_pc); returns their outputs.  Bitwise the outputs of conv3d."""
+    built = [conv3d_args(x, w, **kw) for x, w, kw in members]
+    n = len(built)
+    ap = (C.POINTER(ConvArgs) * n)(*[C.pointer(a) for a, _ in built])
+    wp = (C.c_void_p * n)(*[w.handle for _, w, _ in members])
+    check(load().flk_conv3d_pc(ap, wp, n, dtype_code(members[0][0].dtype), stream_ptr()))
+    return [o for _, o in built]
+
+
 def conv3d_args(x, w, *, in_coff=0, cin=None, stride=(1, 1, 1), pad=None, out=None, out_coff=0, out_grid=None,
                 out_stride=(1, 1, 1), out_offset=(0, 0, 0), scale=None, bias=None, add=None, add_coff=0, mask=None,
                 mask_coff=0, relu=False, in2=None, in2_coff=0, out2=None, out2_coff=0, cout1=0, splitk=False, pos_bias=None):
@@ -463,8 +474,8 @@ class Net:
         self.input_numel = load().flk_net_input_numel(h)
         # VideoResNet plans: channels of the (h,w)-folded input tensor -- 16, or 32 in bf16 (two bf16 numbers per value, fold_t = 4);
         # the input GRADIENT always has the 16-channel layout
-        self.input_channels = self.input_numel // (B * (T // 2 if arch == FLK_NET_I3D else T) * (H // 2) * (W // 2))
-        self.input_fold = I3D_FOLD if arch == FLK_NET_I3D else (4 if self.input_channels == 32 else 1)
+        self.input_channels = load().flk_net_input_channels(h)
+        self.input_fold = load().flk_net_input_fold(h)
         self.grad_numel = self.input_numel if arch == FLK_NET_I3D else self.input_numel // self.input_channels * 16
         self.workspace_bytes = load().flk_net_workspace_bytes(h)
 

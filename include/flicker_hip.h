@@ -119,6 +119,19 @@ int64_t flk_conv_splitk_bytes(const flk_conv_args* a, const flk_conv_weights* w)
  * one template argument the members share; every w[i] must have been packed with nf in {nfw, 2 nfw, 4 nfw}.  ring != 0: the members
  * take the LDS weight ring instead (the large launches' path): all packed with nf == nfw (4 or 8), 256-row tiles.  Longest K loops first. */
 int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype, void* stream);
+/* n <= 3 convolutions of 3x3x3 taps, stride 1, bf16, weights packed with nf = 4 (i3d.py:183-186 Conv3d_2c_3x3; 200-209 / 229-238 Branch_1 and
+ * Branch_2 of the Mixed_3* blocks; forward and data-gradient) in ONE persistent launch with wave-specialised producers (csrc/conv_pc.hip: one
+ * 512-thread workgroup per CU; four consumer waves that only read fragments and issue MFMAs, two waves streaming the weights by LDS-DMA, two
+ * staging the next halo).  Bitwise the outputs of flk_conv3d.  Members in the order given, longest K loops first.
+ * flk_conv3d_pc_why_not: NULL when flk_conv3d_pc takes the convolution, else the reason (a static string). */
+int flk_conv3d_pc(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int dtype, void* stream);
+const char* flk_conv3d_pc_why_not(const flk_conv_args* a, const flk_conv_weights* w, int dtype);
+/* 1 when a plan should send these convolutions to flk_conv3d_pc: eligible, at least two rounds of items per workgroup and a modelled
+ * efficiency >= 0.8 (the large layers at the benchmark batch); flk_conv3d and flk_conv3d_group route by it themselves */
+int flk_conv3d_pc_worthwhile(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int dtype);
+/* the validation and planning of flk_conv3d_group without the launch (FLK_OK / the error the launch would return): plan builders call it
+ * once per group when the plan is built */
+int flk_conv3d_group_check(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype);
 /* the (waves along the channels, weight path: 0 LDS ring / 5 LDS ring with the weights a row of taps ahead / 1 direct A / ...) flk_conv3d's heuristics choose for this geometry when the
  * weights are packed at `nf` (force_da: -1 heuristic, 0 ring, 1 direct A): lets a plan builder pick the packing of a grouped launch's
  * members before any weights exist.  No device work. */
@@ -333,11 +346,13 @@ int flk_net_forward_flicker(flk_net* n, const void* x_in, const flk_apply_args* 
 /* apply + forward in one call: the plan launches flk_perturb_apply_s2d itself, per batch slice on the stream that slice's stem
  * convolution runs on (I3D at bs >= 4: the two half-batches -- the second half's apply overlaps the first half's stem), writing the
  * space-to-depth clip into x_s2d_out; with a->center = 1 (flk_net_has_forward_flicker) the position-class bias path is taken.
- * a->fold_t must be the plan's layout (3 for I3D, 1 for VideoResNet).  Same logits as apply followed by flk_net_forward[_flicker].
+ * a->fold_t must be the plan's layout, flk_net_input_fold(): 3 for I3D; VideoResNet plans 1 in fp32 (16 channels) and 4 in bf16 (32 channels:
+ * every value as two bf16 numbers, [hi(16) | lo(16)]).  Same logits as apply followed by flk_net_forward[_flicker].
  * x_s2d_out is SCRATCH: when the stem reads the uint8 clip itself (I3D plan in bf16, a->x_is_u8 with a->center = 1 -- the default
  * engine path) it is left untouched, so a caller that needs the space-to-depth tensor calls flk_perturb_apply_s2d itself. */
 int flk_net_forward_apply(flk_net* n, const flk_apply_args* a, void* x_s2d_out, float* logits, void* stream);
-/* dlogits fp32 [B,C] -> gradient w.r.t. the network input (same layout/dtype as x_in) */
+/* dlogits fp32 [B,C] -> gradient w.r.t. the network input: dtype of x_in; layout of x_in for I3D ([B,T/2,H/2,W/2,32]); VideoResNet plans ALWAYS
+ * [B,T,H/2,W/2,16] -- the gradient of x_adv -- also where the bf16 input has 32 channels (hi | lo) */
 int flk_net_backward(flk_net* n, const float* dlogits, void* gx_in, void* stream);
 /* backward straight to the flickering perturbation: the plan without the stem's data-gradient, then flk_stem_delta_grad on the
  * stem's output gradient.  gdelta fp32 [T,3]; scratch: flk_stem_delta_grad_scratch_bytes(B, T, H).  I3D in bf16 only
@@ -356,7 +371,11 @@ int flk_net_profile(flk_net* n, int enable);
  * its real operands (x_in / dlogits as for forward / backward; synchronises the stream) */
 int flk_net_autotune(flk_net* n, const void* x_in, float* logits, const float* dlogits, void* gx_in, void* stream);
 int flk_net_profile_read(flk_net* n, char* json_out, int64_t cap);
+/* the input tensor flk_net_forward reads (it cannot check the buffer it is given): elements, channels per folded position
+ * (I3D 32; VideoResNet 16 in fp32, 32 in bf16) and the flk_apply_args.fold_t that produces it (3 / 1 / 4) */
 int64_t flk_net_input_numel(const flk_net* n);
+int flk_net_input_channels(const flk_net* n);
+int flk_net_input_fold(const flk_net* n);
 int flk_net_num_classes(const flk_net* n);
 /* debugging / parity: copy a named activation (fp32, NDHWC) to the host */
 int flk_net_get_activation(flk_net* n, const char* name, float* host_out, int64_t cap_numel, int64_t* dims5);

@@ -77,3 +77,28 @@ def test_audit_flags_a_drained_row_ahead_queue(tmp_path):
     m = re.search(r"(\d+) row-ahead kernels with compiler vmcnt waits in the tap loop", r.stdout)
     assert m and int(m.group(1)) >= 1, r.stdout[-500:]
     assert re.search(r"kernels with asm loads audited, 0 with violations", r.stdout), "only the second check may fire"
+
+
+def test_ablation_variants_pass_the_audit():
+    """The round-4 GPU fault: -DCONV_ABLATE variants whose substitute fragments read a weight-queue register before its counted wait.
+    The substitutes are zero fragments now; this pins it -- every ablation bit that skips fragment reads (16, 32, both, all) audits clean --
+    and nothing is re-run on a GPU to see the abort again.  The four compiles run side by side."""
+    from concurrent.futures import ThreadPoolExecutor
+    variants = ["-DCONV_ABLATE=16", "-DCONV_ABLATE=32", "-DCONV_ABLATE=48", "-DCONV_ABLATE=63"]
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(lambda f: subprocess.run([sys.executable, AUDIT, SRC, f], capture_output=True, text=True, timeout=1200), variants))
+    for f, r in zip(variants, res):
+        assert r.returncode == 0, f + "\n" + r.stdout[-3000:] + r.stderr[-2000:]
+        assert "kernels with asm loads audited, 0 with violations" in r.stdout and " 0 kernels" not in r.stdout, f
+
+
+def test_variant_builds_refuse_a_flagged_source(tmp_path, monkeypatch):
+    """build.audit_asm_sources is what FLK_HIPCC_EXTRA builds and tools/build_variant.py call before compiling: it raises on the hazard
+    fixture (one kernel lets hipcc copy an in-flight register) and passes a source without asm loads untouched"""
+    from flickering_adversarial_video_amd import build as B
+    fixture = os.path.join(ROOT, "tests", "fixtures", "asm_inflight_fixture.hip")
+    monkeypatch.setattr(B, "CSRC", os.path.dirname(fixture))
+    monkeypatch.setattr(B, "ASM_LOAD_SOURCES", ["asm_inflight_fixture.hip"])
+    with pytest.raises(RuntimeError, match="audit of asm_inflight_fixture.hip"):
+        B.audit_asm_sources(["asm_inflight_fixture.hip"], ["-DSOMETHING=1"])
+    B.audit_asm_sources(["pool.hip"], ["-DSOMETHING=1"])      # not an asm-load source: nothing to audit, no exception

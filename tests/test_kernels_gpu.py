@@ -669,3 +669,68 @@ def test_conv_ring_weights_a_row_ahead(ops, transpose):
     torch.testing.assert_close(out4.float().cpu(), ref, rtol=r * 2, atol=a * 2)
     assert torch.equal(out4, out8) and torch.equal(out4, out6)
     assert torch.equal(run(4), out4)
+
+
+PC_CASES = [
+    # name, B, T, H, W, [(cin, cout), ...] members, data-gradient form?   -- flk_conv3d_pc: 3x3x3 stride 1, weights packed with nf = 4
+    ("fwd_64_192_8x8x8_tiles", 1, 16, 16, 24, [(64, 192)], False),              # 512-row tiles, two slabs, three channel tiles (Conv3d_2c's shape class)
+    ("dgrad_192_64", 1, 8, 16, 16, [(192, 64)], True),                          # six slabs; ReLU mask in the epilogue
+    ("fwd_96_128_28x28_448_row_tiles", 1, 16, 28, 28, [(96, 128)], False),      # 16x4x7 tiles: seven fragments per consumer wave (NI = 7), three slabs (odd step count)
+    ("group_128_192+32_96", 2, 8, 14, 14, [(128, 192), (32, 96)], False),       # two members (Mixed_3c Branch_1 + Branch_2): different K loops, 96 = 1.5 channel tiles
+    ("group_dgrad_128_96+32_16", 1, 16, 14, 14, [(128, 96), (32, 16)], True),   # narrow outputs: 16 channels in a 64-wide tile
+    ("ragged_40_72_partial_tiles", 3, 5, 9, 11, [(40, 72)], False),             # 40 input channels (a half-valid slab), grid not a multiple of any tile, several clips
+    ("one_slab_16_32", 1, 8, 8, 8, [(16, 32)], False),                          # a 27-step item: fewer steps in flight than the ring is deep for the prologue
+]
+
+
+@pytest.mark.parametrize("case", PC_CASES, ids=[c[0] for c in PC_CASES])
+def test_conv_pc(ops, case):
+    """flk_conv3d_pc (csrc/conv_pc.hip): the persistent producer / consumer form of the large 3x3x3 layers.  Each member against the torch-CPU
+    oracle (bf16 tolerances) with the epilogue the plan uses -- scale, bias, ReLU forward; transposed weights x BN scale, ReLU mask in the
+    data-gradient -- and BITWISE against flk_conv3d on the same packed weights (same K order per output, same epilogue); a second run gives
+    the same bits (no ordering inside the kernel decides a value)."""
+    _, B, T, H, W, mem, tr = case
+    dtype = torch.bfloat16
+    ci_tot = sum(c[0] for c in mem)
+    co_tot = sum(c[1] for c in mem) + 8
+    xin = q(rnd((B, T, H, W, ci_tot), 11), dtype)
+    xg = xin.to(dtype).cuda()
+    maskt = q(rnd((B, T, H, W, co_tot), 12), dtype)
+    out_p = torch.zeros((B, T, H, W, co_tot), dtype=dtype, device="cuda")
+    out_s = torch.zeros_like(out_p)
+    members, singles, refs = [], [], []
+    in_off, out_off = 0, 8
+    for i, (cin, cout) in enumerate(mem):
+        if tr:      # the data-gradient operator of a forward layer cout -> cin: G (cin channels here) -> gx (cout channels), BN scale folded
+            w_fwd = q(rnd((3, 3, 3, cout, cin), 20 + i, (2.0 / (27 * cout)) ** 0.5), dtype)
+            sc = rnd((cin,), 30 + i).abs() + 0.5
+            g = xin[..., in_off:in_off + cin].contiguous()
+            x0 = torch.zeros((B, T, H, W, cout), requires_grad=True)
+            y = ref_conv(x0, w_fwd, (1, 1, 1), (1, 1, 1), (T, H, W)) * sc
+            (ref,) = torch.autograd.grad(y, x0, g)
+            ref = ref * (maskt[..., out_off:out_off + cout] > 0)
+            pw = ops.ConvWeights(w_fwd.numpy(), dtype, 4, transpose=True, row_scale=sc.numpy())
+            kw = dict(in_coff=in_off, cin=cin, out_coff=out_off, mask=maskt.to(dtype).cuda(), mask_coff=out_off)
+        else:
+            w = q(rnd((3, 3, 3, cin, cout), 20 + i, (2.0 / (27 * cin)) ** 0.5), dtype)
+            sc = rnd((cout,), 30 + i).abs() + 0.5
+            bi = rnd((cout,), 40 + i, 0.1)
+            ref = torch.relu(ref_conv(xin[..., in_off:in_off + cin].contiguous(), w, (1, 1, 1), (1, 1, 1), (T, H, W)) * sc + bi)
+            pw = ops.ConvWeights(w.numpy(), dtype, 4)
+            kw = dict(in_coff=in_off, cin=cin, out_coff=out_off, scale=sc.cuda(), bias=bi.cuda(), relu=True)
+        refs.append((ref, out_off, cout))
+        members.append((xg, pw, dict(kw, out=out_p)))
+        singles.append((pw, dict(kw, out=out_s)))
+        in_off += cin
+        out_off += cout
+    ops.conv3d_pc(members)
+    for pw, kw in singles:
+        ops.conv3d(xg, pw, **kw)
+    torch.cuda.synchronize()
+    for ref, off, cout in refs:
+        r, a = tol(dtype, ref)
+        torch.testing.assert_close(out_p[..., off:off + cout].float().cpu(), ref, rtol=r * (2 if tr else 1), atol=a * (2 if tr else 1))   # (a * W is rounded once more when folded)
+    assert torch.equal(out_p, out_s)                                    # bitwise flk_conv3d (untouched channels stay zero)
+    again = torch.zeros_like(out_p)
+    ops.conv3d_pc([(x_, w_, dict(k_, out=again)) for x_, w_, k_ in members])
+    assert torch.equal(again, out_p)

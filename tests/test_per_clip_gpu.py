@@ -170,7 +170,33 @@ def test_per_clip_engine_bf16_tracks_single_runs():
         cos, cB, c1 = cosf(gB, g1), cosf(gB, g32), cosf(g1, g32)
         print(f"clip {b}: logits {e_l:.2e}, adversarial loss {e_a:.2e}, gradient cosine batched vs single {cos:.5f}, vs fp32 {cB:.4f} / {c1:.4f}")
         assert e_l < 2e-2 and e_a < 2e-2
-        assert cos >= min(cB, c1) and abs(cB - c1) < 0.06
+        # the relation, plus an absolute floor under the measured minimum (0.971): a partial per-clip mixing error that leaves the
+        # cosine near 0.9 does not pass.  |cB - c1| is printed above; measured 0.004-0.03 over the four clips
+        assert cos >= min(cB, c1) and cos > 0.96 and abs(cB - c1) < 0.06
+
+
+def test_per_clip_engine_bf16_equals_single_runs_with_split_k_pinned(monkeypatch):
+    """the same comparison with split-K switched off in BOTH plans (FLK_NO_SPLITK=1, read when a plan is built): every other launch
+    layout keeps one K order per output, so the batch-4 and the batch-1 plan then do the same arithmetic per clip and the only thing
+    left to differ would be per-clip indexing -- asserted at 1e-3 (logits, loss, delta-gradient), far below bf16 rounding"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("FLK_NO_SPLITK", "1")
+    B = 4
+    W, xu, engB, eng1 = _engines("bf16", B)
+    labels = engB.logits(xu, adv_flag=0.0).argmax(-1).clone()
+    d0 = torch.from_numpy(np.random.default_rng(4).uniform(-0.05, 0.05, (B, T, 3)).astype(np.float32)).cuda()
+    engB.reset_perturbation(d0)
+    r = engB.step(xu, labels, update=False, **HP)
+    for b in range(B):
+        eng1.reset_perturbation(d0[b])
+        r1 = eng1.step(xu[b:b + 1].contiguous(), labels[b:b + 1].contiguous(), update=False, **HP)
+        gB, g1 = engB.delta_gradient()[b], eng1.delta_gradient()
+        e_l = float((engB._logits[b] - eng1._logits[0]).abs().max() / eng1._logits[0].abs().max())
+        e_a = abs(float(r["adv_loss"][b]) - float(r1["adv_loss"])) / max(abs(float(r1["adv_loss"])), 1e-6)
+        e_g = float((gB - g1).abs().max() / g1.abs().max())
+        print(f"clip {b}: logits {e_l:.2e}, adversarial loss {e_a:.2e}, delta-gradient {e_g:.2e}, bitwise {torch.equal(gB, g1)}")
+        assert e_l < 1e-3 and e_a < 1e-3 and e_g < 1e-3
 
 
 def test_batched_script_equals_the_one_by_one_script(tmp_path):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static audit of the hand-issued asynchronous loads in conv_igemm.hip (cdna_hip_programming.md, "What hipcc does not do", 1).
+"""Static audit of the hand-issued asynchronous loads in conv_igemm.hip / conv_pc.hip (cdna_hip_programming.md, "What hipcc does not do", 1).
 
 The direct-A / mode-3 K loops issue `global_load_dwordx4` from inline asm and retire them with hand-counted
 `s_waitcnt vmcnt(N)` statements that name the destination registers ("; release v[a:b] ...").  hipcc treats an asm load's
@@ -166,7 +166,8 @@ def main():
     text = compile_asm(src, extra)
     bad = total = 0
     drained = 0
-    for m in re.finditer(r"^(\S*(?:conv_igemm_kernel|conv_igemm_group_kernel|pw_gemm_kernel)\S*):[^\n]*\n(.*?)\n\s*s_endpgm", text, re.S | re.M):
+    # (a kernel's body runs to its .Lfunc_end label: kernels with early exits hold several s_endpgm, each an "end" node of the CFG)
+    for m in re.finditer(r"^(\S*(?:conv_igemm_kernel|conv_igemm_group_kernel|conv_pc_kernel|pw_gemm_kernel)\S*):[^\n]*\n(.*?)\n\.Lfunc_end\d+:", text, re.S | re.M):
         name, body = m.group(1), m.group(2).split("\n")
         nloads, viol = audit_kernel(name, body)
         if nloads:

@@ -1,7 +1,8 @@
 """Time ONE convolution geometry in isolation (20 launches x 5 repetitions after a 20-launch warm-up; min / median).
 A/B different builds or env knobs by alternating processes -- single measurements inside a long run drift with the clock state.
 
-usage: conv_time.py k cin cout nf B T H W [T]      (k x k x k taps, stride 1 SAME; a trailing argument = data-gradient)"""
+usage: conv_time.py k cin cout nf B T H W [T]      (k x k x k taps, stride 1 SAME; a trailing argument = data-gradient)
+PC=1 in the environment: the launch goes to flk_conv3d_pc (the producer / consumer kernel; 3x3x3, nf 4) instead of flk_conv3d."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from flickering_adversarial_video_amd import ops
@@ -21,8 +22,20 @@ if splitk:
     print("split-K vs one slice: max |diff| %.3e (max |ref| %.3e)" % ((got - ref).abs().max().item(), ref.abs().max().item()))
 import ctypes as C
 _keep = []
+pc = bool(int(os.environ.get("PC", "0")))
+# EPI=1: the epilogue operands the plan uses -- forward: batch-norm scale, bias, ReLU; data-gradient: the ReLU mask of the layer's input
+epi = {}
+if int(os.environ.get("EPI", "0")):
+    co = cin if tr else cout
+    if tr: epi = dict(mask=torch.randn(B, T, H, W, co, device="cuda").to(torch.bfloat16))
+    else: epi = dict(scale=torch.rand(co, device="cuda") + 0.5, bias=torch.randn(co, device="cuda") * 0.1, relu=True)
+if pc:
+    ref = ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W), **epi)
+    got = ops.conv3d_pc([(x, pw, dict(pad=pad, out_grid=(T, H, W), **epi))])[0]
+    print("producer / consumer kernel vs flk_conv3d: bitwise equal", bool(torch.equal(ref, got)))
 def f():
-    ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W), out=out, splitk=splitk)
+    if pc: ops.conv3d_pc([(x, pw, dict(pad=pad, out_grid=(T, H, W), out=out, **epi))])
+    else: ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W), out=out, splitk=splitk, **epi)
 for _ in range(20): f()
 torch.cuda.synchronize()
 ts = []
