@@ -113,6 +113,7 @@ _SIGS = {
     "flk_conv3d_group": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "flk_conv3d_pc": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
     "flk_conv3d_pc_worthwhile": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "flk_conv3d_pc_query": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "flk_conv3d_pc_why_not": (C.c_char_p, [C.POINTER(ConvArgs), C.c_void_p, C.c_int]),
     "flk_conv3d_group_check": (C.c_int, [C.POINTER(C.POINTER(ConvArgs)), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
     "flk_conv_layout_query": (C.c_int, [C.POINTER(ConvArgs), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1126,8 +1126,9 @@ static void pick_halo_layout(ConvKP& kp, size_t ring_bytes, int max_resident) {
 }
 
 constexpr int FLK_MAX_KSPLIT = 8;
-// FLK_CONV_PC=0: the large 3x3x3 layers stay on conv_igemm_kernel (A/B of the producer / consumer kernel, conv_pc.hip; read once)
-static bool pc_route_on() { static const bool on = !(getenv("FLK_CONV_PC") && atoi(getenv("FLK_CONV_PC")) == 0); return on; }
+// FLK_CONV_PC=0: the large 3x3x3 layers stay on conv_igemm_kernel (A/B of the producer / consumer kernel, conv_pc.hip; read once); 1: single
+// launches only (Conv3d_2c_3x3), 2 (default): the Mixed_3* ring groups as well
+static int pc_route_on() { static const int on = getenv("FLK_CONV_PC") ? atoi(getenv("FLK_CONV_PC")) : 2; return on; }
 
 static int launch_any(const ConvKP& kp, dim3 grid, size_t lds, hipStream_t s, int dtype, int nf, int wn, int mode);
 static bool dbg_on() { static const bool d = getenv("FLK_CONV_DBG") != nullptr; return d; }      // print every launch's layout
@@ -1500,7 +1501,7 @@ extern "C" int flk_conv3d_group_check(const flk_conv_args* const* a, const flk_c
 extern "C" int flk_conv3d_group(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype, void* stream) {
   // ring groups of 64-channel tiles on large grids (Branch_1 + Branch_2 of Mixed_3b / 3c at the benchmark batch): the persistent producer / consumer
   // kernel takes all members in one launch -- bitwise the same outputs
-  if (pc_route_on() && ring && nfw == 4 && dtype == FLK_BF16 && a && w && n >= 1 && flk_conv3d_pc_worthwhile(a, w, n, dtype)) return flk_conv3d_pc(a, w, n, dtype, stream);
+  if (pc_route_on() >= 2 && ring && nfw == 4 && dtype == FLK_BF16 && a && w && n >= 1 && flk_conv3d_pc_worthwhile(a, w, n, dtype)) return flk_conv3d_pc(a, w, n, dtype, stream);
   ConvGroupKP g; size_t lds; long total; int gmode;
   if (int rc = group_plan(a, w, n, nfw, ring, dtype, g, lds, total, gmode)) return rc;
   hipStream_t s = (hipStream_t)stream;

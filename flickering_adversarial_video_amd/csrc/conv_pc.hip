@@ -1,28 +1,35 @@
 // 3x3x3 stride-1 convolution (Unit3D forward and data-gradient of the large I3D layers: Conv3d_2c_3x3 and the Mixed_3* Branch_1 /
-// Branch_2 units, i3d.py:183-186, 200-209, 229-238) with WAVE-SPECIALISED producers -- bf16 only.
+// Branch_2 units, i3d.py:183-186, 200-209, 229-238; the 3x3x3 layers of r3d_18 / mc3_18 at large batches) with WAVE-SPECIALISED producers
+// -- bf16 only, round 5.
 //
 // conv_igemm_kernel (conv_igemm.hip) runs 256-thread workgroups in which every wave loads, stages and multiplies; three of them share a
-// CU, and its ablations ("ring write behind the barrier") show a launch costing the SUM of its memory phase and its MFMA phase:
-// a workgroup spends a third of its life outside the tap loop (halo staging, epilogue) and inside it a step lasts ~1100 cycles for 768
-// cycles of MFMA issue.  Here ONE persistent 512-thread workgroup per CU walks a list of (position tile, channel tile) items:
-//   * waves 0-3 (one per SIMD) are CONSUMERS: ds_read_b128 + MFMA only.  A consumer owns 16 NI positions x 64 channels (NI = 8: 512-row
-//     tiles; 32 MFMAs per 12 fragment reads), keeps the fragments of step k + 1 in a second register set -- read while the MFMAs of step k
-//     issue -- and never leaves the tap loop except for its epilogue;
+// CU, and its ablations (DESIGN_LOG.md, "ring write behind the barrier") show a launch costing the SUM of its memory phase and its MFMA
+// phase: a workgroup spends a third of its life outside the tap loop (halo staging, epilogue) and inside it a step lasts ~1100 cycles for
+// 768 cycles of MFMA issue.  Here ONE persistent 512-thread workgroup per CU walks a list of (position tile, channel tile) items:
+//   * waves 0-3 (one per SIMD) are CONSUMERS: ds_read_b128 + MFMA only.  A consumer owns 16 NI positions x 64 channels (NI = 7: 448-row
+//     tiles, 28 MFMAs per 11 fragment reads; NI = 8: 512 rows).  Registers: 16 NI accumulators; the weight fragments in three rotating
+//     sets (read one step ahead, right behind the barrier that publishes them); the position fragments in ONE set -- the MFMAs run position-
+//     fragment-major and a fragment's register is refilled for the next step one group of four MFMAs behind its last use.  The K loop is
+//     (slab, frame of taps) x a fully unrolled body of nine steps: a step holds its barrier, its reads, eight address adds and its MFMAs,
+//     one filler behind each MFMA; no condition -- an item's last step reads the first weights of the NEXT item.  A consumer leaves the tap
+//     loop only for its epilogue (conv_igemm_kernel's arithmetic; one straight-line form per feature set; scale / bias through LDS);
 //   * waves 4-5 stream the WEIGHTS: per K step (32 input channels x one tap) the tile's 4 KiB of MFMA A fragments, by LDS-DMA
-//     (global_load_lds_dwordx4) into a ring of R = 6 slots, D = 4 steps ahead of the consumers, behind a counted s_waitcnt vmcnt;
+//     (global_load_lds_dwordx4) into a ring of R = 6 slots, D = 4 steps ahead of the consumers, behind a counted s_waitcnt vmcnt, across
+//     item boundaries; with an item's first weights, the batch-norm scale / bias of its 64 channels;
 //   * waves 6-7 stage the HALO box of the NEXT 32-channel slab (or of the next item's first slab) into the second of two LDS images while the
-//     consumers multiply out of the first: global loads from inline asm, requested six steps before they are written (hand-counted waits;
-//     tools/audit_asm_loads.py audits this file too).
-// One s_barrier per K step, joined by all eight waves, is the only synchronisation: barrier b_k publishes the weights of step k (landed:
-// the streaming waves waited for them) and, at a slab's first step, its halo image; it frees the ring slot of step k - 2 and, one step
-// into a slab, the image of the slab before it.  Producers arrive early and wait; the consumers' program order is
-//     b_k ; read fragments of step k ; MFMAs of step k - 1 ; b_{k+1} ; ...
-// so that between two barriers a SIMD's matrix pipe has 32 MFMAs to issue and nothing to wait for.
+//     consumers multiply out of the first: one asm global load per 16-byte piece, two pieces requested per step and committed six steps later
+//     (hand-counted waits; tools/audit_asm_loads.py audits this file too).
+// One s_barrier per K step, joined by all eight waves, is the only synchronisation: the barrier of step k publishes the weights of step
+// k + 1 (landed: the streaming waves waited for them) and, before a slab's first read, its halo image; it frees the ring slot of step k - 1
+// and, one step into a slab, the image of the slab before it.  Producers arrive early and wait.
 // Same products, same K order per output (slab-major, taps t-h-w) and the same epilogue as conv_igemm_kernel: bitwise its results.
+// Measured (MI355X, round 5): Conv3d_2c forward at half the benchmark batch 0.239 -> 0.218 ms (1 220 TFLOP/s), its data-gradient
+// 0.233 -> 0.215; in-kernel clock 1.9-2.1 GHz, 605-620 cycles per K step for 448 of MFMA issue; SQ MFMA busy 0.52 (conv_igemm_kernel 0.41-0.44).
 #include <stdlib.h>
 #include <algorithm>
 #include <array>
 #include <map>
+#include <type_traits>
 #include "flk_internal.h"
 #include "conv_common.h"
 
@@ -46,6 +53,13 @@ static_assert(PC_NP * 32 >= PC_MAX_HALO, "halo pieces do not cover the image");
 
 // (bit 128: no barriers at all -- racy, WRONG results, every address still valid: what the loop costs without its synchronisation)
 #define PC_BARRIER() do { if (PAB(128)) __builtin_amdgcn_s_barrier(); } while (0)
+
+#ifdef PC_STAMP
+// diagnostic build (-DPC_STAMP, tools/build_variant.py): consumer wave 0 of every workgroup stamps the K loop of its SECOND item -- shader
+// cycles (s_memtime), 100 MHz real time (s_memrealtime), K steps -- into a buffer nothing else reads; flk_pc_stamps_read copies it out.
+// In-kernel clock = cycles / realtime x 100 MHz; cycles per step against the 512 (NI = 8) of MFMA issue.
+__device__ unsigned long long pc_stamps[512][4];
+#endif
 
 struct PcKP {
   ConvKP m[PC_MAX_MEMBERS];          // members of the launch (a grouped launch: Branch_1 and Branch_2 of an Inception block)
@@ -236,6 +250,9 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
         for (int i = 0; i < NI; ++i) bq[i] = PAB(32) ? *(const frag*)(smem + (hb + rowpos[i])) : frag{};
       }
       const int nslab = p.nslab;
+#ifdef PC_STAMP
+      const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 1
       for (int sl = 0; sl < nslab; ++sl) {
         const int img = ((gslab + sl) & 1) * halo_bytes;
@@ -255,6 +272,12 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
           step(a2, a0, hb + 2 * wh16 + 32, nb9);
         }
       }
+#ifdef PC_STAMP
+      if (wave == 0 && lane == 0 && nitem == 1 && blockIdx.x < 512) {
+        pc_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0; pc_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        pc_stamps[blockIdx.x][2] = (unsigned long long)(nslab * PC_TAPS); pc_stamps[blockIdx.x][3] = (unsigned long long)NI;
+      }
+#endif
       gslab += p.nslab;
 
       // ---- epilogue: lane = position m of fragment i, lane group q owns EPL channels of each of the two 32-channel store groups.  The arithmetic is
@@ -276,16 +299,16 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
         const bool ok = r < p.rows && ot0 + rt < p.To && oh0 + rh < p.Ho && ow0 + rw < p.Wo;
         return ok ? obase + pc_mul24(rt, ohw) + pc_mul24(rh, p.OW) + rw : -1;
       };
-      if (!PAB(16)) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-          for (int f = 0; f < NFW; ++f) asm volatile("" :: "v"(acc[f][i]));
-      } else if (hs && hbias && p.relu && !hadd && !hmask) {
-        // forward: relu(acc * scale + bias).  Scale and bias of the item's 64 channels were brought into LDS by the weight-streaming waves with the
-        // item's first weights (a global load here would expose an L2 round trip per item with the matrix pipe idle)
-        float4 sc[NG][2], bi[NG][2];
-        {
+      // one straight-line form per feature set (compile-time flags; chosen once per item), rows in batches: the add / mask operands of a
+      // batch are all requested before the first is used (row by row, behind the branch that skips rows outside the tensor, every row paid its
+      // own memory round trip)
+      auto epi = [&](auto HS, auto ADD, auto RELU, auto MASK) {
+        constexpr bool kHS = decltype(HS)::value, kADD = decltype(ADD)::value, kRELU = decltype(RELU)::value, kMASK = decltype(MASK)::value;
+        constexpr int HALF = kADD && kMASK ? 2 : kADD || kMASK ? 4 : NI;      // rows per batch: its add / mask operands are in flight together
+        // scale / bias of the lane's 16 channels: brought into LDS by the weight-streaming waves with the item's first weights (a global load
+        // here would expose an L2 round trip per item with the matrix pipe idle)
+        float4 sc[kHS ? NG : 1][2], bi[kHS ? NG : 1][2];
+        if constexpr (kHS) {
           const char* const sa = sbarea + (nitem & 1) * 2048 + q * EPL * 4;
 #pragma unroll
           for (int g = 0; g < NG; ++g)
@@ -296,57 +319,83 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int orow = out_row(i);
-          if (orow < 0) continue;
-          char* const dst = p.out + ((size_t)(unsigned)orow * p.out_ld + p.out_coff + cbase) * 2;
+        for (int i0 = 0; i0 < NI; i0 += HALF) {
+          int orow[HALF];
+          uint4 av[kADD ? HALF : 1][NG], mv[kMASK ? HALF : 1][NG];
 #pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            if (cbase + g * 4 * EPL >= p.cout) continue;
-            float v[EPL];
+          for (int u = 0; u < HALF; ++u) {
+            if (i0 + u >= NI) continue;
+            orow[u] = out_row(i0 + u);
+            const size_t orw = (size_t)(unsigned)(orow[u] < 0 ? 0 : orow[u]);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-              const float scv = e < 4 ? (&sc[g][0].x)[e] : (&sc[g][1].x)[e - 4], biv = e < 4 ? (&bi[g][0].x)[e] : (&bi[g][1].x)[e - 4];
-              v[e] = fmaxf(epi_scale_bias(acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3], scv, biv, true, true), 0.f);
+            for (int g = 0; g < NG; ++g) {
+              const int go = cbase + g * 4 * EPL < p.cout ? g * 4 * EPL * 2 : 0;
+              if constexpr (kADD) av[u][g] = pc_ld16(p.add + (orw * p.add_ld + p.add_coff + cbase) * 2 + go);
+              if constexpr (kMASK) mv[u][g] = pc_ld16(p.mask + (orw * p.mask_ld + p.mask_coff + cbase) * 2 + go);
             }
-            pc_st16(dst + g * 4 * EPL * 2, PR::from_f32(v));
+          }
+#pragma unroll
+          for (int u = 0; u < HALF; ++u) {
+            if (i0 + u >= NI) continue;
+            const int i = i0 + u;
+            if (orow[u] < 0) continue;
+            char* const dst = p.out + ((size_t)(unsigned)orow[u] * p.out_ld + p.out_coff + cbase) * 2;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+              if (cbase + g * 4 * EPL >= p.cout) continue;
+              float v[EPL], t[EPL];
+#pragma unroll
+              for (int e = 0; e < EPL; ++e) {
+                v[e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
+                if constexpr (kHS) {
+                  const float scv = e < 4 ? (&sc[g][0].x)[e] : (&sc[g][1].x)[e - 4], biv = e < 4 ? (&bi[g][0].x)[e] : (&bi[g][1].x)[e - 4];
+                  v[e] = epi_scale_bias(v[e], scv, biv, true, true);
+                }
+              }
+              if constexpr (kADD) {
+                PR::to_f32(av[u][g], t);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v[e] += t[e];
+              }
+              if constexpr (kRELU) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v[e] = fmaxf(v[e], 0.f);
+              }
+              if constexpr (kMASK) {
+                PR::to_f32(mv[u][g], t);
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) v[e] = t[e] > 0.f ? v[e] : 0.f;
+              }
+              pc_st16(dst + g * 4 * EPL * 2, PR::from_f32(v));
+            }
           }
         }
-      } else if (!hs && !hbias && !p.relu && !hadd && hmask) {
-        // data-gradient: acc where the layer's input was positive.  All mask rows are requested before the first is used (row by row, behind the
-        // branch that skips rows outside the tensor, every row paid its own memory round trip)
-        int orow[NI];
-        uint4 mv[NI][NG];
+      };
+      typedef std::true_type Y;
+      typedef std::false_type N;
+      const bool relu = p.relu != 0, hsb = hs && hbias;
+      if (!PAB(16)) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          orow[i] = out_row(i);
-          const char* const msk = p.mask + ((size_t)(unsigned)(orow[i] < 0 ? 0 : orow[i]) * p.mask_ld + p.mask_coff + cbase) * 2;
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int g = 0; g < NG; ++g) mv[i][g] = pc_ld16(msk + (cbase + g * 4 * EPL < p.cout ? g * 4 * EPL * 2 : 0));
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          if (orow[i] < 0) continue;
-          char* const dst = p.out + ((size_t)(unsigned)orow[i] * p.out_ld + p.out_coff + cbase) * 2;
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-            if (cbase + g * 4 * EPL >= p.cout) continue;
-            float v[EPL], a[EPL];
-            PR::to_f32(mv[i][g], a);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) v[e] = a[e] > 0.f ? acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3] : 0.f;
-            pc_st16(dst + g * 4 * EPL * 2, PR::from_f32(v));
-          }
-        }
-      } else {
-        float4 sc[NG][2], bi[NG][2];
+          for (int f = 0; f < NFW; ++f) asm volatile("" :: "v"(acc[f][i]));
+      } else if (hsb && !hadd && relu && !hmask) epi(Y{}, N{}, Y{}, N{});       // Unit3D / conv + BN + ReLU forward
+      else if (hsb && hadd && relu && !hmask) epi(Y{}, Y{}, Y{}, N{});          // ... with the block's residual (VideoResNet conv2)
+      else if (hsb && !hadd && !relu && !hmask) epi(Y{}, N{}, N{}, N{});
+      else if (!hs && !hbias && !hadd && !relu && hmask) epi(N{}, N{}, N{}, Y{});      // data-gradient: ReLU mask of the layer's input
+      else if (!hs && !hbias && hadd && !relu && hmask) epi(N{}, Y{}, N{}, Y{});       // ... accumulated onto the shortcut's gradient
+      else if (!hs && !hbias && hadd && !relu && !hmask) epi(N{}, Y{}, N{}, N{});
+      else if (!hs && !hbias && !hadd && !relu && !hmask) epi(N{}, N{}, N{}, N{});
+      else {
+        // anything else (scale without bias, ...): conv_igemm_kernel's general epilogue
+        float4 sg[NG][2], bg[NG][2];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           const int c = cbase + g * 4 * EPL, cc = c < p.cout ? c : 0;
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            sc[g][h] = hs ? *(const float4*)(p.scale + cc + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);
-            bi[g][h] = hbias ? *(const float4*)(p.bias + cc + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sg[g][h] = hs ? *(const float4*)(p.scale + cc + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);
+            bg[g][h] = hbias ? *(const float4*)(p.bias + cc + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
 #pragma unroll
@@ -358,7 +407,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
           for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
-          finish_store_row_pre<bf16_t, NG>(p, (size_t)(unsigned)orow, cbase, v, sc, bi);
+          finish_store_row_pre<bf16_t, NG>(p, (size_t)(unsigned)orow, cbase, v, sg, bg);
         }
       }
       ++nitem;
@@ -720,7 +769,7 @@ static int pc_cus() {
 // data-gradient at half the batch: 784 tiles of 8x8x8 on 256 workgroups are FOUR rounds of 162 steps for 3.06 rounds of work; 896 tiles of
 // 8x8x7 are four rounds of seven eighths the length).  Candidates: boxes of at most 512, 448 and 384 rows; the cheapest busiest workgroup wins.
 // *eff = the launch's useful share of (busiest workgroup x workgroups) under that model.
-static int pc_plan(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int dtype, PcKP& best, int& ni_best, double* eff) {
+static int pc_plan(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int dtype, PcKP& best, int& ni_best, double* eff, double* steps = nullptr) {
   FLK_REQUIRE(a && w && n >= 1 && n <= PC_MAX_MEMBERS, "flk_conv3d_pc: 1..%d members", PC_MAX_MEMBERS);
   for (int i = 0; i < n; ++i) {
     FLK_REQUIRE(a[i] && w[i] && w[i]->dev, "flk_conv3d_pc: null member %d", i);
@@ -782,6 +831,7 @@ static int pc_plan(const flk_conv_args* const* a, const flk_conv_weights* const*
     if (busiest < best_cost) {
       best_cost = busiest; best = kp; ni_best = ni_max;
       if (eff) *eff = useful / (busiest * kp.slots);
+      if (steps) *steps = busiest;
     }
   }
   if (hit == cache.end()) {
@@ -828,9 +878,11 @@ extern "C" int flk_conv3d_pc(const flk_conv_args* const* a, const flk_conv_weigh
   return FLK_OK;
 }
 
-// Should a plan send these convolutions to flk_conv3d_pc?  Eligible members, at least two rounds of items per workgroup, and a modelled
-// efficiency (pc_plan) of at least 0.8: the persistent kernel pays where it keeps the chip full -- the large layers at the benchmark batch --
-// and loses to conv_igemm_kernel's small workgroups where a launch is a round or two (batch 1).
+// Should a plan send these convolutions to flk_conv3d_pc?  Eligible members, a modelled efficiency (pc_plan) of at least 0.8 and a busiest
+// workgroup of at least PC_MIN_STEPS full K steps (~0.33 us each): the persistent kernel pays where it keeps the chip full for a while -- the
+// large layers at the benchmark batch -- and loses to conv_igemm_kernel's small workgroups where a launch is a round or two: one 160-KB
+// workgroup per CU cannot start beside the previous kernel's tail, and its first halo image and weights are staged with nothing to hide
+// them (measured: Conv3d_2c at batch 1, ~160 steps, +0.05 ms per launch; FLK_PC_MIN_STEPS overrides the bound for A/B runs).
 extern "C" int flk_conv3d_pc_worthwhile(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int dtype) {
   if (!a || !w || n < 1 || n > PC_MAX_MEMBERS) return 0;
   for (int i = 0; i < n; ++i)
@@ -838,8 +890,36 @@ extern "C" int flk_conv3d_pc_worthwhile(const flk_conv_args* const* a, const flk
   PcKP kp{};
   int ni = 8;
   double eff = 0;
-  if (pc_plan(a, w, n, dtype, kp, ni, &eff) != FLK_OK) return 0;
-  return kp.per_xcd >= 2 * kp.slots && eff >= 0.8;
+  double steps = 0;
+  if (pc_plan(a, w, n, dtype, kp, ni, &eff, &steps) != FLK_OK) return 0;
+  static const double min_steps = getenv("FLK_PC_MIN_STEPS") ? atof(getenv("FLK_PC_MIN_STEPS")) : 300.0;
+  return eff >= 0.8 && steps >= min_steps;
+}
+
+// The launch flk_conv3d_pc would make for these geometries, without weights or a device (plan builders, tests): member 0's tile, the
+// fragments per consumer wave, and the model's two figures -- useful share of (busiest workgroup x workgroups), K steps of the busiest
+// workgroup.  Returns what flk_conv3d_pc_worthwhile decides (1 / 0), or a negative FLK_E* code.
+extern "C" int flk_conv3d_pc_query(const flk_conv_args* const* a, int n, int dtype, int* tile3, int* ni_out, double* eff_out, double* steps_out) {
+  FLK_REQUIRE(a && n >= 1 && n <= PC_MAX_MEMBERS, "flk_conv3d_pc_query: 1..%d members", PC_MAX_MEMBERS);
+  flk_conv_weights fw[PC_MAX_MEMBERS];
+  const flk_conv_weights* wp[PC_MAX_MEMBERS];
+  for (int i = 0; i < n; ++i) {
+    FLK_REQUIRE(a[i], "flk_conv3d_pc_query: null member %d", i);
+    flk_conv_weights& w = fw[i];
+    w.dev = (void*)1; w.kt = a[i]->kt; w.kh = a[i]->kh; w.kw = a[i]->kw; w.cin = a[i]->cin; w.cout = a[i]->cout; w.dtype = dtype; w.nf = 4;
+    w.nslab = (a[i]->cin + 31) / 32; w.ntaps = a[i]->kt * a[i]->kh * a[i]->kw; w.cout_frags = ((a[i]->cout + 15) / 16 + 3) / 4 * 4; w.nslab1 = w.nslab;
+    wp[i] = &w;
+    if (const char* why = pc_ineligible(a[i], &w, dtype)) { flk_set_error("flk_conv3d_pc_query: member %d: %s", i, why); return FLK_EINVAL; }
+  }
+  PcKP kp{};
+  int ni = 8;
+  double eff = 0, steps = 0;
+  if (int rc = pc_plan(a, wp, n, dtype, kp, ni, &eff, &steps)) return rc;
+  if (tile3) { tile3[0] = kp.m[0].Tt; tile3[1] = kp.m[0].Ht; tile3[2] = kp.m[0].Wt; }
+  if (ni_out) *ni_out = ni;
+  if (eff_out) *eff_out = eff;
+  if (steps_out) *steps_out = steps;
+  return flk_conv3d_pc_worthwhile(a, wp, n, dtype);
 }
 
 // does flk_conv3d_pc take this convolution (0) -- or why not (a static string; plan builders decide packing and launch form with it)
@@ -847,3 +927,11 @@ extern "C" const char* flk_conv3d_pc_why_not(const flk_conv_args* a, const flk_c
   if (!a || !w) return "null argument";
   return pc_ineligible(a, w, dtype);
 }
+
+#ifdef PC_STAMP
+extern "C" int flk_pc_stamps_read(unsigned long long* out, int n) {
+  FLK_CHECK_HIP(hipDeviceSynchronize());
+  FLK_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_stamps), sizeof(unsigned long long) * 4 * (n < 512 ? n : 512)));
+  return FLK_OK;
+}
+#endif

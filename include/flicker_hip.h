@@ -129,6 +129,9 @@ const char* flk_conv3d_pc_why_not(const flk_conv_args* a, const flk_conv_weights
 /* 1 when a plan should send these convolutions to flk_conv3d_pc: eligible, at least two rounds of items per workgroup and a modelled
  * efficiency >= 0.8 (the large layers at the benchmark batch); flk_conv3d and flk_conv3d_group route by it themselves */
 int flk_conv3d_pc_worthwhile(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int dtype);
+/* the same decision from the geometries alone (no weights, no device), with the launch behind it: member 0's tile (tile3[3] = Tt, Ht, Wt), the
+ * position fragments per consumer wave, the modelled efficiency and the K steps of the busiest workgroup; returns 1 / 0 or a negative FLK_E* */
+int flk_conv3d_pc_query(const flk_conv_args* const* a, int n, int dtype, int* tile3, int* ni, double* eff, double* steps);
 /* the validation and planning of flk_conv3d_group without the launch (FLK_OK / the error the launch would return): plan builders call it
  * once per group when the plan is built */
 int flk_conv3d_group_check(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int nfw, int ring, int dtype);

@@ -95,3 +95,43 @@ def test_group_launch_validation_and_layout_query_without_gpu(lib):
     assert lib.flk_conv3d_group(ap, wp, 1, 3, 0, _lib.FLK_BF16, None) == -1 and b"fragments" in lib.flk_last_error()
     assert lib.flk_conv3d_group(ap, wp, 1, 4, 0, _lib.FLK_F32, None) == -1
     assert lib.flk_conv3d_group(ap, wp, 1, 4, 0, _lib.FLK_BF16, None) == -1 and b"null member" in lib.flk_last_error()
+
+
+def test_producer_consumer_routing_model_without_gpu(lib):
+    """flk_conv3d_pc_query: what flk_conv3d / flk_conv3d_group send to the persistent producer / consumer kernel (csrc/conv_pc.hip), decided on
+    the host from the geometry.  Conv3d_2c_3x3 (i3d.py:183-186) at half the benchmark batch: forward 64 -> 192 on 8x7x8 boxes (448 rows) -- 11 rounds of
+    seven eighths the length beat 10 rounds of 8x8x8 -- and its data-gradient 192 -> 64 likewise (3.5 -> 4 rounds instead of 3.06 -> 4); the
+    same layer at batch 1 stays on conv_igemm_kernel (a round or two of items: the persistent launch cannot hide its start-up), as do strided
+    and non-3x3x3 convolutions (refused with the reason)."""
+    import ctypes as C
+    from flickering_adversarial_video_amd import _lib
+
+    def conv(B, T, H, W, cin, cout, k=3, stride=1):
+        a = _lib.ConvArgs()
+        a.B, a.Ti, a.Hi, a.Wi = B, T, H, W
+        a.To, a.Ho, a.Wo, a.OT, a.OH, a.OW = T // stride, H // stride, W // stride, T // stride, H // stride, W // stride
+        a.kt = a.kh = a.kw = k
+        a.st = a.sh = a.sw = stride
+        a.ost = a.osh = a.osw = 1
+        a.pt = a.ph = a.pw = (k - 1) // 2
+        a.cin, a.cout, a.in_ld, a.out_ld = cin, cout, cin, cout
+        return a
+
+    def query(*members):
+        ap = (C.POINTER(_lib.ConvArgs) * len(members))(*[C.pointer(m) for m in members])
+        tile, ni, eff, steps = (C.c_int * 3)(), C.c_int(), C.c_double(), C.c_double()
+        rc = lib.flk_conv3d_pc_query(ap, len(members), _lib.FLK_BF16, tile, C.byref(ni), C.byref(eff), C.byref(steps))
+        return rc, tuple(tile), ni.value, eff.value, steps.value
+
+    rc, tile, ni, eff, steps = query(conv(4, 32, 56, 56, 64, 192))
+    assert rc == 1 and tile == (8, 7, 8) and ni == 7 and eff > 0.8 and 500 < steps < 700, (rc, tile, ni, eff, steps)
+    rc, tile, ni, eff, steps = query(conv(4, 32, 56, 56, 192, 64))
+    assert rc == 1 and tile == (8, 7, 8) and ni == 7, (rc, tile, ni, eff, steps)
+    rc, tile, ni, eff, steps = query(conv(1, 32, 56, 56, 64, 192))
+    assert rc == 0 and steps < 300, (rc, tile, ni, eff, steps)                      # batch 1: too short a launch
+    rc, tile, ni, eff, steps = query(conv(8, 32, 28, 28, 128, 192), conv(8, 32, 28, 28, 32, 96))      # Mixed_3c Branch_1 + Branch_2 (i3d.py:229-238)
+    assert rc == 1 and tile[0] * tile[1] * tile[2] == 448 and 28 % tile[1] == 0 and 28 % tile[2] == 0 and ni == 7 and eff > 0.8, (rc, tile, ni, eff, steps)
+    rc = query(conv(8, 16, 14, 14, 96, 208))[0]
+    assert rc == 0                                                                   # Mixed_4*: a single round of items
+    assert query(conv(4, 32, 56, 56, 64, 192, k=1))[0] == -1 and b"3x3x3" in lib.flk_last_error()
+    assert query(conv(4, 32, 56, 56, 64, 192, stride=2))[0] == -1 and b"stride" in lib.flk_last_error()

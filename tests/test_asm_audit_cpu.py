@@ -32,6 +32,21 @@ def test_no_compiler_access_to_in_flight_registers():
     assert "conv_igemm_group_kernel" in r.stdout, "the grouped ring kernels issue asm loads too"
 
 
+def test_producer_consumer_kernel_halo_loads_are_audited():
+    """csrc/conv_pc.hip: the halo-staging waves keep 33 asm loads in flight across up to six barriers each; the schedule is straight-line code
+    from every request to its commit so that neither hipcc's liveness nor this audit can find a path around a wait.  Also its timing-only
+    variants that change the staging / loop structure (-DPC_ABLATE bits 4 and 128, -DPC_STAMP)."""
+    from concurrent.futures import ThreadPoolExecutor
+    pc = os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_pc.hip")
+    runs = [[], ["-DPC_ABLATE=128"], ["-DPC_STAMP"]]
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        res = list(ex.map(lambda f: subprocess.run([sys.executable, AUDIT, pc] + f, capture_output=True, text=True, timeout=900), runs))
+    for f, r in zip(runs, res):
+        assert r.returncode == 0, str(f) + "\n" + r.stdout[-3000:] + r.stderr[-2000:]
+        assert "2 kernels with asm loads audited, 0 with violations" in r.stdout, str(f) + r.stdout[-500:]
+        assert "conv_pc_kernelILi7E" in r.stdout and "66 asm loads" in r.stdout
+
+
 def test_audit_flags_a_minimal_hazard():
     """tests/fixtures/asm_inflight_fixture.hip: one kernel that touches the destination only behind its wait (must pass), one that
     lets hipcc copy the register while the load is in flight (must be flagged) -- the audit is not vacuous"""
