@@ -12,7 +12,7 @@ def agg(path, counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"]
-        key = next((k for k in ("conv_igemm_group_kernel", "conv_igemm_kernel", "conv1x1_dma_kernel", "stem_fwd_u8_kernel", "stem_delta_grad_kernel", "stem_mask_kernel") if k in n), None) \
+        key = next((k for k in ("conv_pc_kernel", "conv_igemm_group_kernel", "conv_igemm_kernel", "conv1x1_dma_kernel", "conv_t3_dma_kernel", "stem_fwd_u8_kernel", "stem_delta_grad_kernel", "stem_mask_kernel") if k in n), None) \
             or n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
         d[key][0] += 1
         d[key][1] += float(r["Counter_Value"])
@@ -27,5 +27,7 @@ for k in sorted(f, key=lambda k: -f[k][1]):
     rd, wr = 2 * f[k][1] * 1024, w.get(k, [0, 0.0])[1] * 1024
     out["kernels"][k] = {"launches": launches, "read_bytes": rd, "write_bytes": wr, "bytes_per_launch": (rd + wr) / max(launches, 1)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-c = out["kernels"]["conv_igemm_kernel"]
-print("conv_igemm_kernel:", c["launches"], "launches,", round(c["bytes_per_launch"] / 1e6, 1), "MB per launch")
+for kn in ("conv_pc_kernel", "conv_igemm_kernel", "conv_igemm_group_kernel"):
+    if kn in out["kernels"]:
+        c = out["kernels"][kn]
+        print(kn + ":", c["launches"], "launches,", round(c["bytes_per_launch"] / 1e6, 1), "MB per launch")
