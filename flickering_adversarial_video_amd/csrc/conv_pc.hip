@@ -44,7 +44,7 @@ static_assert(PC_R >= PC_D + 2, "ring too short for the look-ahead");
 static_assert(PC_NP * 32 >= PC_MAX_HALO, "halo pieces do not cover the image");
 
 // timing experiments (-DPC_ABLATE=bits builds only, tools/build_variant.py --src conv_pc.hip; WRONG results): 1 no MFMAs, 2 consumers at priority 0,
-// 4 no halo staging, 8 no weight DMA, 16 no epilogue stores, 32 no position-fragment reads, 64 no weight-fragment reads.  The product build compiles every PAB() to true.
+// 4 no halo staging, 8 no weight DMA, 16 no epilogue stores, 32 no position-fragment reads, 64 no weight-fragment reads, 256 no staggered start.  The product build compiles every PAB() to true.
 #ifdef PC_ABLATE
 #define PAB(bit) (!((PC_ABLATE) & (bit)))
 #else
@@ -58,7 +58,7 @@ static_assert(PC_NP * 32 >= PC_MAX_HALO, "halo pieces do not cover the image");
 // diagnostic build (-DPC_STAMP, tools/build_variant.py): consumer wave 0 of every workgroup stamps the K loop of its SECOND item -- shader
 // cycles (s_memtime), 100 MHz real time (s_memrealtime), K steps -- into a buffer nothing else reads; flk_pc_stamps_read copies it out.
 // In-kernel clock = cycles / realtime x 100 MHz; cycles per step against the 512 (NI = 8) of MFMA issue.
-__device__ unsigned long long pc_stamps[512][4];
+__device__ unsigned long long pc_stamps[512][8];
 #endif
 
 struct PcKP {
@@ -151,6 +151,9 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       // scalar load + s_waitcnt of its own, and hipcc sinks those loads into the innermost conditional blocks instead of hoisting them: the
       // first build of this kernel spent 28 us per item in its epilogue and 37 us per slab in the halo staging that way (4 x the whole
       // conv_igemm_kernel launch).  pc_u / pc_uniform (v_readfirstlane) make each copy a value the compiler cannot re-materialise from memory.
+#ifdef PC_STAMP
+      const unsigned long long sti = __builtin_amdgcn_s_memtime();
+#endif
       const ConvKP& pk = kp.m[it.mi];
       ConvKP p{};
       p.rows = pc_u(pk.rows); p.FP = pc_u(pk.FP); p.Wh = pc_u(pk.Wh); p.plane_b = pc_u(pk.plane_b); p.tfast = pc_u(pk.tfast);
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int fp16 = p.FP * 16, wh16 = p.Wh * 16;
+      const int nsteps_item = p.nslab * PC_TAPS;
       // Registers: 128 accumulators; the weight fragments in THREE rotating sets (a step's four are used by all its MFMAs; the next step's are
       // read right behind the barrier that publishes them; three sets because the loop body below is nine steps long -- no copies, no
       // renaming at the back edge); the position fragments in ONE -- the MFMAs run position-fragment-major, and fragment i of the next step
@@ -241,6 +245,20 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       };
       if (first_item) {
         first_item = false;
+        // Workgroups that get one item FEWER than the busiest (the last round is not full) start late, by a different fraction of an item
+        // each.  All workgroups of a launch run the same items in lock-step, so their epilogues -- 57 KB of stores per CU -- hit the memory
+        // system together: measured 5 200 cycles per epilogue = 14.7 MB per round at ~6 TB/s, the chip's write bandwidth, with the matrix
+        // pipes idle (in-kernel stamps, -DPC_STAMP); a workgroup alone stores its tile several times faster.  The late starters' epilogues
+        // fall between the others'; their slack pays for it (they would have idled at the end).
+        {
+          const int nmax = (kp.per_xcd + kp.slots - 1) / kp.slots, rem = kp.per_xcd - (nmax - 1) * kp.slots;      // slots [0, rem) run nmax items
+          if (PAB(256) && slot >= rem && nmax > 1) {
+            const int late = kp.slots - rem, idx = slot - rem;
+            const int item_cycles = nsteps_item * 620 + 6000;
+            const int delay = (int)(((long long)item_cycles * (2 * idx + 1)) / (2 * late));
+            for (int c = 0; c < delay; c += 1024) __builtin_amdgcn_s_sleep(16);
+          }
+        }
         PC_BARRIER();                     // b_0: the first weights and the first halo image of this workgroup
         read_a(a0);
       }
@@ -273,9 +291,11 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
         }
       }
 #ifdef PC_STAMP
+      const unsigned long long ste = __builtin_amdgcn_s_memtime();
       if (wave == 0 && lane == 0 && nitem == 1 && blockIdx.x < 512) {
-        pc_stamps[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - st0; pc_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
+        pc_stamps[blockIdx.x][0] = ste - st0; pc_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
         pc_stamps[blockIdx.x][2] = (unsigned long long)(nslab * PC_TAPS); pc_stamps[blockIdx.x][3] = (unsigned long long)NI;
+        pc_stamps[blockIdx.x][4] = st0 - sti;             // item set-up: parameter copy, row decode, first position fragments
       }
 #endif
       gslab += p.nslab;
@@ -410,6 +430,11 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
           finish_store_row_pre<bf16_t, NG>(p, (size_t)(unsigned)orow, cbase, v, sg, bg);
         }
       }
+#ifdef PC_STAMP
+      if (wave == 0 && lane == 0 && nitem == 1 && blockIdx.x < 512) pc_stamps[blockIdx.x][5] = __builtin_amdgcn_s_memtime() - ste;      // the epilogue
+      if (wave == 0 && lane == 0 && nitem == 2 && blockIdx.x < 512) pc_stamps[blockIdx.x][6] = sti;                                      // (item 2's start: against item 1's end below)
+      if (wave == 0 && lane == 0 && nitem == 1 && blockIdx.x < 512) pc_stamps[blockIdx.x][7] = __builtin_amdgcn_s_memtime();
+#endif
       ++nitem;
     }
     return;
@@ -931,7 +956,7 @@ extern "C" const char* flk_conv3d_pc_why_not(const flk_conv_args* a, const flk_c
 #ifdef PC_STAMP
 extern "C" int flk_pc_stamps_read(unsigned long long* out, int n) {
   FLK_CHECK_HIP(hipDeviceSynchronize());
-  FLK_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_stamps), sizeof(unsigned long long) * 4 * (n < 512 ? n : 512)));
+  FLK_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(pc_stamps), sizeof(unsigned long long) * 8 * (n < 512 ? n : 512)));
   return FLK_OK;
 }
 #endif

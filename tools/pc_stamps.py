@@ -13,11 +13,12 @@ epi = dict(mask=torch.randn(B, T, H, W, co, device="cuda").to(torch.bfloat16)) i
 pad = (1, 1, 1)
 for _ in range(200): ops.conv3d_pc([(x, pw, dict(pad=pad, out_grid=(T, H, W), **epi))])      # (long enough for the clock to settle)
 lib = C.CDLL(_lib.LIB_PATH)
-buf = (C.c_ulonglong * (4 * 256))()
+buf = (C.c_ulonglong * (8 * 256))()
 assert lib.flk_pc_stamps_read(buf, 256) == 0
-a = np.array(buf[:], dtype=np.float64).reshape(256, 4)
+a = np.array(buf[:], dtype=np.float64).reshape(256, 8)
 a = a[a[:, 2] > 0]
 clk = a[:, 0] / a[:, 1] * 0.1      # GHz
 cps = a[:, 0] / a[:, 2]
 print(f"{len(a)} workgroups: in-kernel clock median {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f}); cycles per K step median {np.median(cps):.0f} "
       f"(min {cps.min():.0f}, max {cps.max():.0f}); NI {int(a[0, 3])}: {int(a[0, 3]) * 64} cycles of MFMA issue per step; ns per step {np.median(a[:, 1] * 10 / a[:, 2]):.0f}")
+print(f"per item (cycles, medians): set-up {np.median(a[:, 4]):.0f}, K loop {np.median(a[:, 0]):.0f}, epilogue {np.median(a[:, 5]):.0f}, item end -> next item's start {np.median(a[:, 6] - a[:, 7]):.0f}")
