@@ -44,7 +44,8 @@ static_assert(PC_R >= PC_D + 2, "ring too short for the look-ahead");
 static_assert(PC_NP * 32 >= PC_MAX_HALO, "halo pieces do not cover the image");
 
 // timing experiments (-DPC_ABLATE=bits builds only, tools/build_variant.py --src conv_pc.hip; WRONG results): 1 no MFMAs, 2 consumers at priority 0,
-// 4 no halo staging, 8 no weight DMA, 16 no epilogue stores, 32 no position-fragment reads, 64 no weight-fragment reads, 256 no staggered start.  The product build compiles every PAB() to true.
+// 4 no halo staging, 8 no weight DMA, 16 no epilogue stores, 32 no position-fragment reads, 64 no weight-fragment reads, 256 no staggered start,
+// 512 no halo loads (the staging waves still compute and write), 1024 no halo writes (they still load).  The product build compiles every PAB() to true.
 #ifdef PC_ABLATE
 #define PAB(bit) (!((PC_ABLATE) & (bit)))
 #else
@@ -512,11 +513,11 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     const int ht = tid - 384;                             // 0 .. 127
     const int ch = ht & 3, hp0 = ht >> 2;                 // this thread's 16-byte channel chunk; its first halo position (then every 32nd)
     // the slab being staged: everything the staging needs, in registers (see the consumers' note on kp.m[mi].field)
-    struct Slab { int b, it0, ih0, iw0, s, img, P, FP, cells, Wh, Ti, Hi, Wi, in_ld, cin, plane_b; unsigned m_HW, m_Wh; const char* base; };
+    struct Slab { int b, it0, ih0, iw0, s, img, P, FP, cells, Wh, Ti, Hi, Wi, in_ld, cin, plane_b, key; unsigned m_HW, m_Wh; const char* base; };
     auto slab_of = [&](const PcIter& c, int s, int img) {
       const ConvKP& p = kp.m[c.mi];
       Slab z{};
-      z.s = s; z.img = img;
+      z.s = s; z.img = img; z.key = (c.mi << 24) | c.ptile;      // (position tiles < 2^24: the host checks the positions)
       z.P = pc_u(p.P); z.FP = pc_u(p.FP); z.Wh = pc_u(p.Wh); z.cells = pc_u(p.Hh) * z.Wh; z.Ti = pc_u(p.Ti); z.Hi = pc_u(p.Hi); z.Wi = pc_u(p.Wi);
       z.in_ld = pc_u(p.in_ld); z.cin = pc_u(p.cin); z.plane_b = pc_u(p.plane_b); z.m_HW = (unsigned)pc_u((int)p.m_HW); z.m_Wh = (unsigned)pc_u((int)p.m_Wh);
       z.base = pc_uniform(p.in + (size_t)(p.in_coff + s * 32) * 2);
@@ -544,26 +545,38 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     // on a 0.23 ms launch.
     pc_u32x4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {}, v7 = {}, v8 = {}, v9 = {}, v10 = {}, v11 = {}, v12 = {}, v13 = {}, v14 = {}, v15 = {}, v16 = {}, v17 = {}, v18 = {}, v19 = {}, v20 = {}, v21 = {}, v22 = {}, v23 = {}, v24 = {}, v25 = {}, v26 = {}, v27 = {}, v28 = {}, v29 = {}, v30 = {}, v31 = {}, v32 = {};
     int g0 = -2, g1 = -2, g2 = -2, g3 = -2, g4 = -2, g5 = -2, g6 = -2, g7 = -2, g8 = -2, g9 = -2, g10 = -2, g11 = -2, g12 = -2, g13 = -2, g14 = -2, g15 = -2, g16 = -2, g17 = -2, g18 = -2, g19 = -2, g20 = -2, g21 = -2, g22 = -2, g23 = -2, g24 = -2, g25 = -2, g26 = -2, g27 = -2, g28 = -2, g29 = -2, g30 = -2, g31 = -2, g32 = -2;
+    // (the lane's byte offset of piece n inside a slab of the position tile: see PC_REQ)
+    unsigned o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u, o4 = 0u, o5 = 0u, o6 = 0u, o7 = 0u, o8 = 0u, o9 = 0u, o10 = 0u, o11 = 0u, o12 = 0u, o13 = 0u, o14 = 0u, o15 = 0u, o16 = 0u, o17 = 0u, o18 = 0u, o19 = 0u, o20 = 0u, o21 = 0u, o22 = 0u, o23 = 0u, o24 = 0u, o25 = 0u, o26 = 0u, o27 = 0u, o28 = 0u, o29 = 0u, o30 = 0u, o31 = 0u, o32 = 0u;
     Slab z{};
-    bool chvalid = false;
+    z.key = -1;
+    bool chvalid = false, fresh = true;
     char* dst = nullptr;
     auto begin_slab = [&](const Slab& zn) {
+      fresh = pc_u(zn.key != z.key) != 0;
       z = zn;
       chvalid = z.s * 32 + ch * EPL < z.cin;
       dst = smem + z.img * kp.halo_bytes + plane_off(ch, z.plane_b) + hp0 * 16;
     };
     // request piece n: one unconditional load (position 0 of the tensor for padding and missing slots: always readable, never written to LDS),
-    // SADDR form -- scalar slab base + one 32-bit lane offset
+    // SADDR form -- scalar slab base + one 32-bit lane offset.  Which input position a piece holds depends on the position tile only, not on
+    // the slab or the channel tile: index and byte offset are computed for the FIRST slab staged of a position tile (`fresh`) and kept in
+    // registers for its other slabs and for the channel tiles that follow -- staged afresh per slab (~30 vector instructions per piece, 66
+    // pieces per slab on the two SIMDs these waves share with consumers 2 and 3) the staging cost the launch 13-15 % (-DPC_ABLATE=4).
 #define PC_REQ(n)                                                                                                 \
     if (PAB(4)) {                                                                                                 \
-      g##n = piece_g(z, n);                                                                                       \
-      const unsigned vo = (__umul24((unsigned)((g##n >= 0 && chvalid) ? g##n : 0), (unsigned)z.in_ld) + (unsigned)(ch * EPL)) * 2u; \
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v##n) : "v"(vo), "s"(z.base) : "memory");             \
+      if (fresh) {                                                                                                \
+        g##n = piece_g(z, n);                                                                                     \
+        o##n = (__umul24((unsigned)(g##n >= 0 ? g##n : 0), (unsigned)z.in_ld) + (unsigned)(ch * EPL)) * 2u;        \
+      }                                                                                                           \
+      const unsigned vo = chvalid ? o##n : (unsigned)(ch * EPL) * 2u;                                             \
+      if (PAB(512)) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v##n) : "v"(vo), "s"(z.base) : "memory"); \
+      else asm volatile("" : "=v"(v##n) : "v"(vo));                                                               \
     }
     // commit piece n (behind the counted wait that releases its register): zeros for padding, nothing for a missing slot
 #define PC_PUT(n)                                                                                                 \
     if (PAB(4)) {                                                                                                 \
-      if (g##n != -2) *(pc_u32x4*)(dst + (n) * 512) = (g##n >= 0 && chvalid) ? v##n : pc_u32x4{0u, 0u, 0u, 0u};    \
+      if (!PAB(1024)) asm volatile("" :: "v"(v##n));                                                               \
+      else if (g##n != -2) *(pc_u32x4*)(dst + (n) * 512) = (g##n >= 0 && chvalid) ? v##n : pc_u32x4{0u, 0u, 0u, 0u}; \
     }
     PcIter it{slot, kp.slots, 0, 0, 0};                   // the item being consumed
     if (!it.next(kp, xcd)) return;
