@@ -252,6 +252,12 @@ __device__ static inline void finish_store_row_pre(const ConvKP& p, size_t opos,
 
 // ---- LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 64 lanes x 16 bytes to 1 KiB of contiguous LDS at m0 + 16 * lane ----
 __device__ static inline unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+// (per-lane 64-bit source address)
+__device__ static inline void glds16_v64(const char* src, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_base) : "memory");
+}
 __device__ static inline void glds16(unsigned voff, const char* sbase, unsigned lds_base) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"

@@ -17,8 +17,8 @@
 //     (global_load_lds_dwordx4) into a ring of R = 6 slots, D = 4 steps ahead of the consumers, behind a counted s_waitcnt vmcnt, across
 //     item boundaries; with an item's first weights, the batch-norm scale / bias of its 64 channels;
 //   * waves 6-7 stage the HALO box of the NEXT 32-channel slab (or of the next item's first slab) into the second of two LDS images while the
-//     consumers multiply out of the first: one asm global load per 16-byte piece, two pieces requested per step and committed six steps later
-//     (hand-counted waits; tools/audit_asm_loads.py audits this file too).
+//     consumers multiply out of the first, by LDS-DMA as well: one wave-instruction fills 64 consecutive cells of one chunk plane, every lane
+//     with its own source address (a block of zeros for padding); two per step and wave, nothing in the last third of a slab.
 // One s_barrier per K step, joined by all eight waves, is the only synchronisation: the barrier of step k publishes the weights of step
 // k + 1 (landed: the streaming waves waited for them) and, before a slab's first read, its halo image; it frees the ring slot of step k - 1
 // and, one step into a slab, the image of the slab before it.  Producers arrive early and wait.
@@ -36,12 +36,12 @@
 constexpr int PC_MAX_MEMBERS = 3;
 constexpr int PC_R = 6;             // weight ring slots of 4 KiB (one K step of a 64-channel tile)
 constexpr int PC_D = 4;             // weight look-ahead in K steps; PC_R >= PC_D + 2 (a slot is re-filled two barriers after its step)
-constexpr int PC_MAX_HALO = 1056;   // halo slots per image: 2 x (4 planes x 1056 x 16 B + 64) + 6 x 4 KiB + 4 KiB (scale / bias) = 163 968 B > 160 KiB: the host checks the launch's own image
+constexpr int PC_MAX_HALO = 1024;   // halo slots per image (16 DMA blocks of 64 per chunk plane): 2 x (4 planes x 16 KiB + 64) + 6 x 4 KiB + 4 KiB (scale / bias) = 159 872 B of the 160 KiB
 constexpr int PC_THREADS = 512;
-constexpr int PC_NP = 33;           // halo pieces per thread of the two staging waves (32 positions x 4 chunks each)
+constexpr int PC_NBLK = 16;         // DMA blocks (64 halo positions) per chunk plane
 constexpr int PC_TAPS = 27;
 static_assert(PC_R >= PC_D + 2, "ring too short for the look-ahead");
-static_assert(PC_NP * 32 >= PC_MAX_HALO, "halo pieces do not cover the image");
+static_assert(PC_NBLK * 64 >= PC_MAX_HALO, "halo blocks do not cover the image");
 
 // timing experiments (-DPC_ABLATE=bits builds only, tools/build_variant.py --src conv_pc.hip; WRONG results): 1 no MFMAs, 2 consumers at priority 0,
 // 4 no halo staging, 8 no weight DMA, 16 no epilogue stores, 32 no position-fragment reads, 64 no weight-fragment reads, 256 no staggered start,
@@ -61,6 +61,9 @@ static_assert(PC_NP * 32 >= PC_MAX_HALO, "halo pieces do not cover the image");
 // In-kernel clock = cycles / realtime x 100 MHz; cycles per step against the 512 (NI = 8) of MFMA issue.
 __device__ unsigned long long pc_stamps[512][8];
 #endif
+
+// 16 bytes of zeros in device memory: the source of every halo cell that holds no data
+__device__ __attribute__((aligned(16))) unsigned pc_zero16[4];
 
 struct PcKP {
   ConvKP m[PC_MAX_MEMBERS];          // members of the launch (a grouped launch: Branch_1 and Branch_2 of an Inception block)
@@ -510,17 +513,24 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
 
   // =================================================== halo staging ===================================================
   {
-    const int ht = tid - 384;                             // 0 .. 127
-    const int ch = ht & 3, hp0 = ht >> 2;                 // this thread's 16-byte channel chunk; its first halo position (then every 32nd)
-    // the slab being staged: everything the staging needs, in registers (see the consumers' note on kp.m[mi].field)
-    struct Slab { int b, it0, ih0, iw0, s, img, P, FP, cells, Wh, Ti, Hi, Wi, in_ld, cin, plane_b, key; unsigned m_HW, m_Wh; const char* base; };
+    // LDS-DMA: one wave-instruction writes 64 consecutive 16-byte cells of ONE chunk plane -- halo positions 64 j .. 64 j + 63, each lane
+    // with its own 64-bit source address (the position's 16 bytes of the slab's chunk, or a block of zeros for padding, for the cells
+    // between two frames and for chunks past cin).  Wave 6 fills planes 0 and 1, wave 7 planes 2 and 3: block j of both planes at step
+    // j + 1 of the slab before (2 DMAs and ~10 vector instructions per step; nothing after step 16).  The first form of this role moved
+    // every piece through registers (asm load -> counted wait -> zero select -> ds_write_b128, 66 pieces per slab and wave): with the
+    // index arithmetic cached per position tile that staging still cost the launch 16 % (-DPC_ABLATE=4: 0.218 -> 0.182 ms; loads alone
+    // 6 %, the selects and LDS writes alone 8 % -- a ds_write_b128 holds its SIMD's path to the LDS for 13 cycles, which the consumer on
+    // that SIMD needs for its fragment reads).
+    const int hwv = wave - 6;                             // planes 2 hwv, 2 hwv + 1
+    struct Slab { int b, it0, ih0, iw0, s, img, P, FP, cells, Wh, Ti, Hi, Wi, in_ld, cin, plane_b, key, nblk; unsigned m_HW, m_Wh; const char* base; };
     auto slab_of = [&](const PcIter& c, int s, int img) {
       const ConvKP& p = kp.m[c.mi];
       Slab z{};
       z.s = s; z.img = img; z.key = (c.mi << 24) | c.ptile;      // (position tiles < 2^24: the host checks the positions)
       z.P = pc_u(p.P); z.FP = pc_u(p.FP); z.Wh = pc_u(p.Wh); z.cells = pc_u(p.Hh) * z.Wh; z.Ti = pc_u(p.Ti); z.Hi = pc_u(p.Hi); z.Wi = pc_u(p.Wi);
       z.in_ld = pc_u(p.in_ld); z.cin = pc_u(p.cin); z.plane_b = pc_u(p.plane_b); z.m_HW = (unsigned)pc_u((int)p.m_HW); z.m_Wh = (unsigned)pc_u((int)p.m_Wh);
-      z.base = pc_uniform(p.in + (size_t)(p.in_coff + s * 32) * 2);
+      z.nblk = (z.P + 63) >> 6;
+      z.base = pc_uniform(p.in + (size_t)p.in_coff * 2);
       ConvKP t{};
       t.nTt = pc_u(p.nTt); t.nTh = pc_u(p.nTh); t.nTw = pc_u(p.nTw); t.Tt = pc_u(p.Tt); t.Ht = pc_u(p.Ht); t.Wt = pc_u(p.Wt);
       int ot0, oh0, ow0;
@@ -528,55 +538,46 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       z.it0 = ot0 - pc_u(p.pt); z.ih0 = oh0 - pc_u(p.ph); z.iw0 = ow0 - pc_u(p.pw);
       return z;
     };
-    // piece n of this thread: halo position hp0 + 32 n -> linear input position, -1 = zero fill (padding), -2 = no such slot (branch-free)
-    auto piece_g = [&](const Slab& z, int n) -> int {
-      const int hp = hp0 + 32 * n;
+    // halo position hp -> linear input position, or -1: no data (padding, a cell between two frames, beyond the image)
+    auto cell_g = [&](const Slab& z, int hp) -> int {
       const int a = pc_fdiv(hp, z.m_HW), rem = hp - pc_mul24(a, z.FP);
       const int bq = pc_fdiv(rem, z.m_Wh), c = rem - pc_mul24(bq, z.Wh);
       const int it = z.it0 + a, ih = z.ih0 + bq, iw = z.iw0 + c;
-      const bool slot_ok = hp < z.P && rem < z.cells;        // (the slots between two frames, FP > Hh * Wh, are never read)
-      const bool in = (unsigned)it < (unsigned)z.Ti && (unsigned)ih < (unsigned)z.Hi && (unsigned)iw < (unsigned)z.Wi;
+      const bool ok = hp < z.P && rem < z.cells && (unsigned)it < (unsigned)z.Ti && (unsigned)ih < (unsigned)z.Hi && (unsigned)iw < (unsigned)z.Wi;
       const int g = pc_mul24(pc_mul24(z.b * z.Ti + it, z.Hi) + ih, z.Wi) + iw;
-      return !slot_ok ? -2 : in ? g : -1;
+      return ok ? g : -1;
     };
-    // One register quad and one index register per piece: a piece is REQUESTED (index arithmetic + one asm load) at its step and COMMITTED (zero
-    // select + ds_write_b128) six steps later, two pieces per step -- the first form of this role moved them in three batches of eleven, and a
-    // batch step (11 x ~30 vector instructions at the low end of the SIMD's arbitration) kept all eight waves waiting at its barrier: +0.05 ms
-    // on a 0.23 ms launch.
-    pc_u32x4 v0 = {}, v1 = {}, v2 = {}, v3 = {}, v4 = {}, v5 = {}, v6 = {}, v7 = {}, v8 = {}, v9 = {}, v10 = {}, v11 = {}, v12 = {}, v13 = {}, v14 = {}, v15 = {}, v16 = {}, v17 = {}, v18 = {}, v19 = {}, v20 = {}, v21 = {}, v22 = {}, v23 = {}, v24 = {}, v25 = {}, v26 = {}, v27 = {}, v28 = {}, v29 = {}, v30 = {}, v31 = {}, v32 = {};
-    int g0 = -2, g1 = -2, g2 = -2, g3 = -2, g4 = -2, g5 = -2, g6 = -2, g7 = -2, g8 = -2, g9 = -2, g10 = -2, g11 = -2, g12 = -2, g13 = -2, g14 = -2, g15 = -2, g16 = -2, g17 = -2, g18 = -2, g19 = -2, g20 = -2, g21 = -2, g22 = -2, g23 = -2, g24 = -2, g25 = -2, g26 = -2, g27 = -2, g28 = -2, g29 = -2, g30 = -2, g31 = -2, g32 = -2;
-    // (the lane's byte offset of piece n inside a slab of the position tile: see PC_REQ)
-    unsigned o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u, o4 = 0u, o5 = 0u, o6 = 0u, o7 = 0u, o8 = 0u, o9 = 0u, o10 = 0u, o11 = 0u, o12 = 0u, o13 = 0u, o14 = 0u, o15 = 0u, o16 = 0u, o17 = 0u, o18 = 0u, o19 = 0u, o20 = 0u, o21 = 0u, o22 = 0u, o23 = 0u, o24 = 0u, o25 = 0u, o26 = 0u, o27 = 0u, o28 = 0u, o29 = 0u, o30 = 0u, o31 = 0u, o32 = 0u;
+    // Which input position a cell holds depends on the position tile only, not on the slab or the channel tile: the lane's byte offset of
+    // block j's cell (from the member's first channel) is computed for the FIRST slab staged of a position tile and kept for its other
+    // slabs and the channel tiles that follow; bit j of `live` = that cell holds data.
+    unsigned o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u, o4 = 0u, o5 = 0u, o6 = 0u, o7 = 0u, o8 = 0u, o9 = 0u, o10 = 0u, o11 = 0u, o12 = 0u, o13 = 0u, o14 = 0u, o15 = 0u;
+    unsigned live = 0u;
     Slab z{};
     z.key = -1;
-    bool chvalid = false, fresh = true;
-    char* dst = nullptr;
+    bool fresh = true;
+    const char* const zeros = (const char*)&pc_zero16;
+    const int halo_b = pc_u(kp.halo_bytes);
+    const unsigned lds0 = lds_addr32(smem);
     auto begin_slab = [&](const Slab& zn) {
       fresh = pc_u(zn.key != z.key) != 0;
       z = zn;
-      chvalid = z.s * 32 + ch * EPL < z.cin;
-      dst = smem + z.img * kp.halo_bytes + plane_off(ch, z.plane_b) + hp0 * 16;
     };
-    // request piece n: one unconditional load (position 0 of the tensor for padding and missing slots: always readable, never written to LDS),
-    // SADDR form -- scalar slab base + one 32-bit lane offset.  Which input position a piece holds depends on the position tile only, not on
-    // the slab or the channel tile: index and byte offset are computed for the FIRST slab staged of a position tile (`fresh`) and kept in
-    // registers for its other slabs and for the channel tiles that follow -- staged afresh per slab (~30 vector instructions per piece, 66
-    // pieces per slab on the two SIMDs these waves share with consumers 2 and 3) the staging cost the launch 13-15 % (-DPC_ABLATE=4).
-#define PC_REQ(n)                                                                                                 \
-    if (PAB(4)) {                                                                                                 \
-      if (fresh) {                                                                                                \
-        g##n = piece_g(z, n);                                                                                     \
-        o##n = (__umul24((unsigned)(g##n >= 0 ? g##n : 0), (unsigned)z.in_ld) + (unsigned)(ch * EPL)) * 2u;        \
-      }                                                                                                           \
-      const unsigned vo = chvalid ? o##n : (unsigned)(ch * EPL) * 2u;                                             \
-      if (PAB(512)) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v##n) : "v"(vo), "s"(z.base) : "memory"); \
-      else asm volatile("" : "=v"(v##n) : "v"(vo));                                                               \
-    }
-    // commit piece n (behind the counted wait that releases its register): zeros for padding, nothing for a missing slot
-#define PC_PUT(n)                                                                                                 \
-    if (PAB(4)) {                                                                                                 \
-      if (!PAB(1024)) asm volatile("" :: "v"(v##n));                                                               \
-      else if (g##n != -2) *(pc_u32x4*)(dst + (n) * 512) = (g##n >= 0 && chvalid) ? v##n : pc_u32x4{0u, 0u, 0u, 0u}; \
+    // block j of this wave's two planes, slab z
+#define PC_BLK(j)                                                                                                              \
+    if (PAB(4) && (j) < z.nblk) {                                                                                              \
+      if (fresh) {                                                                                                             \
+        const int g = cell_g(z, 64 * (j) + lane);                                                                              \
+        o##j = __umul24((unsigned)(g >= 0 ? g : 0), (unsigned)z.in_ld) * 2u;                                                   \
+        live = (live & ~(1u << (j))) | ((g >= 0 ? 1u : 0u) << (j));                                                            \
+      }                                                                                                                        \
+      const bool lv = (live >> (j)) & 1u;                                                                                      \
+      const unsigned lb = lds0 + (unsigned)(z.img * halo_b + (j) * 1024);                                             \
+      _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) {                                                                       \
+        const int c = 2 * hwv + k2;                                                                                            \
+        const bool chv = z.s * 32 + c * EPL < z.cin;                                                                           \
+        const char* const src = (lv && chv) ? z.base + (size_t)o##j + (size_t)((z.s * 32 + c * EPL) * 2) : zeros;             \
+        if (PAB(512)) glds16_v64(src, (unsigned)__builtin_amdgcn_readfirstlane((int)(lb + (unsigned)plane_off(c, z.plane_b)))); \
+      }                                                                                                                        \
     }
     PcIter it{slot, kp.slots, 0, 0, 0};                   // the item being consumed
     if (!it.next(kp, xcd)) return;
@@ -586,135 +587,45 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     {
       // the first slab of the workgroup: staged before b_0, synchronously
       begin_slab(slab_of(it, 0, 0));
-      PC_REQ(0) PC_REQ(1) PC_REQ(2) PC_REQ(3) PC_REQ(4) PC_REQ(5) PC_REQ(6) PC_REQ(7) PC_REQ(8) PC_REQ(9) PC_REQ(10) PC_REQ(11) PC_REQ(12) PC_REQ(13) PC_REQ(14) PC_REQ(15) PC_REQ(16) PC_REQ(17) PC_REQ(18) PC_REQ(19) PC_REQ(20) PC_REQ(21) PC_REQ(22) PC_REQ(23) PC_REQ(24) PC_REQ(25) PC_REQ(26) PC_REQ(27) PC_REQ(28) PC_REQ(29) PC_REQ(30) PC_REQ(31) PC_REQ(32)
-      asm volatile("s_waitcnt vmcnt(0) ; release %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9), "+v"(v10), "+v"(v11), "+v"(v12), "+v"(v13), "+v"(v14), "+v"(v15) :: "memory");
-      asm volatile("; release %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15" : "+v"(v16), "+v"(v17), "+v"(v18), "+v"(v19), "+v"(v20), "+v"(v21), "+v"(v22), "+v"(v23), "+v"(v24), "+v"(v25), "+v"(v26), "+v"(v27), "+v"(v28), "+v"(v29), "+v"(v30), "+v"(v31) :: "memory");
-      asm volatile("; release %0" : "+v"(v32) :: "memory");
-      PC_PUT(0) PC_PUT(1) PC_PUT(2) PC_PUT(3) PC_PUT(4) PC_PUT(5) PC_PUT(6) PC_PUT(7) PC_PUT(8) PC_PUT(9) PC_PUT(10) PC_PUT(11) PC_PUT(12) PC_PUT(13) PC_PUT(14) PC_PUT(15) PC_PUT(16) PC_PUT(17) PC_PUT(18) PC_PUT(19) PC_PUT(20) PC_PUT(21) PC_PUT(22) PC_PUT(23) PC_PUT(24) PC_PUT(25) PC_PUT(26) PC_PUT(27) PC_PUT(28) PC_PUT(29) PC_PUT(30) PC_PUT(31) PC_PUT(32)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PC_BLK(0) PC_BLK(1) PC_BLK(2) PC_BLK(3) PC_BLK(4) PC_BLK(5) PC_BLK(6) PC_BLK(7) PC_BLK(8) PC_BLK(9) PC_BLK(10) PC_BLK(11) PC_BLK(12) PC_BLK(13) PC_BLK(14) PC_BLK(15)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     while (true) {
       const int nslab = pc_u(kp.m[it.mi].nslab);
       for (int s = 0; s < nslab; ++s, ++gslab) {
-        // slab (it, s) is being consumed out of image gslab & 1; the slab after it goes into the other image while that happens: requested
-        // from step 0 on, written from step 6 on (the image's last reader, the slab before this one, has been read to its end by everyone
-        // behind the barrier of step 1), complete -- lgkmcnt(0) -- at step 22
+        // slab (it, s) is being consumed out of image gslab & 1; the slab after it goes into the other image while that happens: issued
+        // from step 1 on (the image's last reader, the slab before this one, has been read to its end by everyone behind the barrier of
+        // step 1), complete -- vmcnt(0) -- at step 22, four steps before its first reader
         const bool has_next = s + 1 < nslab || have_nx;
-        // (straight-line from every request to its commit: the audit, like hipcc's liveness, follows the control-flow graph, and in a counted
-        //  loop over the 27 steps a path would lead from a request past its commit.  Generated: two requests per step from step 0, two commits
-        //  per step from step 6, each wait leaving exactly the younger requests in flight)
         if (has_next) {
           begin_slab(s + 1 < nslab ? slab_of(it, s + 1, (gslab + 1) & 1) : slab_of(nx, 0, (gslab + 1) & 1));
           PC_BARRIER();                                   // step 0
-          PC_REQ(0)
-          PC_REQ(1)
-          PC_BARRIER();                                   // step 1
-          PC_REQ(2)
-          PC_REQ(3)
-          PC_BARRIER();                                   // step 2
-          PC_REQ(4)
-          PC_REQ(5)
-          PC_BARRIER();                                   // step 3
-          PC_REQ(6)
-          PC_REQ(7)
-          PC_BARRIER();                                   // step 4
-          PC_REQ(8)
-          PC_REQ(9)
-          PC_BARRIER();                                   // step 5
-          PC_REQ(10)
-          PC_REQ(11)
-          PC_BARRIER();                                   // step 6
-          PC_REQ(12)
-          PC_REQ(13)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v0), "+v"(v1) :: "memory");
-          PC_PUT(0)
-          PC_PUT(1)
-          PC_BARRIER();                                   // step 7
-          PC_REQ(14)
-          PC_REQ(15)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v2), "+v"(v3) :: "memory");
-          PC_PUT(2)
-          PC_PUT(3)
-          PC_BARRIER();                                   // step 8
-          PC_REQ(16)
-          PC_REQ(17)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v4), "+v"(v5) :: "memory");
-          PC_PUT(4)
-          PC_PUT(5)
-          PC_BARRIER();                                   // step 9
-          PC_REQ(18)
-          PC_REQ(19)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v6), "+v"(v7) :: "memory");
-          PC_PUT(6)
-          PC_PUT(7)
-          PC_BARRIER();                                   // step 10
-          PC_REQ(20)
-          PC_REQ(21)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v8), "+v"(v9) :: "memory");
-          PC_PUT(8)
-          PC_PUT(9)
-          PC_BARRIER();                                   // step 11
-          PC_REQ(22)
-          PC_REQ(23)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v10), "+v"(v11) :: "memory");
-          PC_PUT(10)
-          PC_PUT(11)
-          PC_BARRIER();                                   // step 12
-          PC_REQ(24)
-          PC_REQ(25)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v12), "+v"(v13) :: "memory");
-          PC_PUT(12)
-          PC_PUT(13)
-          PC_BARRIER();                                   // step 13
-          PC_REQ(26)
-          PC_REQ(27)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v14), "+v"(v15) :: "memory");
-          PC_PUT(14)
-          PC_PUT(15)
-          PC_BARRIER();                                   // step 14
-          PC_REQ(28)
-          PC_REQ(29)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v16), "+v"(v17) :: "memory");
-          PC_PUT(16)
-          PC_PUT(17)
-          PC_BARRIER();                                   // step 15
-          PC_REQ(30)
-          PC_REQ(31)
-          asm volatile("s_waitcnt vmcnt(12) ; release %0 %1" : "+v"(v18), "+v"(v19) :: "memory");
-          PC_PUT(18)
-          PC_PUT(19)
-          PC_BARRIER();                                   // step 16
-          PC_REQ(32)
-          asm volatile("s_waitcnt vmcnt(11) ; release %0 %1" : "+v"(v20), "+v"(v21) :: "memory");
-          PC_PUT(20)
-          PC_PUT(21)
+          PC_BARRIER(); PC_BLK(0)                         // step 1
+          PC_BARRIER(); PC_BLK(1)
+          PC_BARRIER(); PC_BLK(2)
+          PC_BARRIER(); PC_BLK(3)
+          PC_BARRIER(); PC_BLK(4)
+          PC_BARRIER(); PC_BLK(5)
+          PC_BARRIER(); PC_BLK(6)
+          PC_BARRIER(); PC_BLK(7)
+          PC_BARRIER(); PC_BLK(8)
+          PC_BARRIER(); PC_BLK(9)
+          PC_BARRIER(); PC_BLK(10)
+          PC_BARRIER(); PC_BLK(11)
+          PC_BARRIER(); PC_BLK(12)
+          PC_BARRIER(); PC_BLK(13)
+          PC_BARRIER(); PC_BLK(14)
+          PC_BARRIER(); PC_BLK(15)                        // step 16
           PC_BARRIER();                                   // step 17
-          asm volatile("s_waitcnt vmcnt(9) ; release %0 %1" : "+v"(v22), "+v"(v23) :: "memory");
-          PC_PUT(22)
-          PC_PUT(23)
-          PC_BARRIER();                                   // step 18
-          asm volatile("s_waitcnt vmcnt(7) ; release %0 %1" : "+v"(v24), "+v"(v25) :: "memory");
-          PC_PUT(24)
-          PC_PUT(25)
-          PC_BARRIER();                                   // step 19
-          asm volatile("s_waitcnt vmcnt(5) ; release %0 %1" : "+v"(v26), "+v"(v27) :: "memory");
-          PC_PUT(26)
-          PC_PUT(27)
-          PC_BARRIER();                                   // step 20
-          asm volatile("s_waitcnt vmcnt(3) ; release %0 %1" : "+v"(v28), "+v"(v29) :: "memory");
-          PC_PUT(28)
-          PC_PUT(29)
-          PC_BARRIER();                                   // step 21
-          asm volatile("s_waitcnt vmcnt(1) ; release %0 %1" : "+v"(v30), "+v"(v31) :: "memory");
-          PC_PUT(30)
-          PC_PUT(31)
+          PC_BARRIER();
+          PC_BARRIER();
+          PC_BARRIER();
+          PC_BARRIER();
           PC_BARRIER();                                   // step 22
-          asm volatile("s_waitcnt vmcnt(0) ; release %0" : "+v"(v32) :: "memory");
-          PC_PUT(32)
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the image is complete four steps before its first reader
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           PC_BARRIER();                                   // step 23
-          PC_BARRIER();                                   // step 24
-          PC_BARRIER();                                   // step 25
+          PC_BARRIER();
+          PC_BARRIER();
           PC_BARRIER();                                   // step 26
         } else {
 #pragma unroll 1
@@ -725,11 +636,8 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       it = nx;
       have_nx = nx.next(kp, xcd);
     }
-#undef PC_REQ
-#undef PC_PUT
+#undef PC_BLK
     PC_BARRIER();                         // b_total: the barrier of the consumers' last step
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
   }
 }
 
@@ -777,7 +685,7 @@ static int pc_plan_member(const flk_conv_args* a, const flk_conv_weights* w, int
     }
   kp.tfast = best_t; kp.FP = best_fp; kp.P = (kp.Th - 1) * best_fp + cells;
   FLK_REQUIRE(kp.P <= PC_MAX_HALO && kp.rows <= 512, "flk_conv3d_pc: no tile fits (halo %d)", kp.P);
-  kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
+  kp.plane_b = (kp.P + 63) / 64 * 1024;      // whole DMA blocks: a block's 64 cells never reach into the next plane
   auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
   kp.m_HW = magic(kp.FP); kp.m_Wh = magic(kp.Wh); kp.m_hw = magic((kp.tfast ? kp.Tt : kp.Ht) * kp.Wt); kp.m_Wt = magic(kp.Wt);
   const long ptiles = (long)a->B * kp.nTt * kp.nTh * kp.nTw;

@@ -32,10 +32,10 @@ def test_no_compiler_access_to_in_flight_registers():
     assert "conv_igemm_group_kernel" in r.stdout, "the grouped ring kernels issue asm loads too"
 
 
-def test_producer_consumer_kernel_halo_loads_are_audited():
-    """csrc/conv_pc.hip: the halo-staging waves keep 33 asm loads in flight across up to six barriers each; the schedule is straight-line code
-    from every request to its commit so that neither hipcc's liveness nor this audit can find a path around a wait.  Also its timing-only
-    variants that change the staging / loop structure (-DPC_ABLATE bits 4 and 128, -DPC_STAMP)."""
+def test_producer_consumer_kernel_has_no_register_asm_loads():
+    """csrc/conv_pc.hip moves weights AND halo through LDS-DMA (no destination registers: nothing for hipcc's liveness to get wrong); its first
+    form kept 33 asm register loads in flight per staging thread.  The audit still runs on it and on its timing-only variants with every
+    non-default build (build.ASM_LOAD_SOURCES): a register-destination asm load that comes back must pass it."""
     from concurrent.futures import ThreadPoolExecutor
     pc = os.path.join(ROOT, "flickering_adversarial_video_amd", "csrc", "conv_pc.hip")
     runs = [[], ["-DPC_ABLATE=128"], ["-DPC_STAMP"]]
@@ -43,8 +43,7 @@ def test_producer_consumer_kernel_halo_loads_are_audited():
         res = list(ex.map(lambda f: subprocess.run([sys.executable, AUDIT, pc] + f, capture_output=True, text=True, timeout=900), runs))
     for f, r in zip(runs, res):
         assert r.returncode == 0, str(f) + "\n" + r.stdout[-3000:] + r.stderr[-2000:]
-        assert "2 kernels with asm loads audited, 0 with violations" in r.stdout, str(f) + r.stdout[-500:]
-        assert "conv_pc_kernelILi7E" in r.stdout and "66 asm loads" in r.stdout
+        assert "0 kernels with asm loads audited, 0 with violations" in r.stdout, str(f) + r.stdout[-500:]
 
 
 def test_audit_flags_a_minimal_hazard():
