@@ -150,47 +150,55 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     bool first_item = true;
     frag a0[NFW];         // weight fragments of an item's first step: read by the previous item's last step (by the prologue for the first item)
     if (PAB(2)) __builtin_amdgcn_s_setprio(1);      // the partner wave on this SIMD is a producer: its vector instructions take the leftover issue slots
+    // The member's parameters, copied into registers when the MEMBER changes (a launch has one to three; a workgroup's items run member by
+    // member).  Read in place -- kp.m[mi].field with a run-time mi -- every use is a scalar load + s_waitcnt of its own, and hipcc sinks
+    // those loads into the innermost conditional blocks instead of hoisting them: the first build of this kernel spent 28 us per item in its
+    // epilogue and 37 us per slab in the halo staging that way (4 x the whole conv_igemm_kernel launch).  pc_u / pc_uniform
+    // (v_readfirstlane) make each copy a value the compiler cannot re-materialise from memory.  The rows' cells in the halo image depend on
+    // the member's tile geometry only: computed with the copy (per ITEM the set-up was ~1 000 cycles, 3 % of a 54-step item).
+    ConvKP p{};
+    int cur_mi = -1, halo_bytes = 0, inner = 1;
+    int rowpos[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) rowpos[i] = 0;
+    auto row_cell24 = [&](int r, int& rt, int& rh, int& rw) {      // conv_common.h row_cell with 24-bit multiplies
+      const int o = pc_fdiv(r, p.m_hw), rem = r - pc_mul24(o, inner);
+      const int i = pc_fdiv(rem, p.m_Wt);
+      rw = rem - pc_mul24(i, p.Wt);
+      rt = p.tfast ? i : o;
+      rh = p.tfast ? o : i;
+    };
     while (it.next(kp, xcd)) {
-      // The member's parameters, copied ONCE per item into registers.  Read in place -- kp.m[mi].field with a run-time mi -- every use is a
-      // scalar load + s_waitcnt of its own, and hipcc sinks those loads into the innermost conditional blocks instead of hoisting them: the
-      // first build of this kernel spent 28 us per item in its epilogue and 37 us per slab in the halo staging that way (4 x the whole
-      // conv_igemm_kernel launch).  pc_u / pc_uniform (v_readfirstlane) make each copy a value the compiler cannot re-materialise from memory.
 #ifdef PC_STAMP
       const unsigned long long sti = __builtin_amdgcn_s_memtime();
 #endif
-      const ConvKP& pk = kp.m[it.mi];
-      ConvKP p{};
-      p.rows = pc_u(pk.rows); p.FP = pc_u(pk.FP); p.Wh = pc_u(pk.Wh); p.plane_b = pc_u(pk.plane_b); p.tfast = pc_u(pk.tfast);
-      p.Tt = pc_u(pk.Tt); p.Ht = pc_u(pk.Ht); p.Wt = pc_u(pk.Wt); p.m_hw = (unsigned)pc_u((int)pk.m_hw); p.m_Wt = (unsigned)pc_u((int)pk.m_Wt);
-      p.nTt = pc_u(pk.nTt); p.nTh = pc_u(pk.nTh); p.nTw = pc_u(pk.nTw); p.nslab = pc_u(pk.nslab);
-      p.To = pc_u(pk.To); p.Ho = pc_u(pk.Ho); p.Wo = pc_u(pk.Wo); p.OT = pc_u(pk.OT); p.OH = pc_u(pk.OH); p.OW = pc_u(pk.OW);
-      p.out = (char*)pc_uniform(pk.out); p.out2 = p.out; p.out_ld = pc_u(pk.out_ld); p.out_coff = pc_u(pk.out_coff); p.cout = pc_u(pk.cout); p.cout1 = p.cout;
-      p.scale = (const float*)pc_uniform((const char*)pk.scale); p.bias = (const float*)pc_uniform((const char*)pk.bias);
-      p.add = pc_uniform(pk.add); p.add_ld = pc_u(pk.add_ld); p.add_coff = pc_u(pk.add_coff);
-      p.mask = pc_uniform(pk.mask); p.mask_ld = pc_u(pk.mask_ld); p.mask_coff = pc_u(pk.mask_coff); p.relu = pc_u(pk.relu);
-      const int halo_bytes = pc_u(kp.halo_bytes);
+      if (it.mi != cur_mi) {
+        cur_mi = it.mi;
+        const ConvKP& pk = kp.m[it.mi];
+        p.rows = pc_u(pk.rows); p.FP = pc_u(pk.FP); p.Wh = pc_u(pk.Wh); p.plane_b = pc_u(pk.plane_b); p.tfast = pc_u(pk.tfast);
+        p.Tt = pc_u(pk.Tt); p.Ht = pc_u(pk.Ht); p.Wt = pc_u(pk.Wt); p.m_hw = (unsigned)pc_u((int)pk.m_hw); p.m_Wt = (unsigned)pc_u((int)pk.m_Wt);
+        p.nTt = pc_u(pk.nTt); p.nTh = pc_u(pk.nTh); p.nTw = pc_u(pk.nTw); p.nslab = pc_u(pk.nslab);
+        p.To = pc_u(pk.To); p.Ho = pc_u(pk.Ho); p.Wo = pc_u(pk.Wo); p.OT = pc_u(pk.OT); p.OH = pc_u(pk.OH); p.OW = pc_u(pk.OW);
+        p.out = (char*)pc_uniform(pk.out); p.out2 = p.out; p.out_ld = pc_u(pk.out_ld); p.out_coff = pc_u(pk.out_coff); p.cout = pc_u(pk.cout); p.cout1 = p.cout;
+        p.scale = (const float*)pc_uniform((const char*)pk.scale); p.bias = (const float*)pc_uniform((const char*)pk.bias);
+        p.add = pc_uniform(pk.add); p.add_ld = pc_u(pk.add_ld); p.add_coff = pc_u(pk.add_coff);
+        p.mask = pc_uniform(pk.mask); p.mask_ld = pc_u(pk.mask_ld); p.mask_coff = pc_u(pk.mask_coff); p.relu = pc_u(pk.relu);
+        halo_bytes = pc_u(kp.halo_bytes);
+        inner = (p.tfast ? p.Tt : p.Ht) * p.Wt;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int r = wave * 16 * NI + i * 16 + m;
+          int pos = 0;
+          if (r < p.rows) {
+            int rt, rh, rw;
+            row_cell24(r, rt, rh, rw);
+            pos = pc_mul24(rt, p.FP) + pc_mul24(rh, p.Wh) + rw;
+          }
+          rowpos[i] = pos * 16 + plane_off(q, p.plane_b);
+        }
+      }
       int b, ot0, oh0, ow0;
       pc_tile_origin(p, it.ptile, b, ot0, oh0, ow0);
-      const int inner = (p.tfast ? p.Tt : p.Ht) * p.Wt;
-      auto row_cell24 = [&](int r, int& rt, int& rh, int& rw) {      // conv_common.h row_cell with 24-bit multiplies
-        const int o = pc_fdiv(r, p.m_hw), rem = r - pc_mul24(o, inner);
-        const int i = pc_fdiv(rem, p.m_Wt);
-        rw = rem - pc_mul24(i, p.Wt);
-        rt = p.tfast ? i : o;
-        rh = p.tfast ? o : i;
-      };
-      int rowpos[NI];
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int r = wave * 16 * NI + i * 16 + m;
-        int pos = 0;
-        if (r < p.rows) {
-          int rt, rh, rw;
-          row_cell24(r, rt, rh, rw);
-          pos = pc_mul24(rt, p.FP) + pc_mul24(rh, p.Wh) + rw;
-        }
-        rowpos[i] = pos * 16 + plane_off(q, p.plane_b);
-      }
       f32x4 acc[NFW][NI];
 #pragma unroll
       for (int f = 0; f < NFW; ++f)
@@ -303,6 +311,13 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       }
 #endif
       gslab += p.nslab;
+      if constexpr (NI == 8) {
+        // 128 accumulators: the epilogue has no registers to carry the rows' cells to the next item (92 spilled): this instance re-derives
+        // the member state per item, as every instance did at first
+#pragma unroll
+        for (int i = 0; i < NI; ++i) rowpos[i] = 0;
+        cur_mi = -1;
+      }
 
       // ---- epilogue: lane = position m of fragment i, lane group q owns EPL channels of each of the two 32-channel store groups.  The arithmetic is
       // conv_igemm_kernel's (conv_common.h finish_store: acc * scale, rounded, + bias, rounded; + add; ReLU; mask; bf16), in the same order; the
@@ -460,14 +475,24 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     const char *scp = nullptr, *bip = nullptr;
     size_t wstep = 0;
     int sbmax = 0;
+    // (member fields: read when the member changes, not per item -- an item switch sits between two barriers every wave waits at)
+    int w_mi = -1, m_cn = 0, m_cout = 0;
+    size_t m_wstep = 0;
+    const char *m_w = nullptr, *m_sc = nullptr, *m_bi = nullptr;
     auto setup = [&]() {
       if (!have) return;
-      const ConvKP& p = kp.m[it.mi];
-      cn = pc_u(p.nslab) * PC_TAPS;
-      wstep = (size_t)pc_u(p.cout_frags) * 1024;
-      wt = pc_uniform(p.w + (size_t)it.ntile * 4 * 1024);
-      scp = pc_uniform((const char*)p.scale); bip = pc_uniform((const char*)p.bias);
-      sbmax = (pc_u(p.cout) - it.ntile * 64) * 4 - 16;      // last readable 16-byte piece of the tile's scale / bias rows (cout % 8 == 0)
+      if (it.mi != w_mi) {
+        w_mi = it.mi;
+        const ConvKP& p = kp.m[it.mi];
+        m_cn = pc_u(p.nslab) * PC_TAPS;
+        m_wstep = (size_t)pc_u(p.cout_frags) * 1024;
+        m_w = pc_uniform(p.w); m_sc = pc_uniform((const char*)p.scale); m_bi = pc_uniform((const char*)p.bias);
+        m_cout = pc_u(p.cout);
+      }
+      cn = m_cn; wstep = m_wstep;
+      wt = m_w + (size_t)it.ntile * 4 * 1024;
+      scp = m_sc; bip = m_bi;
+      sbmax = (m_cout - it.ntile * 64) * 4 - 16;      // last readable 16-byte piece of the tile's scale / bias rows (cout % 8 == 0)
     };
     setup();
     const unsigned ring0 = lds_addr32(ring);
@@ -523,19 +548,27 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     // that SIMD needs for its fragment reads).
     const int hwv = wave - 6;                             // planes 2 hwv, 2 hwv + 1
     struct Slab { int b, it0, ih0, iw0, s, img, P, FP, cells, Wh, Ti, Hi, Wi, in_ld, cin, plane_b, key, nblk; unsigned m_HW, m_Wh; const char* base; };
+    // the member's part of a Slab: read when the member changes
+    Slab mem{};
+    int mem_mi = -1, m_nTt = 1, m_nTh = 1, m_nTw = 1, m_Tt = 1, m_Ht = 1, m_Wt = 1, m_pt = 0, m_ph = 0, m_pw = 0;
     auto slab_of = [&](const PcIter& c, int s, int img) {
-      const ConvKP& p = kp.m[c.mi];
-      Slab z{};
+      if (c.mi != mem_mi) {
+        mem_mi = c.mi;
+        const ConvKP& p = kp.m[c.mi];
+        mem.P = pc_u(p.P); mem.FP = pc_u(p.FP); mem.Wh = pc_u(p.Wh); mem.cells = pc_u(p.Hh) * mem.Wh; mem.Ti = pc_u(p.Ti); mem.Hi = pc_u(p.Hi); mem.Wi = pc_u(p.Wi);
+        mem.in_ld = pc_u(p.in_ld); mem.cin = pc_u(p.cin); mem.plane_b = pc_u(p.plane_b); mem.m_HW = (unsigned)pc_u((int)p.m_HW); mem.m_Wh = (unsigned)pc_u((int)p.m_Wh);
+        mem.nblk = (mem.P + 63) >> 6;
+        mem.base = pc_uniform(p.in + (size_t)p.in_coff * 2);
+        m_nTt = pc_u(p.nTt); m_nTh = pc_u(p.nTh); m_nTw = pc_u(p.nTw); m_Tt = pc_u(p.Tt); m_Ht = pc_u(p.Ht); m_Wt = pc_u(p.Wt);
+        m_pt = pc_u(p.pt); m_ph = pc_u(p.ph); m_pw = pc_u(p.pw);
+      }
+      Slab z = mem;
       z.s = s; z.img = img; z.key = (c.mi << 24) | c.ptile;      // (position tiles < 2^24: the host checks the positions)
-      z.P = pc_u(p.P); z.FP = pc_u(p.FP); z.Wh = pc_u(p.Wh); z.cells = pc_u(p.Hh) * z.Wh; z.Ti = pc_u(p.Ti); z.Hi = pc_u(p.Hi); z.Wi = pc_u(p.Wi);
-      z.in_ld = pc_u(p.in_ld); z.cin = pc_u(p.cin); z.plane_b = pc_u(p.plane_b); z.m_HW = (unsigned)pc_u((int)p.m_HW); z.m_Wh = (unsigned)pc_u((int)p.m_Wh);
-      z.nblk = (z.P + 63) >> 6;
-      z.base = pc_uniform(p.in + (size_t)p.in_coff * 2);
       ConvKP t{};
-      t.nTt = pc_u(p.nTt); t.nTh = pc_u(p.nTh); t.nTw = pc_u(p.nTw); t.Tt = pc_u(p.Tt); t.Ht = pc_u(p.Ht); t.Wt = pc_u(p.Wt);
+      t.nTt = m_nTt; t.nTh = m_nTh; t.nTw = m_nTw; t.Tt = m_Tt; t.Ht = m_Ht; t.Wt = m_Wt;
       int ot0, oh0, ow0;
       pc_tile_origin(t, c.ptile, z.b, ot0, oh0, ow0);
-      z.it0 = ot0 - pc_u(p.pt); z.ih0 = oh0 - pc_u(p.ph); z.iw0 = ow0 - pc_u(p.pw);
+      z.it0 = ot0 - m_pt; z.ih0 = oh0 - m_ph; z.iw0 = ow0 - m_pw;
       return z;
     };
     // halo position hp -> linear input position, or -1: no data (padding, a cell between two frames, beyond the image)
@@ -598,8 +631,8 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
         // step 1), complete -- vmcnt(0) -- at step 22, four steps before its first reader
         const bool has_next = s + 1 < nslab || have_nx;
         if (has_next) {
-          begin_slab(s + 1 < nslab ? slab_of(it, s + 1, (gslab + 1) & 1) : slab_of(nx, 0, (gslab + 1) & 1));
           PC_BARRIER();                                   // step 0
+          begin_slab(s + 1 < nslab ? slab_of(it, s + 1, (gslab + 1) & 1) : slab_of(nx, 0, (gslab + 1) & 1));      // (behind the barrier: nobody waits for it)
           PC_BARRIER(); PC_BLK(0)                         // step 1
           PC_BARRIER(); PC_BLK(1)
           PC_BARRIER(); PC_BLK(2)
@@ -839,7 +872,8 @@ extern "C" int flk_conv3d_pc_worthwhile(const flk_conv_args* const* a, const flk
   double steps = 0;
   if (pc_plan(a, w, n, dtype, kp, ni, &eff, &steps) != FLK_OK) return 0;
   static const double min_steps = getenv("FLK_PC_MIN_STEPS") ? atof(getenv("FLK_PC_MIN_STEPS")) : 300.0;
-  return eff >= 0.8 && steps >= min_steps;
+  static const double min_eff = getenv("FLK_PC_MIN_EFF") ? atof(getenv("FLK_PC_MIN_EFF")) : 0.8;
+  return eff >= min_eff && steps >= min_steps;
 }
 
 // The launch flk_conv3d_pc would make for these geometries, without weights or a device (plan builders, tests): member 0's tile, the
