@@ -252,6 +252,8 @@ __device__ static inline void finish_store_row_pre(const ConvKP& p, size_t opos,
 
 // ---- LDS-DMA (global_load_lds_dwordx4): one wave-instruction moves 64 lanes x 16 bytes to 1 KiB of contiguous LDS at m0 + 16 * lane ----
 __device__ static inline unsigned lds_addr32(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p; }
+// 16 bytes of zeros in device memory (one copy per translation unit): the source of every halo cell that holds no data
+static __device__ __attribute__((aligned(16))) unsigned flk_zero16[4];
 // (per-lane 64-bit source address)
 __device__ static inline void glds16_v64(const char* src, unsigned lds_base) {
   unsigned keep;

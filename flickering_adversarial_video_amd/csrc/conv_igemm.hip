@@ -46,7 +46,8 @@ constexpr int NPAIR = (FLK_MAX_HALO * 4 + 255) / 256;  // (position, chunk) pair
 // address computations and nowhere in the loop structure.
 // timing experiments on the row-ahead ring loop (-DCONV_ABLATE=bits builds only; WRONG results): 1 no weight stream (neither the row-ahead
 // loads nor their waits: the ring is written from registers that hold zeros), 2 no barrier per step, 4 no ring write, 8 no MFMAs, 16 no
-// position-fragment reads, 32 no weight-fragment reads.  The product build compiles every CAB() to true.
+// position-fragment reads, 32 no weight-fragment reads, 64 no halo staging of the large-halo forms (the image keeps whatever LDS held).  The product
+// build compiles every CAB() to true.
 // (The substitutes for skipped reads are ZERO fragments, and bit 1 drops the LOADS with the waits: a substitute taken from a weight-queue
 //  register, and a ring write of a register whose load nothing had waited for, are what faulted in round 4 -- DESIGN.md.  Variants are built
 //  with tools/build_variant.py, which puts them through tools/audit_asm_loads.py with the same flags and refuses to link a flagged one;
@@ -112,7 +113,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
   const int it0 = ot0 * p.st - p.pt, ih0 = oh0 * p.sh - p.ph, iw0 = ow0 * p.sw - p.pw;
 
   // ---- staging plan: pair n of this thread = (halo position (tid>>2) + 64 n, chunk tid&3) ----
-  const int ch = tid & 3;
+  // Large halos of the multi-tap forms (DMAH): by LDS-DMA instead -- wave w fills chunk plane w, one wave-instruction per block of 64
+  // consecutive cells, every lane with its own source address (a block of zeros for padding and for the cells no tap reads): pair n of a
+  // lane = (halo position lane + 64 n, chunk wave).  No staging registers, no selects, no ds_write_b128 (13 cycles of the SIMD's path to
+  // the LDS each); measured cost of the register form on these launches: 11-17 % (-DCONV_ABLATE=64).  conv_pc.hip stages the same way.
+  constexpr bool DMAH = MODE == 0 || MODE == 1 || MODE == 5 || MODE == 6;
+  const bool dma_halo = DMAH && !small_halo;
+  const int ch = dma_halo ? wave : (tid & 3);
   constexpr int NPK = K1 ? 4 : NPAIR;   // 1x1x1 tiles have P <= 256: 4 pairs per thread
 #ifndef FLK_HALO_BATCH
 #define FLK_HALO_BATCH 4
@@ -124,7 +131,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     const int HW = p.Hh * p.Wh;
 #pragma unroll
     for (int n = 0; n < NPK; ++n) {
-      const int hp = (tid >> 2) + 64 * n;
+      const int hp = dma_halo ? lane + 64 * n : (tid >> 2) + 64 * n;
       int g = -2;
       if (hp < p.P) {
         const int a = fdiv(hp, p.m_HW), rem = hp - a * p.FP;
@@ -183,6 +190,20 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     src = p.in2 + (size_t)(p.in2_coff + s2 * SLABC + ch * EPL) * sizeof(T); ld = p.in2_ld;
     return s2 * SLABC + ch * EPL < p.cin - p.cin1;
   };
+  // slab s into the image at byte offset img of the halo area, by LDS-DMA (dma_halo); complete for this wave at return, for the others
+  // behind the next barrier
+  auto stage_dma = [&](int s) {
+    const char* src; int ld;
+    const bool chvalid = slab_src(s, src, ld);
+    const unsigned lb = lds_addr32(halo) + (unsigned)plane_off(ch, p.plane_b);
+#pragma unroll
+    for (int n = 0; n < NPK; ++n) {
+      if (n * 64 >= p.P || !CAB(64)) break;
+      const char* const a = (goff[n] >= 0 && chvalid) ? src + (size_t)goff[n] * ld * sizeof(T) : (const char*)flk_zero16;
+      glds16_v64(a, (unsigned)__builtin_amdgcn_readfirstlane((int)(lb + (unsigned)(n * 1024))));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   const size_t wstep = (size_t)p.cout_frags * 1024;
   const int nsteps = nslab * p.ntaps;
   const char* const wbase = p.w + (size_t)s_lo * p.ntaps * wstep;
@@ -222,18 +243,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
         if (s + 1 < nslab) prefetch(s + 1);
       } else {
         __syncthreads();  // every wave has finished reading the previous slab's halo
-        const char* src; int ld;
-        const bool chvalid = slab_src(s, src, ld);
-  #pragma unroll
-        for (int n0 = 0; n0 < NPK; n0 += HB) {
-          if (n0 * 64 >= p.P) break;
-          uint4 v[HB];
-  #pragma unroll
-          for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
-  #pragma unroll
-          for (int n = 0; n < HB; ++n)
-            if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
-        }
+        stage_dma(s);
       }
       int tapoff_t = 0;
       for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.FP * 16) {
@@ -358,25 +368,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
     //  the three weight registers would cost the third wave per SIMD)
     for (int s = 0; s < nslab; ++s) {
       __syncthreads();  // every wave has finished reading the previous slab's halo
-      {
-        const char* src; int ld;
-        const bool chvalid = slab_src(s, src, ld);
-  #pragma unroll
-        for (int n0 = 0; n0 < NPK; n0 += HB) {
-          if (n0 * 64 >= p.P) break;
-          uint4 v[HB];
-  #pragma unroll
-          for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
-  #pragma unroll
-          for (int n = 0; n < HB; ++n)
-            if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
-        }
-      }
-      // every halo load has been consumed -- but behind exec-masked branches, so hipcc carries their destination registers as "maybe
-      // pending" into the tap loop and puts s_waitcnt vmcnt(0) in front of whatever reuses one (seen in the mode-6 listing: two per step,
-      // each draining the row-ahead queue).  An explicit vmcnt(0) it can see settles its scoreboard; free here: loads return in order and
-      // the halo loads are the youngest
-      __builtin_amdgcn_s_waitcnt(0x0F70);
+      stage_dma(s);       // (its vmcnt(0) drains the row-ahead weight queue as well: in order, and the halo pieces are the youngest)
       int tapoff_t = 0;
       for (int dt = 0; dt < p.kt; ++dt, tapoff_t += p.FP * 16) {
         int tapoff = tapoff_t;
@@ -620,18 +612,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
             __syncthreads();
           } else {
             __syncthreads();  // every wave has finished reading the previous slab's halo
-            const char* src; int ld;
-            const bool chvalid = slab_src(s, src, ld);
-#pragma unroll
-            for (int n0 = 0; n0 < NPK; n0 += HB) {
-              if (n0 * 64 >= p.P) break;
-              uint4 v[HB];
-#pragma unroll
-              for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
-#pragma unroll
-              for (int n = 0; n < HB; ++n)
-                if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
-            }
+            stage_dma(s);     // (its vmcnt(0) also empties the weight queue: the counted waits behind it find their pieces landed)
             __syncthreads();
           }
         }
@@ -1111,7 +1092,7 @@ static void pick_halo_layout(ConvKP& kp, size_t ring_bytes, int max_resident) {
   if (kp.P <= 256) return;                     // (the two-image path of small halos keeps its 256-slot images)
   const int cells = kp.Hh * kp.Wh;
   auto extra_passes = [&](int tfast, int FP) { return conv_halo_extra_passes(kp, tfast, FP); };
-  auto lds_of = [&](int P) { return 4 * ((size_t)(P * 16 + 255) / 256 * 256) + 64 + ring_bytes; };
+  auto lds_of = [&](int P) { return 4 * ((size_t)(P + 63) / 64 * 1024) + 64 + ring_bytes; };      // (images of whole 64-cell DMA blocks)
   const size_t cap = 160 * 1024;
   const size_t res0 = std::min<size_t>(max_resident, cap / lds_of(kp.P));
   int best = extra_passes(0, cells), best_t = 0, best_fp = cells;
@@ -1387,7 +1368,8 @@ static int conv3d_impl(const flk_conv_args* a, const flk_conv_weights* w, int dt
   if (!w->stem4) {
     // workgroups per CU the registers allow: the ring kernels with <= 64-channel tiles hold three, everything else two
     pick_halo_layout(kp, ring_bytes, (mode == 0 || mode == 5) && nf <= 4 ? 3 : 2);
-    kp.plane_b = (kp.P * 16 + 255) / 256 * 256;
+    // (large halos of the multi-tap forms are staged by LDS-DMA, 64 cells per wave-instruction: planes of whole blocks)
+    kp.plane_b = kp.P > 256 && (mode == 0 || mode == 1 || mode == 5) ? (kp.P + 63) / 64 * 1024 : (kp.P * 16 + 255) / 256 * 256;
     kp.m_HW = magic(kp.FP); kp.m_hw = magic((kp.tfast ? kp.Tt : kp.Ht) * kp.Wt);
   }
   const size_t lds = (kp.P <= 256 ? 2 : 1) * (4 * (size_t)kp.plane_b + 64) + ring_bytes;

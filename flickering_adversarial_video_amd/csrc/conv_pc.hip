@@ -63,7 +63,7 @@ __device__ unsigned long long pc_stamps[512][8];
 #endif
 
 // 16 bytes of zeros in device memory: the source of every halo cell that holds no data
-__device__ __attribute__((aligned(16))) unsigned pc_zero16[4];
+// (conv_common.h flk_zero16)
 
 struct PcKP {
   ConvKP m[PC_MAX_MEMBERS];          // members of the launch (a grouped launch: Branch_1 and Branch_2 of an Inception block)
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     Slab z{};
     z.key = -1;
     bool fresh = true;
-    const char* const zeros = (const char*)&pc_zero16;
+    const char* const zeros = (const char*)flk_zero16;
     const int halo_b = pc_u(kp.halo_bytes);
     const unsigned lds0 = lds_addr32(smem);
     auto begin_slab = [&](const Slab& zn) {
