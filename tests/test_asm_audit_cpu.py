@@ -76,14 +76,30 @@ def test_audit_flags_the_pre_fix_k_loops(tmp_path):
 
 
 def test_audit_flags_a_drained_row_ahead_queue(tmp_path):
-    """the product source without the explicit vmcnt(0) behind the halo staging of the row-ahead kernels: hipcc then carries the halo
-    loads' destination registers as "maybe pending" into the tap loop and waits on vmcnt in front of the fragment reads that reuse them
-    -- every such wait drains the inline-asm weight queue (results correct, the layer 10 % slower: DESIGN.md, mode 6)"""
+    """The audit's second check, on a source that has the hazard: the row-ahead kernels (modes 5 / 6) with their halo staged through REGISTERS
+    again (the product stages it by LDS-DMA since round 5) and no wait hipcc can see behind it.  hipcc then carries the halo loads'
+    destination registers as "maybe pending" into the tap loop and waits on vmcnt in front of whatever reuses them -- every such wait
+    drains the inline-asm weight queue (results correct, the layer 10 % slower: DESIGN_LOG.md, mode 6)."""
     s = open(SRC).read()
-    line = "      __builtin_amdgcn_s_waitcnt(0x0F70);\n"
+    line = "      stage_dma(s);       // (its vmcnt(0) drains the row-ahead weight queue as well: in order, and the halo pieces are the youngest)\n"
     assert s.count(line) == 1, "conv_igemm.hip changed: update the fixture's patch"
+    staged = """      {
+        const char* src; int ld;
+        const bool chvalid = slab_src(s, src, ld);
+  #pragma unroll
+        for (int n0 = 0; n0 < NPK; n0 += HB) {
+          if (n0 * 64 >= p.P) break;
+          uint4 v[HB];
+  #pragma unroll
+          for (int n = 0; n < HB; ++n) v[n] = ldhalo(src, ld, goff[n0 + n], chvalid);
+  #pragma unroll
+          for (int n = 0; n < HB; ++n)
+            if (goff[n0 + n] != -2) *(uint4*)(hdst + (n0 + n) * 1024) = v[n];
+        }
+      }
+"""
     p = tmp_path / "conv_igemm_noscoreboard.hip"
-    p.write_text(s.replace(line, ""))
+    p.write_text(s.replace(line, staged))
     r = _audit(str(p))
     assert r.returncode == 1, r.stdout[-2000:] + r.stderr[-2000:]
     assert "compiler wait inside the row-ahead tap loop" in r.stdout
