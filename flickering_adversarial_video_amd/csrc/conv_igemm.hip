@@ -1528,7 +1528,7 @@ extern "C" int flk_conv_set_autotune(int on) { g_tuning = on != 0; return FLK_OK
 extern "C" int flk_conv3d(const flk_conv_args* a, const flk_conv_weights* w, int dtype, void* stream) {
   if (!a || !w) return conv3d_impl(a, w, dtype, stream, 0, -1);
   // the large 3x3x3 stride-1 layers (Conv3d_2c_3x3 at the benchmark batch): the persistent producer / consumer kernel -- bitwise the same outputs
-  if (pc_route_on() && !g_tuning && dtype == FLK_BF16 && w->ntaps == 27 && w->nf == 4 && !a->splitk_ws && flk_conv3d_pc_worthwhile(&a, &w, 1, dtype))
+  if (pc_route_on() && !g_tuning && dtype == FLK_BF16 && (w->ntaps == 27 || (w->ntaps == 9 && w->kt == 1)) && w->nf == 4 && !a->splitk_ws && flk_conv3d_pc_worthwhile(&a, &w, 1, dtype))
     return flk_conv3d_pc(&a, &w, 1, dtype, stream);
   for (const flk_conv_weights::Tuned& tn : w->tuned)
     if (tn.B == a->B && tn.To == a->To && tn.Ho == a->Ho && tn.Wo == a->Wo) return conv3d_impl(a, w, dtype, stream, tn.wn, tn.da);

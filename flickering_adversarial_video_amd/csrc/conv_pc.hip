@@ -39,7 +39,7 @@ constexpr int PC_D = 4;             // weight look-ahead in K steps; PC_R >= PC_
 constexpr int PC_MAX_HALO = 1024;   // halo slots per image (16 DMA blocks of 64 per chunk plane): 2 x (4 planes x 16 KiB + 64) + 6 x 4 KiB + 4 KiB (scale / bias) = 159 872 B of the 160 KiB
 constexpr int PC_THREADS = 512;
 constexpr int PC_NBLK = 16;         // DMA blocks (64 halo positions) per chunk plane
-constexpr int PC_TAPS = 27;
+constexpr int PC_ROW = 9;            // K steps per frame of taps (3 x 3); a slab is kt of them (kt = 3: Unit3D; kt = 1: the spatial half of a (2+1)D unit)
 static_assert(PC_R >= PC_D + 2, "ring too short for the look-ahead");
 static_assert(PC_NBLK * 64 >= PC_MAX_HALO, "halo blocks do not cover the image");
 
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
         const ConvKP& pk = kp.m[it.mi];
         p.rows = pc_u(pk.rows); p.FP = pc_u(pk.FP); p.Wh = pc_u(pk.Wh); p.plane_b = pc_u(pk.plane_b); p.tfast = pc_u(pk.tfast);
         p.Tt = pc_u(pk.Tt); p.Ht = pc_u(pk.Ht); p.Wt = pc_u(pk.Wt); p.m_hw = (unsigned)pc_u((int)pk.m_hw); p.m_Wt = (unsigned)pc_u((int)pk.m_Wt);
-        p.nTt = pc_u(pk.nTt); p.nTh = pc_u(pk.nTh); p.nTw = pc_u(pk.nTw); p.nslab = pc_u(pk.nslab);
+        p.nTt = pc_u(pk.nTt); p.nTh = pc_u(pk.nTh); p.nTw = pc_u(pk.nTw); p.nslab = pc_u(pk.nslab); p.kt = pc_u(pk.kt);
         p.To = pc_u(pk.To); p.Ho = pc_u(pk.Ho); p.Wo = pc_u(pk.Wo); p.OT = pc_u(pk.OT); p.OH = pc_u(pk.OH); p.OW = pc_u(pk.OW);
         p.out = (char*)pc_uniform(pk.out); p.out2 = p.out; p.out_ld = pc_u(pk.out_ld); p.out_coff = pc_u(pk.out_coff); p.cout = pc_u(pk.cout); p.cout1 = p.cout;
         p.scale = (const float*)pc_uniform((const char*)pk.scale); p.bias = (const float*)pc_uniform((const char*)pk.bias);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) acc[f][i] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int fp16 = p.FP * 16, wh16 = p.Wh * 16;
-      const int nsteps_item = p.nslab * PC_TAPS;
+      const int nsteps_item = p.nslab * PC_ROW * p.kt;
       // Registers: 128 accumulators; the weight fragments in THREE rotating sets (a step's four are used by all its MFMAs; the next step's are
       // read right behind the barrier that publishes them; three sets because the loop body below is nine steps long -- no copies, no
       // renaming at the back edge); the position fragments in ONE -- the MFMAs run position-fragment-major, and fragment i of the next step
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) bq[i] = PAB(32) ? *(const frag*)(smem + (hb + rowpos[i])) : frag{};
       }
-      const int nslab = p.nslab;
+      const int nslab = p.nslab, kt = p.kt;
 #ifdef PC_STAMP
       const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -287,10 +287,10 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       for (int sl = 0; sl < nslab; ++sl) {
         const int img = ((gslab + sl) & 1) * halo_bytes;
 #pragma unroll 1
-        for (int dt = 0; dt < 3; ++dt) {
+        for (int dt = 0; dt < kt; ++dt) {
           const int hb = img + dt * fp16;
           // the first step of the next body: the next frame of taps, or the next slab (the other image); behind the item's last body: any valid address
-          const int nb9 = dt < 2 ? hb + fp16 : ((gslab + sl + 1) & 1) * halo_bytes;
+          const int nb9 = dt + 1 < kt ? hb + fp16 : ((gslab + sl + 1) & 1) * halo_bytes;
           step(a0, a1, hb, hb + 16);
           step(a1, a2, hb + 16, hb + 32);
           step(a2, a0, hb + 32, hb + wh16);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       const unsigned long long ste = __builtin_amdgcn_s_memtime();
       if (wave == 0 && lane == 0 && nitem == 1 && blockIdx.x < 512) {
         pc_stamps[blockIdx.x][0] = ste - st0; pc_stamps[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - sr0;
-        pc_stamps[blockIdx.x][2] = (unsigned long long)(nslab * PC_TAPS); pc_stamps[blockIdx.x][3] = (unsigned long long)NI;
+        pc_stamps[blockIdx.x][2] = (unsigned long long)(nslab * PC_ROW * kt); pc_stamps[blockIdx.x][3] = (unsigned long long)NI;
         pc_stamps[blockIdx.x][4] = st0 - sti;             // item set-up: parameter copy, row decode, first position fragments
       }
 #endif
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     int total = 0;
     {
       PcIter c{slot, kp.slots, 0, 0, 0};
-      while (c.next(kp, xcd)) total += kp.m[c.mi].nslab * PC_TAPS;
+      while (c.next(kp, xcd)) total += kp.m[c.mi].nslab * PC_ROW * kp.m[c.mi].kt;
     }
     PcIter it{slot, kp.slots, 0, 0, 0};
     bool have = it.next(kp, xcd);
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       if (it.mi != w_mi) {
         w_mi = it.mi;
         const ConvKP& p = kp.m[it.mi];
-        m_cn = pc_u(p.nslab) * PC_TAPS;
+        m_cn = pc_u(p.nslab) * PC_ROW * pc_u(p.kt);
         m_wstep = (size_t)pc_u(p.cout_frags) * 1024;
         m_w = pc_uniform(p.w); m_sc = pc_uniform((const char*)p.scale); m_bi = pc_uniform((const char*)p.bias);
         m_cout = pc_u(p.cout);
@@ -591,9 +591,17 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
     const char* const zeros = (const char*)flk_zero16;
     const int halo_b = pc_u(kp.halo_bytes);
     const unsigned lds0 = lds_addr32(smem);
+    // what each image holds: (position tile, slab).  A member of TWO slabs alternates its images in step with its channel tiles -- the slab
+    // the next channel tile starts with is still there (Conv3d_2c forward: 64 -> 192, three channel tiles per position tile: two stagings
+    // in three skipped; the (1,3,3) 64 -> 144 of r2plus1d_18 likewise)
+    int held0 = -1, held1 = -1;
     auto begin_slab = [&](const Slab& zn) {
       fresh = pc_u(zn.key != z.key) != 0;
       z = zn;
+      const int tag = (z.key << 3) | (z.s & 7);             // (members of more than 8 slabs never find their slab again anyway)
+      const int held = z.img ? held1 : held0;
+      if (held == tag && z.s < 8) z.nblk = 0;
+      if (z.img) held1 = tag; else held0 = tag;
     };
     // block j of this wave's two planes, slab z
 #define PC_BLK(j)                                                                                                              \
@@ -624,15 +632,18 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     while (true) {
-      const int nslab = pc_u(kp.m[it.mi].nslab);
+      const int nslab = pc_u(kp.m[it.mi].nslab), kt_it = pc_u(kp.m[it.mi].kt);      // slabs of the item being consumed; 27 or 9 K steps per slab
       for (int s = 0; s < nslab; ++s, ++gslab) {
         // slab (it, s) is being consumed out of image gslab & 1; the slab after it goes into the other image while that happens: issued
         // from step 1 on (the image's last reader, the slab before this one, has been read to its end by everyone behind the barrier of
-        // step 1), complete -- vmcnt(0) -- at step 22, four steps before its first reader
+        // step 1) and complete -- vmcnt(0) -- some steps before its first reader.  Straight-line per slab length (a run-time step loop that
+        // picks its blocks cost the 27-step layers 40 %: 181 spilled scalars, v_readlane in front of every compare).
         const bool has_next = s + 1 < nslab || have_nx;
-        if (has_next) {
-          PC_BARRIER();                                   // step 0
-          begin_slab(s + 1 < nslab ? slab_of(it, s + 1, (gslab + 1) & 1) : slab_of(nx, 0, (gslab + 1) & 1));      // (behind the barrier: nobody waits for it)
+        PC_BARRIER();                                     // step 0
+        if (has_next) begin_slab(s + 1 < nslab ? slab_of(it, s + 1, (gslab + 1) & 1) : slab_of(nx, 0, (gslab + 1) & 1));      // (behind the barrier: nobody waits for it)
+        else z.nblk = 0;                                  // (the workgroup's last slab: nothing to stage)
+        if (kt_it == 3) {
+          // 27 steps: one block (two DMAs) per step, complete at step 22
           PC_BARRIER(); PC_BLK(0)                         // step 1
           PC_BARRIER(); PC_BLK(1)
           PC_BARRIER(); PC_BLK(2)
@@ -661,8 +672,16 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
           PC_BARRIER();
           PC_BARRIER();                                   // step 26
         } else {
-#pragma unroll 1
-          for (int j = 0; j < PC_TAPS; ++j) PC_BARRIER();
+          // 9 steps (one frame of taps): four blocks per step, complete at step 7
+          PC_BARRIER(); PC_BLK(0) PC_BLK(1) PC_BLK(2) PC_BLK(3)              // step 1
+          PC_BARRIER(); PC_BLK(4) PC_BLK(5) PC_BLK(6) PC_BLK(7)
+          PC_BARRIER(); PC_BLK(8) PC_BLK(9) PC_BLK(10) PC_BLK(11)
+          PC_BARRIER(); PC_BLK(12) PC_BLK(13) PC_BLK(14) PC_BLK(15)          // step 4
+          PC_BARRIER();
+          PC_BARRIER();
+          PC_BARRIER();                                   // step 7
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          PC_BARRIER();                                   // step 8
         }
       }
       if (!have_nx) break;
@@ -679,7 +698,7 @@ __global__ __launch_bounds__(PC_THREADS, 2) void conv_pc_kernel(const PcKP kp) {
 // position-class bias; weights packed with 64-channel tiles (nf = 4).
 static const char* pc_ineligible(const flk_conv_args* a, const flk_conv_weights* w, int dtype) {
   if (dtype != FLK_BF16 || w->dtype != FLK_BF16) return "bf16 only";
-  if (!(a->kt == 3 && a->kh == 3 && a->kw == 3 && w->kt == 3 && w->kh == 3 && w->kw == 3)) return "3x3x3 taps only";
+  if (!((a->kt == 3 || a->kt == 1) && a->kh == 3 && a->kw == 3 && w->kt == a->kt && w->kh == 3 && w->kw == 3)) return "3x3x3 or 1x3x3 taps only";
   if (!(a->st == 1 && a->sh == 1 && a->sw == 1 && a->ost == 1 && a->osh == 1 && a->osw == 1 && a->oot == 0 && a->ooh == 0 && a->oow == 0 &&
         a->To == a->OT && a->Ho == a->OH && a->Wo == a->OW)) return "stride 1 with a logical == physical output grid only";
   if (a->in2 || a->out2 || a->pos_bias || w->cin_split || w->stem4) return "one input segment, one output segment, no position-class bias";
@@ -694,7 +713,7 @@ static int pc_plan_member(const flk_conv_args* a, const flk_conv_weights* w, int
   kp.scale = a->scale; kp.bias = a->bias; kp.add = (const char*)a->add; kp.mask = (const char*)a->mask;
   kp.in_ld = a->in_ld; kp.in_coff = a->in_coff; kp.cin = a->cin; kp.in2_ld = a->in_ld; kp.in2_coff = a->in_coff; kp.cin1 = a->cin;
   kp.B = a->B; kp.Ti = a->Ti; kp.Hi = a->Hi; kp.Wi = a->Wi;
-  kp.kt = kp.kh = kp.kw = 3; kp.st = kp.sh = kp.sw = 1; kp.pt = a->pt; kp.ph = a->ph; kp.pw = a->pw;
+  kp.kt = a->kt; kp.kh = kp.kw = 3; kp.st = kp.sh = kp.sw = 1; kp.pt = a->pt; kp.ph = a->ph; kp.pw = a->pw;
   kp.To = a->To; kp.Ho = a->Ho; kp.Wo = a->Wo;
   kp.out_ld = a->out_ld; kp.out_coff = a->out_coff; kp.cout = a->cout; kp.cout1 = a->cout;
   kp.OT = a->OT; kp.OH = a->OH; kp.OW = a->OW; kp.ost = kp.osh = kp.osw = 1;
@@ -702,10 +721,10 @@ static int pc_plan_member(const flk_conv_args* a, const flk_conv_weights* w, int
   kp.nslab = w->nslab; kp.nslab1 = w->nslab; kp.ntaps = w->ntaps; kp.cout_frags = w->cout_frags; kp.ntile_n = w->cout_frags / 4;
   kp.ksplit = 1; kp.wn = 1;
   // the tile: the box of <= max_rows rows flk_choose_tile scores best under this kernel's halo budget
-  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, 3, 3, 3, 1, 1, 1, max_rows, 1008);      // (unpadded cells; the padded image is checked below)
+  const flk_tile t = flk_choose_tile(a->To, a->Ho, a->Wo, a->kt, 3, 3, 1, 1, 1, max_rows, 1008);      // (unpadded cells; the padded image is checked below)
   kp.Tt = t.Tt; kp.Ht = t.Ht; kp.Wt = t.Wt; kp.rows = t.Tt * t.Ht * t.Wt;
   kp.nTt = (a->To + t.Tt - 1) / t.Tt; kp.nTh = (a->Ho + t.Ht - 1) / t.Ht; kp.nTw = (a->Wo + t.Wt - 1) / t.Wt;
-  kp.Th = t.Tt + 2; kp.Hh = t.Ht + 2; kp.Wh = t.Wt + 2;
+  kp.Th = t.Tt + a->kt - 1; kp.Hh = t.Ht + 2; kp.Wh = t.Wt + 2;
   const int cells = kp.Hh * kp.Wh;
   // frame pitch / row enumeration with the fewest extra LDS passes per position-fragment read (conv_halo_extra_passes) that fits the image
   int best = force_fp ? 0 : conv_halo_extra_passes(kp, 0, cells), best_t = force_fp ? force_tfast : 0, best_fp = force_fp ? force_fp : cells;
@@ -802,11 +821,11 @@ static int pc_plan(const flk_conv_args* const* a, const flk_conv_weights* const*
       for (int q = j; q < kp.per_xcd; q += kp.slots) {
         int r = q, mi = 0;
         while (mi + 1 < n && r >= kp.cnt[mi]) r -= kp.cnt[mi++];
-        t += (kp.m[mi].nslab * PC_TAPS + 7) * (ni_max / 8.0);
+        t += (kp.m[mi].nslab * PC_ROW * kp.m[mi].kt + 7) * (ni_max / 8.0);
       }
       busiest = std::max(busiest, t);
     }
-    for (int i = 0; i < n; ++i) useful += (double)a[i]->B * a[i]->To * a[i]->Ho * a[i]->Wo / 512.0 * kp.m[i].ntile_n * kp.m[i].nslab * PC_TAPS / 8.0;
+    for (int i = 0; i < n; ++i) useful += (double)a[i]->B * a[i]->To * a[i]->Ho * a[i]->Wo / 512.0 * kp.m[i].ntile_n * kp.m[i].nslab * PC_ROW * kp.m[i].kt / 8.0;
     if (busiest < best_cost) {
       best_cost = busiest; best = kp; ni_best = ni_max;
       if (eff) *eff = useful / (busiest * kp.slots);
@@ -857,11 +876,13 @@ extern "C" int flk_conv3d_pc(const flk_conv_args* const* a, const flk_conv_weigh
   return FLK_OK;
 }
 
-// Should a plan send these convolutions to flk_conv3d_pc?  Eligible members, a modelled efficiency (pc_plan) of at least 0.8 and a busiest
-// workgroup of at least PC_MIN_STEPS full K steps (~0.33 us each): the persistent kernel pays where it keeps the chip full for a while -- the
-// large layers at the benchmark batch -- and loses to conv_igemm_kernel's small workgroups where a launch is a round or two: one 160-KB
-// workgroup per CU cannot start beside the previous kernel's tail, and its first halo image and weights are staged with nothing to hide
-// them (measured: Conv3d_2c at batch 1, ~160 steps, +0.05 ms per launch; FLK_PC_MIN_STEPS overrides the bound for A/B runs).
+// Should a plan send these convolutions to flk_conv3d_pc?  Eligible members, a modelled efficiency (pc_plan: useful share of busiest workgroup x
+// workgroups, the channel tiles' padding included) of at least 0.65 and a busiest workgroup of at least 150 full K steps (~0.3 us each).  The
+// persistent kernel pays where it keeps the chip busy for a while; one 160-KB workgroup per CU cannot start beside the previous kernel's tail and
+// its first halo image and weights are staged with nothing to hide them.  With the register-staged halo of the first form the bounds were 0.8 / 300
+// (Conv3d_2c at batch 1, ~160 steps, lost 0.05 ms per launch); since the LDS-DMA staging (cheaper start, a third of the producers' work) the
+// same sweep reads: I3D bs 8 5.38 -> 5.35 ms per step, I3D bs 1 2.05 -> 1.88, mc3_18 bs 16 4.47 -> 4.37, r2plus1d_18 bs 8 4.17 -> 4.09 (its (1,3,3)
+// layers), and the same within noise for 0.5-0.65 / 60-180.  FLK_PC_MIN_STEPS / FLK_PC_MIN_EFF override the bounds for A/B runs.
 extern "C" int flk_conv3d_pc_worthwhile(const flk_conv_args* const* a, const flk_conv_weights* const* w, int n, int dtype) {
   if (!a || !w || n < 1 || n > PC_MAX_MEMBERS) return 0;
   for (int i = 0; i < n; ++i)
@@ -871,8 +892,8 @@ extern "C" int flk_conv3d_pc_worthwhile(const flk_conv_args* const* a, const flk
   double eff = 0;
   double steps = 0;
   if (pc_plan(a, w, n, dtype, kp, ni, &eff, &steps) != FLK_OK) return 0;
-  static const double min_steps = getenv("FLK_PC_MIN_STEPS") ? atof(getenv("FLK_PC_MIN_STEPS")) : 300.0;
-  static const double min_eff = getenv("FLK_PC_MIN_EFF") ? atof(getenv("FLK_PC_MIN_EFF")) : 0.8;
+  static const double min_steps = getenv("FLK_PC_MIN_STEPS") ? atof(getenv("FLK_PC_MIN_STEPS")) : 150.0;
+  static const double min_eff = getenv("FLK_PC_MIN_EFF") ? atof(getenv("FLK_PC_MIN_EFF")) : 0.65;
   return eff >= min_eff && steps >= min_steps;
 }
 

@@ -101,8 +101,8 @@ def test_producer_consumer_routing_model_without_gpu(lib):
     """flk_conv3d_pc_query: what flk_conv3d / flk_conv3d_group send to the persistent producer / consumer kernel (csrc/conv_pc.hip), decided on
     the host from the geometry.  Conv3d_2c_3x3 (i3d.py:183-186) at half the benchmark batch: forward 64 -> 192 on 8x7x8 boxes (448 rows) -- 11 rounds of
     seven eighths the length beat 10 rounds of 8x8x8 -- and its data-gradient 192 -> 64 likewise (3.5 -> 4 rounds instead of 3.06 -> 4); the
-    same layer at batch 1 stays on conv_igemm_kernel (a round or two of items: the persistent launch cannot hide its start-up), as do strided
-    and non-3x3x3 convolutions (refused with the reason)."""
+    same layer at batch 1 (160 K steps) is routed too since the halo is staged by LDS-DMA, a single round of short items (Mixed_4*) is not;
+    (1,3,3) taps are taken, strided and other tap shapes refused with the reason."""
     import ctypes as C
     from flickering_adversarial_video_amd import _lib
 
@@ -128,10 +128,14 @@ def test_producer_consumer_routing_model_without_gpu(lib):
     rc, tile, ni, eff, steps = query(conv(4, 32, 56, 56, 192, 64))
     assert rc == 1 and tile == (8, 7, 8) and ni == 7, (rc, tile, ni, eff, steps)
     rc, tile, ni, eff, steps = query(conv(1, 32, 56, 56, 64, 192))
-    assert rc == 0 and steps < 300, (rc, tile, ni, eff, steps)                      # batch 1: too short a launch
+    assert rc == 1 and 150 <= steps < 170, (rc, tile, ni, eff, steps)               # batch 1: 160 steps -- routed since the LDS-DMA halo staging (bound 150; 300 before)
     rc, tile, ni, eff, steps = query(conv(8, 32, 28, 28, 128, 192), conv(8, 32, 28, 28, 32, 96))      # Mixed_3c Branch_1 + Branch_2 (i3d.py:229-238)
     assert rc == 1 and tile[0] * tile[1] * tile[2] == 448 and 28 % tile[1] == 0 and 28 % tile[2] == 0 and ni == 7 and eff > 0.8, (rc, tile, ni, eff, steps)
     rc = query(conv(8, 16, 14, 14, 96, 208))[0]
-    assert rc == 0                                                                   # Mixed_4*: a single round of items
+    assert rc == 0                                                                   # Mixed_4*: a single round of items (77 steps)
+    a133 = conv(8, 16, 56, 56, 64, 144)                                              # the spatial half of r2plus1d_18's layer1 units (Conv2Plus1D, model.py:421): (1,3,3) taps
+    a133.kt, a133.pt = 1, 0
+    rc, tile, ni, eff, steps = query(a133)
+    assert rc == 1 and tile[0] * tile[1] * tile[2] == 448 and ni == 7 and eff > 0.65 and steps > 150, (rc, tile, ni, eff, steps)
     assert query(conv(4, 32, 56, 56, 64, 192, k=1))[0] == -1 and b"3x3x3" in lib.flk_last_error()
     assert query(conv(4, 32, 56, 56, 64, 192, stride=2))[0] == -1 and b"stride" in lib.flk_last_error()

@@ -680,6 +680,10 @@ PC_CASES = [
     ("group_dgrad_128_96+32_16", 1, 16, 14, 14, [(128, 96), (32, 16)], True),   # narrow outputs: 16 channels in a 64-wide tile
     ("ragged_40_72_partial_tiles", 3, 5, 9, 11, [(40, 72)], False),             # 40 input channels (a half-valid slab), grid not a multiple of any tile, several clips
     ("one_slab_16_32", 1, 8, 8, 8, [(16, 32)], False),                          # a 27-step item: fewer steps in flight than the ring is deep for the prologue
+    # (1,3,3) taps -- the spatial half of a (2+1)D unit (torchvision Conv2Plus1D, model.py:421): 9-step slabs, no temporal halo
+    ("k133_fwd_64_144", 2, 8, 28, 28, [(64, 144)], False, 1),                   # r2plus1d layer1's 64 -> 144: two slabs, 144 = 2.25 channel tiles
+    ("k133_dgrad_144_64", 1, 8, 28, 28, [(144, 64)], True, 1),                  # its data-gradient: five slabs (the last half-valid), ReLU mask
+    ("k133_one_slab_ragged", 2, 3, 9, 10, [(24, 40)], False, 1),                # one 9-step slab per item, partial tiles
 ]
 
 
@@ -689,7 +693,9 @@ def test_conv_pc(ops, case):
     oracle (bf16 tolerances) with the epilogue the plan uses -- scale, bias, ReLU forward; transposed weights x BN scale, ReLU mask in the
     data-gradient -- and BITWISE against flk_conv3d on the same packed weights (same K order per output, same epilogue); a second run gives
     the same bits (no ordering inside the kernel decides a value)."""
-    _, B, T, H, W, mem, tr = case
+    _, B, T, H, W, mem, tr = case[:7]
+    kt = case[7] if len(case) > 7 else 3
+    pt = (kt - 1) // 2
     dtype = torch.bfloat16
     ci_tot = sum(c[0] for c in mem)
     co_tot = sum(c[1] for c in mem) + 8
@@ -702,20 +708,20 @@ def test_conv_pc(ops, case):
     in_off, out_off = 0, 8
     for i, (cin, cout) in enumerate(mem):
         if tr:      # the data-gradient operator of a forward layer cout -> cin: G (cin channels here) -> gx (cout channels), BN scale folded
-            w_fwd = q(rnd((3, 3, 3, cout, cin), 20 + i, (2.0 / (27 * cout)) ** 0.5), dtype)
+            w_fwd = q(rnd((kt, 3, 3, cout, cin), 20 + i, (2.0 / (9 * kt * cout)) ** 0.5), dtype)
             sc = rnd((cin,), 30 + i).abs() + 0.5
             g = xin[..., in_off:in_off + cin].contiguous()
             x0 = torch.zeros((B, T, H, W, cout), requires_grad=True)
-            y = ref_conv(x0, w_fwd, (1, 1, 1), (1, 1, 1), (T, H, W)) * sc
+            y = ref_conv(x0, w_fwd, (1, 1, 1), (pt, 1, 1), (T, H, W)) * sc
             (ref,) = torch.autograd.grad(y, x0, g)
             ref = ref * (maskt[..., out_off:out_off + cout] > 0)
             pw = ops.ConvWeights(w_fwd.numpy(), dtype, 4, transpose=True, row_scale=sc.numpy())
             kw = dict(in_coff=in_off, cin=cin, out_coff=out_off, mask=maskt.to(dtype).cuda(), mask_coff=out_off)
         else:
-            w = q(rnd((3, 3, 3, cin, cout), 20 + i, (2.0 / (27 * cin)) ** 0.5), dtype)
+            w = q(rnd((kt, 3, 3, cin, cout), 20 + i, (2.0 / (9 * kt * cin)) ** 0.5), dtype)
             sc = rnd((cout,), 30 + i).abs() + 0.5
             bi = rnd((cout,), 40 + i, 0.1)
-            ref = torch.relu(ref_conv(xin[..., in_off:in_off + cin].contiguous(), w, (1, 1, 1), (1, 1, 1), (T, H, W)) * sc + bi)
+            ref = torch.relu(ref_conv(xin[..., in_off:in_off + cin].contiguous(), w, (1, 1, 1), (pt, 1, 1), (T, H, W)) * sc + bi)
             pw = ops.ConvWeights(w.numpy(), dtype, 4)
             kw = dict(in_coff=in_off, cin=cin, out_coff=out_off, scale=sc.cuda(), bias=bi.cuda(), relu=True)
         refs.append((ref, out_off, cout))

@@ -1,7 +1,7 @@
 """Time ONE convolution geometry in isolation (20 launches x 5 repetitions after a 20-launch warm-up; min / median).
 A/B different builds or env knobs by alternating processes -- single measurements inside a long run drift with the clock state.
 
-usage: conv_time.py k cin cout nf B T H W [T]      (k x k x k taps, stride 1 SAME; a trailing argument = data-gradient)
+usage: conv_time.py k cin cout nf B T H W [T]      (k x k x k taps, stride 1 SAME; a trailing argument = data-gradient; KT=1 in the environment: 1 x k x k)
 PC=1 in the environment: the launch goes to flk_conv3d_pc (the producer / consumer kernel; 3x3x3, nf 4) instead of flk_conv3d."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,10 +11,11 @@ kt, cin, cout, nf, B, T, H, W = (int(v) for v in sys.argv[1:9])
 tr = len(sys.argv) > 9
 torch.manual_seed(0)
 x = torch.randn(B, T, H, W, cout if tr else cin, device="cuda").to(torch.bfloat16)
-w = (np.random.default_rng(0).standard_normal((kt, kt, kt, cin, cout)) * 0.05).astype(np.float32)
+kt0 = int(os.environ.get("KT", kt))      # KT=1: (1, k, k) taps -- the spatial half of a (2+1)D unit
+w = (np.random.default_rng(0).standard_normal((kt0, kt, kt, cin, cout)) * 0.05).astype(np.float32)
 pw = ops.ConvWeights(w, torch.bfloat16, nf, transpose=tr)
 out = torch.empty(B, T, H, W, cin if tr else cout, device="cuda", dtype=torch.bfloat16)
-pad = tuple([kt - 1 - (kt - 1) // 2] * 3) if tr else None
+pad = (kt0 - 1 - (kt0 - 1) // 2, kt - 1 - (kt - 1) // 2, kt - 1 - (kt - 1) // 2) if tr else None
 splitk = bool(int(os.environ.get("SPLITK", "0")))      # give the launch a split-K workspace (FLK_CONV_KSPLIT forces the slice count)
 if splitk:
     ref = ops.conv3d(x, pw, pad=pad, out_grid=(T, H, W)).float()
