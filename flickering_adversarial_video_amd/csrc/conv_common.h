@@ -200,6 +200,88 @@ __device__ static inline void finish_store_row(const ConvKP& p, size_t opos, con
   }
 }
 
+// ---- the epilogue in two halves, so that a caller can request the add / mask operands of SEVERAL output positions before it finishes the
+// first: called position by position (finish_store_row*), the operand loads of position i + 1 sit behind the stores of position i -- the
+// compiler must assume they alias -- and a wave pays one memory round trip per position with nothing else to do (four per tile in the
+// halo and LDS-DMA kernels, four times the store groups in conv_igemm_body's first form: a data-gradient's ReLU mask comes from HBM).
+// epi_fetch: the operands of one position's NG store groups (a group past cout reads the row's first channels: valid memory, never used).
+template <typename T, int NG>
+__device__ static inline void epi_fetch(const ConvKP& p, size_t opos, int c0, uint4 (&av)[NG], uint4 (&mv)[NG]) {
+  constexpr int EPL = Prec<T>::EPL;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = c0 + g * 4 * EPL;
+    const bool in = c < p.cout;
+    av[g] = make_uint4(0u, 0u, 0u, 0u); mv[g] = av[g];
+    if (p.add) av[g] = *(const uint4*)(p.add + (opos * p.add_ld + p.add_coff + (in ? c : 0)) * sizeof(T));
+    if (p.mask) mv[g] = *(const uint4*)(p.mask + (opos * p.mask_ld + p.mask_coff + (in ? c : 0)) * sizeof(T));
+  }
+}
+// finish_store for the NG store groups of one position with scale / bias in registers (sc / bi: EPL / 4 float4 per group) and the add / mask
+// operands fetched: acc * scale, + bias (two roundings: epi_scale_bias), + position-class bias, + add, ReLU, mask, store -- finish_store's order
+// (SB = false: the caller has applied scale and bias to the accumulators already)
+template <typename T, int NG, bool SB = true>
+__device__ static inline void finish_store_row_ops(const ConvKP& p, size_t opos, const float* pb, int c0, float (&v)[NG][Prec<T>::EPL],
+                                                   const float4 (&sc)[NG][Prec<T>::EPL / 4], const float4 (&bi)[NG][Prec<T>::EPL / 4],
+                                                   const uint4 (&av)[NG], const uint4 (&mv)[NG]) {
+  typedef Prec<T> PR;
+  constexpr int EPL = PR::EPL;
+  const bool hs = p.scale != nullptr, hb = p.bias != nullptr;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = c0 + g * 4 * EPL;
+    if (c >= p.cout) continue;
+    float* w = v[g];
+    if constexpr (SB) {
+#pragma unroll
+      for (int h = 0; h < EPL / 4; ++h) {
+        const int e = 4 * h;
+        w[e] = epi_scale_bias(w[e], sc[g][h].x, bi[g][h].x, hs, hb); w[e + 1] = epi_scale_bias(w[e + 1], sc[g][h].y, bi[g][h].y, hs, hb);
+        w[e + 2] = epi_scale_bias(w[e + 2], sc[g][h].z, bi[g][h].z, hs, hb); w[e + 3] = epi_scale_bias(w[e + 3], sc[g][h].w, bi[g][h].w, hs, hb);
+      }
+    }
+    if (pb) {
+#pragma unroll
+      for (int e = 0; e < EPL; e += 4) {
+        const float4 t4 = *(const float4*)(pb + c + e);
+        w[e] += t4.x; w[e + 1] += t4.y; w[e + 2] += t4.z; w[e + 3] += t4.w;
+      }
+    }
+    if (p.add) {
+      float a[EPL];
+      PR::to_f32(av[g], a);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] += a[e];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] = fmaxf(w[e], 0.f);
+    }
+    if (p.mask) {
+      float a[EPL];
+      PR::to_f32(mv[g], a);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) w[e] = a[e] > 0.f ? w[e] : 0.f;
+    }
+    if (c < p.cout1) *(uint4*)(p.out + (opos * p.out_ld + p.out_coff + c) * sizeof(T)) = PR::from_f32(w);
+    else *(uint4*)(p.out2 + (opos * p.out2_ld + p.out2_coff + (c - p.cout1)) * sizeof(T)) = PR::from_f32(w);
+  }
+}
+// scale / bias of a lane's NG store groups (a group past cout: the first channels, never used; absent: 1 / 0)
+template <typename T, int NG>
+__device__ static inline void epi_scale_bias_regs(const ConvKP& p, int c0, float4 (&sc)[NG][Prec<T>::EPL / 4], float4 (&bi)[NG][Prec<T>::EPL / 4]) {
+  constexpr int EPL = Prec<T>::EPL;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int c = c0 + g * 4 * EPL, cc = c < p.cout ? c : 0;
+#pragma unroll
+    for (int h = 0; h < EPL / 4; ++h) {
+      sc[g][h] = p.scale ? *(const float4*)(p.scale + cc + 4 * h) : make_float4(1.f, 1.f, 1.f, 1.f);
+      bi[g][h] = p.bias ? *(const float4*)(p.bias + cc + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
 // finish_store_row with the batch-norm scale / bias of the lane's NG store groups already in registers (loaded once per lane: inside the
 // row loop hipcc re-requests them behind every store -- it must assume they alias the output -- and waits for each)
 template <typename T, int NG>

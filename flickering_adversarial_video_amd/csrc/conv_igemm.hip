@@ -654,6 +654,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvKP& p, const int bx, c
   // store group g of this wave = global group wn*NG + g: channels ntile*16NF + (wn*NG + g)*4*EPL + q*EPL + [0, EPL)
   constexpr int NG = 4 * NFW / EPL;   // 16-byte channel groups per lane
   const int cbase = ntile * 16 * NFT + wn * NG * 4 * EPL + q * EPL;
+  // (Position by position, store group by store group.  Measured and not kept, round 5: scale / bias once per lane + the add / mask operands
+  //  of two positions in flight, as in the LDS-DMA kernels below -- Mixed_4 data-gradients 0 ... -3 %, but the late VideoResNet layers at
+  //  batch 1 (8-70 workgroups, pure latency chains) +18 %, r2plus1d_18 bs 1 2.16 -> 2.30 ms: hipcc schedules this form's loads earlier.)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = wm * 64 + i * 16 + m;
@@ -877,17 +880,40 @@ __global__ __launch_bounds__(256, 2) void conv1x1_dma_kernel(const ConvKP p) {
       }
     }
   }
+  if constexpr (PRE) {
+    // the add / mask operands of two positions in flight (conv_common.h, epi_fetch): two memory round trips per tile, not four
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned pos = pos0 + (unsigned)(64 * wave + 16 * i + m);
-    if (pos >= npos) continue;
-    float v[NG][EPL];
+    for (int i0 = 0; i0 < 4; i0 += 2) {
+      unsigned pos[2];
+      uint4 av[2][NG], mv[2][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+      for (int u = 0; u < 2; ++u) {
+        pos[u] = pos0 + (unsigned)(64 * wave + 16 * (i0 + u) + m);
+        epi_fetch<bf16_t, NG>(p, (size_t)(pos[u] < npos ? pos[u] : 0u), cbase, av[u], mv[u]);
+      }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
-    if constexpr (PRE) finish_store_row_pre<bf16_t, NG>(p, (size_t)pos, cbase, v, sc, bi);
-    else finish_store_row<bf16_t, NG>(p, (size_t)pos, nullptr, cbase, v);
+      for (int u = 0; u < 2; ++u) {
+        if (pos[u] >= npos) continue;
+        float v[NG][EPL];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i0 + u][(g * EPL + e) & 3];
+        finish_store_row_ops<bf16_t, NG>(p, (size_t)pos[u], nullptr, cbase, v, sc, bi, av[u], mv[u]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned pos = pos0 + (unsigned)(64 * wave + 16 * i + m);
+      if (pos >= npos) continue;
+      float v[NG][EPL];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
+      finish_store_row<bf16_t, NG>(p, (size_t)pos, nullptr, cbase, v);
+    }
   }
 }
 
@@ -1028,16 +1054,35 @@ __global__ __launch_bounds__(256, 1) void conv_t3_dma_kernel(const ConvKP p) {
       }
     }
   }
+  if constexpr (PRE) {
+    // the add / mask operands of two fragments in flight (conv_common.h, epi_fetch)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (!fvalid[i]) continue;
-    float v[NG][EPL];
+    for (int i0 = 0; i0 < 4; i0 += 2) {
+      uint4 av[2][NG], mv[2][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+      for (int u = 0; u < 2; ++u) epi_fetch<bf16_t, NG>(p, (size_t)fpos[i0 + u], cbase, av[u], mv[u]);      // (a clamped group: valid memory, not stored)
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
-    if constexpr (PRE) finish_store_row_pre<bf16_t, NG>(p, (size_t)fpos[i], cbase, v, sc, bi);
-    else finish_store_row<bf16_t, NG>(p, (size_t)fpos[i], nullptr, cbase, v);
+      for (int u = 0; u < 2; ++u) {
+        if (!fvalid[i0 + u]) continue;
+        float v[NG][EPL];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i0 + u][(g * EPL + e) & 3];
+        finish_store_row_ops<bf16_t, NG>(p, (size_t)fpos[i0 + u], nullptr, cbase, v, sc, bi, av[u], mv[u]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!fvalid[i]) continue;
+      float v[NG][EPL];
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[g][e] = acc[(g * EPL + e) >> 2][i][(g * EPL + e) & 3];
+      finish_store_row<bf16_t, NG>(p, (size_t)fpos[i], nullptr, cbase, v);
+    }
   }
 }
 
