@@ -409,6 +409,24 @@ def test_conv_two_segment_output_and_input(ops, dtype):
     torch.testing.assert_close(gx.float().cpu(), gx_ref, rtol=r * 2, atol=a * 2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv_multi_tap_two_input_segments_large_halo(ops, dtype):
+    """A 3x3x3 convolution whose input channels come from TWO buffers (in / in2, weights packed with cin_split) on a grid large enough for a
+    > 256-cell halo: the large-halo forms of conv_igemm_kernel stage by LDS-DMA with per-lane source addresses since round 5, and the source
+    segment (base pointer, channel stride, valid chunks) changes from slab to slab.  Against the torch-CPU oracle on the concatenated input."""
+    B, T, H, W = 1, 6, 18, 20
+    c0, c1, cout = 40, 24, 48            # 40: the first segment's last slab is half valid (bf16 slab = 32 channels, fp32 = 16)
+    xa, xb = q(rnd((B, T, H, W, c0 + 8), 51), dtype), q(rnd((B, T, H, W, c1), 52), dtype)
+    w = q(rnd((3, 3, 3, c0 + c1, cout), 53, (2.0 / (27 * (c0 + c1))) ** 0.5), dtype)
+    sc, bi = rnd((cout,), 54).abs() + 0.5, rnd((cout,), 55) * 0.1
+    x = torch.cat([xa[..., 8:], xb], -1)
+    ref = torch.relu(ref_conv(x, w, (1, 1, 1), (1, 1, 1), (T, H, W)) * sc + bi)
+    pw = ops.ConvWeights(w.numpy(), dtype, 4, cin_split=c0)
+    y = ops.conv3d(xa.to(dtype).cuda(), pw, in_coff=8, cin=c0 + c1, in2=xb.to(dtype).cuda(), in2_coff=0, scale=sc.cuda(), bias=bi.cuda(), relu=True)
+    r, a = tol(dtype, ref)
+    torch.testing.assert_close(y.float().cpu(), ref, rtol=r, atol=a)
+
+
 @pytest.mark.parametrize("nf", [4, 6, 8])
 def test_conv1x1_dma_ring_all_features(ops, nf):
     """conv1x1_dma_kernel (bf16 1x1x1 GEMMs of >= 2048 positions: both operands through the LDS-DMA ring) with everything the fused
