@@ -1,6 +1,6 @@
-// 3x3x3 stride-1 convolution (Unit3D forward and data-gradient of the large I3D layers: Conv3d_2c_3x3 and the Mixed_3* Branch_1 /
-// Branch_2 units, i3d.py:183-186, 200-209, 229-238; the 3x3x3 layers of r3d_18 / mc3_18 at large batches) with WAVE-SPECIALISED producers
-// -- bf16 only, round 5.
+// 3x3x3 and 1x3x3 stride-1 convolution (Unit3D forward and data-gradient of the large I3D layers: Conv3d_2c_3x3 and the Mixed_3* Branch_1 /
+// Branch_2 units, i3d.py:183-186, 200-209, 229-238; the 3x3x3 layers of r3d_18 / mc3_18 and the spatial halves of r2plus1d_18's layer1 units
+// -- torchvision Conv2Plus1D, model.py:421 -- at large batches) with WAVE-SPECIALISED producers -- bf16 only, round 5.
 //
 // conv_igemm_kernel (conv_igemm.hip) runs 256-thread workgroups in which every wave loads, stages and multiplies; three of them share a
 // CU, and its ablations (DESIGN_LOG.md, "ring write behind the barrier") show a launch costing the SUM of its memory phase and its MFMA
@@ -23,8 +23,9 @@
 // k + 1 (landed: the streaming waves waited for them) and, before a slab's first read, its halo image; it frees the ring slot of step k - 1
 // and, one step into a slab, the image of the slab before it.  Producers arrive early and wait.
 // Same products, same K order per output (slab-major, taps t-h-w) and the same epilogue as conv_igemm_kernel: bitwise its results.
-// Measured (MI355X, round 5): Conv3d_2c forward at half the benchmark batch 0.239 -> 0.218 ms (1 220 TFLOP/s), its data-gradient
-// 0.233 -> 0.215; in-kernel clock 1.9-2.1 GHz, 605-620 cycles per K step for 448 of MFMA issue; SQ MFMA busy 0.52 (conv_igemm_kernel 0.41-0.44).
+// Measured (MI355X, round 5): Conv3d_2c forward at half the benchmark batch 0.239 (conv_igemm_kernel) -> 0.218 (register-staged
+// halo) -> 0.203 ms (LDS-DMA halo: 1 300 TFLOP/s), its data-gradient 0.233 -> 0.215 -> 0.188 (1 420); in-kernel clock 1.9-2.1 GHz, 605-620
+// cycles per K step for 448 of MFMA issue; SQ MFMA busy 0.56 (conv_igemm_kernel 0.41-0.44).
 #include <stdlib.h>
 #include <algorithm>
 #include <array>
